@@ -1,0 +1,249 @@
+#!/usr/bin/env python
+"""Benchmark of the Block Transformer decode path on MI355X (driver contract: see the repo prompt / DESIGN.md §Measurement).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One *step* = one full ``BlockTransformer.generate`` over one batch of synthetic prompts, timed the way the reference's
+``measure_generation_time.py:131-161`` times it: prefill + decode, random ids, random-init weights of the named
+architecture, EOS disabled, greedy.  Workload at N=1 (BASELINE.json configs[1]): block_main_b4_1.2b, bf16, prefill 2048 /
+decode 128.  For N > 1 every rank runs the same per-GPU batch on its own request shard (weak scaling, no data-path
+collective; RCCL only for the barrier and the max/sum reductions).
+
+Prints ONE JSON line on rank 0.  ``value`` = decoded tokens / second for the whole job = N * B * D / max-over-ranks time.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from block_transformer_amd import _lib, parallel  # noqa: E402
+from block_transformer_amd.config import get_max_length, named_dims  # noqa: E402
+from block_transformer_amd.model.utils import load_block_transformer_from_dims  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 measured copy ceiling
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak
+
+
+def algorithmic_counts(dims, B: int, P: int, D: int, itemsize: int = 2):
+    """Algorithmic flops / bytes of one generate() (SURVEY.md section 8d formulas, per kernel family).
+
+    linear flops  = 2*M*N*K summed over every bt_linear launch (prefill chunks, block-decoder steps, token-decoder
+                    steps, expansion, logits);
+    attn_rows bytes = K and V rows streamed by the row-wise attention kernel (global steps + local windows);
+    attn_flash flops = 4 * d * (causal pairs) per head (QK^T and PV)."""
+    L, E, V = dims.L, dims.E, dims.vocab
+    bd, td = dims.bd, dims.td
+    nb = math.ceil(P / L)
+    max_length = nb * L + D
+    total_blocks = nb
+    n_tok_blocks = 0
+    while True:
+        n_tok_blocks += 1
+        total_blocks += 1
+        if total_blocks * L >= max_length:
+            break
+    n_roll = n_tok_blocks - 1
+
+    def stack_flops(d, rows):
+        return 2 * rows * d.layers * (3 * d.hidden * d.hidden + d.hidden * d.hidden + 2 * d.hidden * d.inter)
+
+    lin = stack_flops(bd, B * nb)                                   # prefill
+    lin += n_roll * stack_flops(bd, B)                              # block-decoder steps
+    per_block_td = stack_flops(td, B * E) + (L - 1) * stack_flops(td, B)
+    per_block_td += 2 * B * (E * td.hidden) * bd.hidden             # expansion
+    per_block_td += L * 2 * B * V * td.hidden                       # logits
+    lin += n_tok_blocks * per_block_td
+    # row-wise attention bytes: global steps read n_k K rows + n_k V rows per (b, head); n_k = nb+1 .. nb+n_roll
+    kv_row = bd.hidden * itemsize                                   # one position, all heads, K or V
+    glob = sum(2 * B * bd.layers * kv_row * (nb + 1 + i) for i in range(n_roll))
+    local_keys = sum(range(1, E + 1)) + sum(E + t for t in range(1, L))   # keys read per block per (b, head)
+    loc = n_tok_blocks * 2 * B * td.layers * td.hidden * itemsize * local_keys
+    flash = 4 * B * bd.layers * bd.hidden * (nb * (nb + 1) // 2)
+    return {"linear_flops": float(lin), "attn_rows_bytes": float(glob + loc), "attn_rows_global_bytes": float(glob),
+            "attn_flash_flops": float(flash), "n_tok_blocks": n_tok_blocks, "n_roll": n_roll, "nb": nb}
+
+
+def build_model(dims, dtype_name: str, device, seed: int):
+    torch.manual_seed(seed)
+    with torch.device(device):
+        model = load_block_transformer_from_dims(dims, dtype_name, keep_unused_embed_in=False)
+    model.eval()
+    # benchmark protocol (reference measure_generation_time.py:82-90): pad 1, eos 0, generation EOS disabled, greedy
+    model.token_decoder.config.pad_token_id = 1
+    model.token_decoder.config.eos_token_id = 0
+    model.token_decoder.generation_config.eos_token_id = None
+    return model
+
+
+def cpu_baseline(model, dims, sample_prefill: int, sample_decode: int):
+    """The CPU oracle (a port of the reference's eager path) timed on this box's host cores, on a bounded sample of
+    the same workload: same weights (copied from the GPU model, fp32), batch 1."""
+    from oracle.cpu_ref import oracle_from_dims
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    o = oracle_from_dims(dims, sd, pad_token_id=1)
+    ids = torch.randint(0, dims.vocab, (1, sample_prefill), generator=torch.Generator().manual_seed(0))
+    ml = get_max_length(dims.L, sample_prefill, sample_decode)
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        out = o.generate(ids, max_length=ml)
+    dt = time.perf_counter() - t0
+    return {"value": sample_decode / dt, "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"batch 1, prefill {sample_prefill} / decode {sample_decode} of the same model (fp32 eager "
+                      f"PyTorch, {cores} threads), {dt:.1f} s",
+            "seconds": dt}, out, ids
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="block_main_b4_1.2b")
+    ap.add_argument("--prefill", type=int, default=2048)
+    ap.add_argument("--decode", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=1024, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--seed", type=int, default=1234)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--cpu-sample", default="128,32", help="prefill,decode of the CPU baseline sample")
+    args = ap.parse_args()
+
+    rank, world, local = parallel.init_distributed()
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the decode path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    dims = named_dims(args.config)
+    B, P, D, L = args.batch, args.prefill, args.decode, dims.L
+    max_length = get_max_length(L, P, D)
+
+    model = build_model(dims, args.dtype, device, args.seed)   # same weights on every rank (replicated)
+    model.use_graphs = not args.no_graphs
+    gen = torch.Generator().manual_seed(args.seed + 1000 * rank)
+    input_ids = torch.randint(0, dims.vocab, (B, P), generator=gen).to(device)
+
+    def step():
+        return model.generate(input_ids, max_length=max_length)
+
+    for _ in range(args.warmup):
+        out = step()
+    parallel.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    parallel.barrier()
+    elapsed = time.perf_counter() - t0
+    assert out.shape == (B, max_length), out.shape
+    elapsed = parallel.max_over_ranks(elapsed)
+    ms_per_step = elapsed / args.steps * 1e3
+    tokens_per_step = parallel.sum_over_ranks(B * D)
+    value = tokens_per_step / (ms_per_step / 1e3)
+
+    result = {
+        "metric": "decoded_tokens_per_sec_per_node", "value": value, "unit": "tokens/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"{args.config} prefill{P}/decode{D}, greedy, EOS disabled, end-to-end generate() "
+                               f"(prefill + decode) as in measure_generation_time.py",
+                   "batch_per_gpu": B, "global_batch": B * world, "prefill": P, "decode": D, "block_length": L,
+                   "parallelism": f"dp{world} request shards", "hipgraph": model.use_graphs},
+    }
+
+    if rank == 0:
+        # phase split (one extra generate with hipEvent phase marks): decode-phase-only throughput
+        model.collect_timers = True
+        model.generate(input_ids, max_length=max_length)
+        model.collect_timers = False
+        tm = model.last_timers
+        prefill_ms = tm.ms("prefill_start", "decode_start")
+        decode_ms = tm.ms("decode_start", "decode_end")
+        result["prefill_ms"] = prefill_ms
+        result["decode_ms"] = decode_ms
+        result["decode_phase_tokens_per_s_per_gpu"] = B * D / (decode_ms / 1e3)
+
+    if rank == 0 and not args.no_roofline:
+        # per-kernel-family GPU time of ONE generate, launched eagerly with a hipEvent pair around every kernel on the
+        # launch stream (libbt_hip's built-in timer), against the algorithmic flops/bytes of the same generate
+        counts = algorithmic_counts(dims, B, P, D, 2 if args.dtype == "bf16" else 4)
+        model.use_graphs = False
+        _lib.prof_enable(True)
+        model.generate(input_ids, max_length=max_length)
+        torch.cuda.synchronize()
+        fam = _lib.prof_collect()
+        _lib.prof_enable(False)
+        model.use_graphs = not args.no_graphs
+        fam_ms = {k: round(v[0], 3) for k, v in fam.items() if v[1]}
+        fam_n = {k: int(v[1]) for k, v in fam.items() if v[1]}
+        result["kernel_family_ms"] = fam_ms
+        result["kernel_family_launches"] = fam_n
+        dominant = max(fam_ms, key=fam_ms.get)
+        pmc = {}
+        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc_path):
+            pmc = json.load(open(pmc_path))
+
+        def roof(name):
+            ms, n = fam[name]
+            if name in ("linear_mfma", "linear_generic"):
+                ach = counts["linear_flops"] / (ms / 1e3) / 1e12
+                return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
+                        "traffic": pmc.get(name), "launches": int(n), "avg_launch_us": ms / n * 1e3,
+                        "algorithmic_per_launch": counts["linear_flops"] / n}
+            if name == "attn_flash":
+                ach = counts["attn_flash_flops"] / (ms / 1e3) / 1e12
+                return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc.get(name),
+                        "launches": int(n), "avg_launch_us": ms / n * 1e3,
+                        "algorithmic_per_launch": counts["attn_flash_flops"] / n}
+            if name == "attn_rows":
+                ach = counts["attn_rows_bytes"] / (ms / 1e3) / 1e9
+                return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": pmc.get(name), "launches": int(n),
+                        "avg_launch_us": ms / n * 1e3, "algorithmic_per_launch": counts["attn_rows_bytes"] / n}
+            return {"kernel": name, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": None, "traffic": None, "launches": int(n), "avg_launch_us": ms / n * 1e3}
+
+        result["roofline"] = roof(dominant)
+        if "attn_rows" in fam_ms and dominant != "attn_rows":
+            result["roofline_global_attention"] = roof("attn_rows")   # the north-star HBM-bound global path
+        if "linear_mfma" in fam_ms and dominant != "linear_mfma":
+            result["roofline_linear"] = roof("linear_mfma")
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        sp, sdn = (int(v) for v in args.cpu_sample.split(","))
+        model.release_buffers()
+        base, cpu_out, cpu_ids = cpu_baseline(model, dims, sp, sdn)
+        # parity on identical inputs, same run: GPU greedy tokens vs the CPU eager path (bf16 vs fp32: agreement rate)
+        gpu_out = model.generate(cpu_ids.to(device), max_length=cpu_out.shape[1]).cpu()
+        base["gpu_vs_cpu_token_agreement"] = float((gpu_out[:, sp:] == cpu_out[:, sp:]).float().mean())
+        result["cpu_baseline"] = base
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        parallel.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

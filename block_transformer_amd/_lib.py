@@ -1,0 +1,143 @@
+"""ctypes binding of libbt_hip.so (include/bt_hip.h).  The HIP extension is mandatory: there is no CPU or PyTorch
+fallback for the decode arithmetic — a missing library or a non-GPU tensor raises."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
+
+import torch  # noqa: F401  (must be imported first: libbt_hip.so binds to the HIP runtime torch already loaded)
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbt_hip.so")
+
+BT_F32, BT_BF16 = 0, 1
+BT_ACT_NONE, BT_ACT_GELU = 0, 1
+ATTN_ROWS, ATTN_FLASH = 0, 1
+
+
+class BtError(RuntimeError):
+    pass
+
+
+class bt_decoder_dims(Structure):
+    _fields_ = [("hidden", c_int32), ("heads", c_int32), ("head_dim", c_int32), ("rot", c_int32),
+                ("inter", c_int32), ("layers", c_int32), ("ln_eps", c_float)]
+
+
+class bt_layer_weights(Structure):
+    _fields_ = [(n, c_void_p) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "qkv_w", "qkv_b", "dense_w", "dense_b",
+                                        "h4_w", "h4_b", "h_w", "h_b")]
+
+
+class bt_decoder_weights(Structure):
+    _fields_ = [("layers_host", POINTER(bt_layer_weights)), ("lnf_w", c_void_p), ("lnf_b", c_void_p)]
+
+
+class bt_attn_args(Structure):
+    _fields_ = [("k_cache", c_void_p), ("v_cache", c_void_p), ("layer_stride", c_int64), ("n_max", c_int64),
+                ("pos0_dev", c_void_p), ("pos0_host", c_int32), ("pos_table", c_void_p), ("mask", c_void_p),
+                ("mask_ld", c_int64), ("cos_tab", c_void_p), ("sin_tab", c_void_p), ("mode", c_int32),
+                ("n_split", c_int32), ("split_ws", c_void_p), ("split_ws_bytes", c_int64)]
+
+
+_SIGS = {
+    "bt_version": (c_int, []),
+    "bt_last_error": (c_char_p, []),
+    "bt_decoder_workspace_bytes": (c_int64, [POINTER(bt_decoder_dims), c_int, c_int64]),
+    "bt_linear": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
+                          c_void_p, c_int64, c_int, c_void_p]),
+    "bt_layernorm": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
+                             c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p]),
+    "bt_embed_rows": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64,
+                              c_void_p, c_int32, c_void_p]),
+    "bt_rope_kv_append": (c_int, [c_int, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p,
+                                  c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bt_attention": (c_int, [c_int, c_int, c_int64, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_void_p,
+                             c_int64, c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p,
+                             c_int64, c_void_p]),
+    "bt_argmax": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "bt_topk_sample": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_float, c_int32, c_uint64, c_void_p,
+                               c_void_p, c_int64, c_void_p]),
+    "bt_decoder_forward": (c_int, [c_int, POINTER(bt_decoder_dims), POINTER(bt_decoder_weights), c_int64, c_int32,
+                                   c_void_p, POINTER(bt_attn_args), c_int32, c_void_p, c_void_p, c_int64, c_void_p]),
+    "bt_finish_block": (c_int, [c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p]),
+    "bt_bump": (c_int, [c_void_p, c_int32, c_void_p]),
+    "bt_graph_begin_capture": (c_int, [c_void_p]),
+    "bt_graph_end_capture": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "bt_graph_launch": (c_int, [c_void_p, c_void_p]),
+    "bt_graph_destroy": (c_int, [c_void_p]),
+    "bt_event_create": (c_int, [POINTER(c_void_p)]),
+    "bt_event_record": (c_int, [c_void_p, c_void_p]),
+    "bt_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
+    "bt_event_destroy": (c_int, [c_void_p]),
+    "bt_prof_enable": (c_int, [c_int]),
+    "bt_prof_collect": (c_int, [POINTER(ctypes.c_double), POINTER(c_int64), c_int]),
+    "bt_debug_force_generic_gemm": (None, [c_int]),
+}
+
+# every symbol include/bt_hip.h declares (tests check the library exports all of them)
+EXPORTED_SYMBOLS = [k for k in _SIGS if not k.startswith("bt_debug")]
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the library; raises ImportError with the build recipe when it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: the Block Transformer decode path has no fallback without its HIP kernels. "
+                "Build it with `python -m block_transformer_amd.build` (needs hipcc, no GPU required).")
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+PROF_FAMILIES = ["linear_mfma", "linear_generic", "layernorm", "embed", "rope_kv_append", "attn_rows", "attn_flash",
+                 "argmax", "sample", "finish_block"]
+
+
+def prof_enable(on: bool) -> None:
+    check(lib().bt_prof_enable(1 if on else 0), "bt_prof_enable")
+
+
+def prof_collect() -> dict:
+    """{family: (milliseconds, launches)} accumulated since prof_enable(True)."""
+    n = len(PROF_FAMILIES)
+    ms = (ctypes.c_double * n)()
+    cnt = (c_int64 * n)()
+    check(lib().bt_prof_collect(ms, cnt, n), "bt_prof_collect")
+    return {PROF_FAMILIES[i]: (ms[i], cnt[i]) for i in range(n)}
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().bt_last_error()
+        raise BtError(f"libbt_hip {what} failed (status {rc}): {msg.decode() if msg else ''}")
+
+
+def dtype_code(dtype: torch.dtype) -> int:
+    if dtype == torch.float32:
+        return BT_F32
+    if dtype == torch.bfloat16:
+        return BT_BF16
+    raise BtError(f"dtype {dtype} is not supported by libbt_hip (float32 and bfloat16 only)")
+
+
+def ptr(t) -> int:
+    """Device pointer of a tensor (None -> NULL).  Refuses CPU tensors: there is no CPU path."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise BtError("libbt_hip operates on GPU memory only; got a CPU tensor (move the model/inputs to 'cuda')")
+    return t.data_ptr()
+
+
+def current_stream() -> int:
+    return torch.cuda.current_stream().cuda_stream

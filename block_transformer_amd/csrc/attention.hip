@@ -1,0 +1,601 @@
+// Attention over the Block Transformer's two KV caches.
+//
+//  rope_kv_append_kernel<T>   partial RoPE on q (in place) and k, append (k_rot, v) to a cache [B][heads][n_max][d].
+//                             Replaces HF apply_rotary_pos_emb + torch.cat cache growth: the cache is preallocated and a
+//                             step writes ONE row per (b, head) instead of re-copying n rows (C4/C5).
+//  attend_rows_kernel<T,D,NW> row-wise streaming attention: one workgroup per (b, head, query row) [x split].  This is
+//                             the GLOBAL decode step (q = 1 against n cached block positions): each (b, head) slab is a
+//                             contiguous n x d stream read with 16-byte loads, 16 lanes per 128-dim bf16 row (4 rows per
+//                             wave-instruction), scores reduced with in-wave shuffles into an LDS score row, softmax with
+//                             wave shuffle + LDS block reduce, then the V stream with per-lane fp32 accumulators.
+//                             HBM-bound: algorithmic bytes = 2 * n * d * sizeof(T) per (b, head) per layer.  MFMA does not
+//                             apply: with q = 1 and no KV sharing across heads every K/V byte is used for exactly one
+//                             multiply-add (arithmetic intensity 1 flop/byte).  The same kernel with NW = 1 serves the
+//                             token decoder's local window (<= E+L-1 keys), whose K/V rows sit in L2/LDS-sized tiles.
+//  flash_prefill_kernel<D>    bf16 MFMA flash attention for the block-decoder prefill (q_len = n): S^T = K Q^T and
+//                             O = P V with v_mfma_f32_16x16x32_bf16, online softmax in registers (the swapped product
+//                             leaves a query's scores in one lane column, so the row max/sum are 2 shuffles), V tile
+//                             transposed through LDS.
+//  attn_combine_kernel<T>     merges split-N partials (flash-decoding style) when B*heads is too small to fill 256 CUs.
+#include "bt_common.h"
+
+namespace bt {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+// ---- RoPE + KV append ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void rope_kv_append_kernel(T* __restrict__ qkv, int64_t ld_qkv, T* __restrict__ kc,
+                                                            T* __restrict__ vc, int64_t n_max, int64_t rows, int q_len,
+                                                            int heads, int D, int rot, const int32_t* __restrict__ pos0_dev,
+                                                            int pos0_host, const int32_t* __restrict__ pos_table,
+                                                            const float* __restrict__ cos_tab,
+                                                            const float* __restrict__ sin_tab) {
+    constexpr int V = Elem<T>::VEC;
+    const int cpr = heads * 3 * D / V;  // 16-byte chunks per qkv row
+    const int64_t gid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= rows * cpr) return;
+    const int64_t row = gid / cpr;
+    const int c = (int)(gid - row * cpr);
+    const int col = c * V;
+    const int head = col / (3 * D);
+    const int within = col - head * 3 * D;
+    const int part = within / D;  // 0 q, 1 k, 2 v
+    const int e0 = within - part * D;
+    const int64_t b = row / q_len;
+    const int t = (int)(row - b * q_len);
+    const int pos0 = pos0_dev ? *pos0_dev : pos0_host;
+    const int cache_row = pos0 + t;
+    const int rpos = pos_table ? pos_table[pos0 + t] : pos0 + t;
+    const int half = rot >> 1;
+    T* src = qkv + row * ld_qkv + col;
+    const int64_t cidx = ((b * heads + head) * n_max + cache_row) * D + e0;
+    if (part == 2) {
+        *reinterpret_cast<uint4*>(vc + cidx) = *reinterpret_cast<const uint4*>(src);
+        return;
+    }
+    float x[V];
+    if (e0 >= rot) {  // pass-through dims
+        if (part == 1) *reinterpret_cast<uint4*>(kc + cidx) = *reinterpret_cast<const uint4*>(src);
+        return;
+    }
+    const float* cs = cos_tab + (int64_t)rpos * half;
+    const float* sn = sin_tab + (int64_t)rpos * half;
+    if (half < V) {
+        // the whole rotary span [0, rot) lies inside this chunk (rot <= V)
+        load_vec<T>(src, x);
+        float y[V];
+#pragma unroll
+        for (int i = 0; i < V; ++i) y[i] = x[i];
+        for (int j = 0; j < half; ++j) {
+            const float c_ = cs[j], s_ = sn[j];
+            y[j] = x[j] * c_ - x[j + half] * s_;
+            y[j + half] = x[j + half] * c_ + x[j] * s_;
+        }
+        if (part == 0) store_vec<T>(src, y);
+        else store_vec<T>(kc + cidx, y);
+        return;
+    }
+    // half >= V: chunk e0 in [0, half) owns the pair (e0, e0 + half); chunks in [half, rot) are written by their owner
+    if (e0 >= half) return;
+    float x2[V], y1[V], y2[V];
+    load_vec<T>(src, x);
+    load_vec<T>(src + half, x2);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+        const float c_ = cs[e0 + i], s_ = sn[e0 + i];
+        y1[i] = x[i] * c_ - x2[i] * s_;
+        y2[i] = x2[i] * c_ + x[i] * s_;
+    }
+    if (part == 0) {
+        store_vec<T>(src, y1);
+        store_vec<T>(src + half, y2);
+    } else {
+        store_vec<T>(kc + cidx, y1);
+        store_vec<T>(kc + cidx + half, y2);
+    }
+}
+
+// ---- row-wise streaming attention ------------------------------------------------------------------------------------------
+template <int NW>
+__device__ inline float block_max(float v, float* red, int wave, int lane) {
+    v = wave_max(v);
+    if (NW == 1) return v;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) r = fmaxf(r, red[w]);
+    return r;
+}
+template <int NW>
+__device__ inline float block_sum(float v, float* red, int wave, int lane) {
+    v = wave_sum(v);
+    if (NW == 1) return v;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) r += red[w];
+    return r;
+}
+
+template <typename T, int D, int NW>
+__global__ __launch_bounds__(NW * 64) void attend_rows_kernel(const T* __restrict__ qkv, int64_t ld_qkv,
+                                                             const T* __restrict__ kc, const T* __restrict__ vc,
+                                                             int64_t n_max, const int32_t* __restrict__ pos0_dev,
+                                                             int pos0_host, const uint8_t* __restrict__ mask,
+                                                             int64_t mask_ld, T* __restrict__ out, int64_t ldo,
+                                                             float* __restrict__ ws, int q_len, int heads, int n_split,
+                                                             float scale) {
+    constexpr int V = Elem<T>::VEC;
+    constexpr int LPR = D / V;     // lanes per K/V row
+    constexpr int RPW = 64 / LPR;  // rows per wave-instruction
+    constexpr int U = 4;           // independent 16-byte loads in flight per lane
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* red = smem;             // [NW]
+    float* ored = smem + 4;        // [NW][D]  cross-wave output reduce
+    float* sc = smem + 4 + NW * D; // [cap] scores / probabilities of this split
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = lane % LPR, sub = lane / LPR;
+    const int64_t idx = blockIdx.x;
+    const int t = (int)(idx % q_len);
+    const int head = (int)((idx / q_len) % heads);
+    const int64_t b = idx / ((int64_t)q_len * heads);
+    const int split = blockIdx.y;
+    const int pos0 = pos0_dev ? *pos0_dev : pos0_host;
+    const int nk = pos0 + t + 1;
+    const int per = (nk + n_split - 1) / n_split;
+    const int k0 = split * per;
+    const int k1 = min(nk, k0 + per);
+    const int cnt = max(k1 - k0, 0);
+
+    float q[V];
+    load_vec<T>(qkv + (b * q_len + t) * ld_qkv + (int64_t)head * 3 * D + c * V, q);
+#pragma unroll
+    for (int i = 0; i < V; ++i) q[i] *= scale;
+    const T* kbase = kc + (b * heads + head) * n_max * D + c * V;
+    const T* vbase = vc + (b * heads + head) * n_max * D + c * V;
+    const uint8_t* mrow = mask ? mask + b * mask_ld : nullptr;
+
+    // pass 1: scores
+    for (int rb = k0 + wave * RPW; rb < k1; rb += NW * RPW * U) {
+        float kv[U][V];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int r = rb + u * NW * RPW + sub;
+            r = r < k1 ? r : k1 - 1;
+            load_vec<T>(kbase + (int64_t)r * D, kv[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < V; ++i) d = fmaf(q[i], kv[u][i], d);
+            d = wave_sum<LPR>(d);
+            const int r = rb + u * NW * RPW + sub;
+            if (c == 0 && r < k1) sc[r - k0] = (mrow && mrow[r] == 0) ? -INFINITY : d;
+        }
+    }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int i = tid; i < cnt; i += NW * 64) m = fmaxf(m, sc[i]);
+    m = block_max<NW>(m, red, wave, lane);
+    float l = 0.f;
+    for (int i = tid; i < cnt; i += NW * 64) {
+        const float p = (m == -INFINITY) ? 0.f : __expf(sc[i] - m);
+        sc[i] = p;
+        l += p;
+    }
+    l = block_sum<NW>(l, red, wave, lane);
+    __syncthreads();
+
+    // pass 2: o = sum_r p[r] * V[r]
+    float acc[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) acc[i] = 0.f;
+    for (int rb = k0 + wave * RPW; rb < k1; rb += NW * RPW * U) {
+        float vv[U][V];
+        float p[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int r = rb + u * NW * RPW + sub;
+            const bool ok = r < k1;
+            r = ok ? r : k1 - 1;
+            load_vec<T>(vbase + (int64_t)r * D, vv[u]);
+            p[u] = ok ? sc[r - k0] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[i] = fmaf(p[u], vv[u][i], acc[i]);
+    }
+    // reduce over the RPW row groups of the wave (lane bits >= log2(LPR)), then across waves
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) acc[i] += __shfl_xor(acc[i], o, 64);
+    }
+    if (NW > 1) {
+        if (sub == 0) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) ored[wave * D + c * V + i] = acc[i];
+        }
+        __syncthreads();
+        if (wave == 0 && sub == 0) {
+#pragma unroll
+            for (int i = 0; i < V; ++i) {
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) s += ored[w * D + c * V + i];
+                acc[i] = s;
+            }
+        }
+    }
+    if (wave == 0 && sub == 0) {
+        if (n_split == 1) {
+            const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+            for (int i = 0; i < V; ++i) acc[i] *= inv;
+            store_vec<T>(out + (b * q_len + t) * ldo + (int64_t)head * D + c * V, acc);
+        } else {
+            float* w = ws + (idx * n_split + split) * (D + 2);
+            if (c == 0) {
+                w[0] = m;
+                w[1] = l;
+            }
+#pragma unroll
+            for (int i = 0; i < V; ++i) w[2 + c * V + i] = acc[i];
+        }
+    }
+}
+
+template <typename T>
+__global__ void attn_combine_kernel(const float* __restrict__ ws, T* __restrict__ out, int64_t ldo, int q_len, int heads,
+                                    int D, int n_split) {
+    const int64_t idx = blockIdx.x;
+    const int t = (int)(idx % q_len);
+    const int head = (int)((idx / q_len) % heads);
+    const int64_t b = idx / ((int64_t)q_len * heads);
+    const float* w = ws + idx * n_split * (D + 2);
+    float m = -INFINITY;
+    for (int s = 0; s < n_split; ++s) m = fmaxf(m, w[s * (D + 2)]);
+    for (int e = threadIdx.x; e < D; e += blockDim.x) {
+        float l = 0.f, o = 0.f;
+        for (int s = 0; s < n_split; ++s) {
+            const float ms = w[s * (D + 2)];
+            const float f = (ms == -INFINITY) ? 0.f : __expf(ms - m);
+            l += w[s * (D + 2) + 1] * f;
+            o += w[s * (D + 2) + 2 + e] * f;
+        }
+        Elem<T>::store(out + (b * q_len + t) * ldo + (int64_t)head * D + e, l > 0.f ? o / l : 0.f);
+    }
+}
+
+// ---- bf16 MFMA flash prefill ---------------------------------------------------------------------------------------------
+// block = 4 waves x (QF = 2 fragments of 16 query rows) = 128 query rows; key tiles of 64.
+constexpr int FQ_ROWS = 128, FK_TILE = 64, VT_PITCH = 72;  // Vt row pitch in bf16 elements (64 keys + 8 pad)
+
+template <int D>
+__global__ __launch_bounds__(256) void flash_prefill_kernel(const bf16* __restrict__ qkv, int64_t ld_qkv,
+                                                           const bf16* __restrict__ kc, const bf16* __restrict__ vc,
+                                                           int64_t n_max, const int32_t* __restrict__ pos0_dev,
+                                                           int pos0_host, const uint8_t* __restrict__ mask,
+                                                           int64_t mask_ld, bf16* __restrict__ out, int64_t ldo,
+                                                           int q_len, int heads, float scale) {
+    constexpr int KK = D / 32;  // k-steps of the QK^T product
+    constexpr int DF = D / 16;  // output d-fragments
+    constexpr int QF = 2;
+    __shared__ __attribute__((aligned(16))) uint16_t vt[D * VT_PITCH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int qb = blockIdx.x, head = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int pos0 = pos0_dev ? *pos0_dev : pos0_host;
+    const int qbase = qb * FQ_ROWS + wave * (QF * 16);
+
+    // Q fragments (B operand of S^T = K Q^T): lane (j = q row = l15, k group g) holds Q[row][kk*32 + g*8 .. +8)
+    bf16x8_t qf[QF][KK];
+    int qrow[QF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        qrow[f] = qbase + f * 16 + l15;
+        const int r = qrow[f] < q_len ? qrow[f] : q_len - 1;
+        const bf16* qp = qkv + (b * q_len + r) * ld_qkv + (int64_t)head * 3 * D + g * 8;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) qf[f][kk] = *reinterpret_cast<const bf16x8_t*>(qp + kk * 32);
+    }
+    f32x4_t oacc[QF][DF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f)
+#pragma unroll
+        for (int d = 0; d < DF; ++d) oacc[f][d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float mrun[QF], lrun[QF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        mrun[f] = -INFINITY;
+        lrun[f] = 0.f;
+    }
+
+    const bf16* kbase = kc + (b * heads + head) * n_max * D;
+    const bf16* vbase = vc + (b * heads + head) * n_max * D;
+    const uint8_t* mrow = mask ? mask + b * mask_ld : nullptr;
+    const int last_q = min(q_len, (qb + 1) * FQ_ROWS) - 1;
+    const int n_keys = pos0 + last_q + 1;
+    const int n_tiles = (n_keys + FK_TILE - 1) / FK_TILE;
+
+    for (int kt = 0; kt < n_tiles; ++kt) {
+        const int key0 = kt * FK_TILE;
+        __syncthreads();  // previous tile's Vt reads are done
+        // stage V^T: chunk = (key, 8 dims)
+#pragma unroll
+        for (int i = 0; i < (FK_TILE * D / 8) / 256; ++i) {
+            const int ch = tid + i * 256;
+            const int key = ch / (D / 8), dc = ch % (D / 8);
+            int kr = key0 + key;
+            kr = kr < n_max ? kr : (int)n_max - 1;
+            const uint4 v = *reinterpret_cast<const uint4*>(vbase + (int64_t)kr * D + dc * 8);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                vt[(dc * 8 + 2 * e) * VT_PITCH + key] = (uint16_t)(w[e] & 0xffffu);
+                vt[(dc * 8 + 2 * e + 1) * VT_PITCH + key] = (uint16_t)(w[e] >> 16);
+            }
+        }
+        __syncthreads();
+
+        // S^T fragments: sacc[f][kf][r] = score(key = key0 + kf*16 + g*4 + r, q = qrow[f])
+        f32x4_t sacc[QF][4];
+#pragma unroll
+        for (int f = 0; f < QF; ++f)
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) sacc[f][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf) {
+            int kr = key0 + kf * 16 + l15;
+            kr = kr < n_max ? kr : (int)n_max - 1;
+            const bf16* kp = kbase + (int64_t)kr * D + g * 8;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                const bf16x8_t kfr = *reinterpret_cast<const bf16x8_t*>(kp + kk * 32);
+#pragma unroll
+                for (int f = 0; f < QF; ++f)
+                    sacc[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[f][kk], sacc[f][kf], 0, 0, 0);
+            }
+        }
+        // key visibility for this lane's 16 keys (same for both q fragments except the causal bound)
+        bool kvis[4][4];
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = key0 + kf * 16 + g * 4 + r;
+                kvis[kf][r] = (mrow == nullptr) || (key < n_keys && mrow[key] != 0);
+            }
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+            const int qpos = pos0 + qrow[f];
+            float tmax = -INFINITY;
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = key0 + kf * 16 + g * 4 + r;
+                    const float s = (key <= qpos && kvis[kf][r]) ? sacc[f][kf][r] * scale : -INFINITY;
+                    sacc[f][kf][r] = s;
+                    tmax = fmaxf(tmax, s);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float mnew = fmaxf(mrun[f], tmax);
+            const float alpha = (mnew == -INFINITY) ? 1.0f : __expf(mrun[f] - mnew);
+            float psum = 0.f;
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = (mnew == -INFINITY) ? 0.f : __expf(sacc[f][kf][r] - mnew);
+                    sacc[f][kf][r] = p;
+                    psum += p;
+                }
+            lrun[f] = lrun[f] * alpha + psum;  // per-lane partial (this lane's keys); reduced over g at the end
+            mrun[f] = mnew;
+            // rescale O rows: row (g*4 + r) of fragment f belongs to the lane column l15' = g*4 + r
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float a = __shfl(alpha, g * 4 + r, 64);
+#pragma unroll
+                for (int d = 0; d < DF; ++d) oacc[f][d][r] *= a;
+            }
+        }
+        // O += P V : two 32-key steps; key slot (g, e): e < 4 -> key (2ks)*16 + g*4 + e ; e >= 4 -> (2ks+1)*16 + g*4 + e-4
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t pf[QF];
+#pragma unroll
+            for (int f = 0; f < QF; ++f) {
+                union {
+                    uint32_t u[4];
+                    bf16x8_t v;
+                } pk;
+                pk.u[0] = pack_bf16x2(sacc[f][2 * ks][0], sacc[f][2 * ks][1]);
+                pk.u[1] = pack_bf16x2(sacc[f][2 * ks][2], sacc[f][2 * ks][3]);
+                pk.u[2] = pack_bf16x2(sacc[f][2 * ks + 1][0], sacc[f][2 * ks + 1][1]);
+                pk.u[3] = pack_bf16x2(sacc[f][2 * ks + 1][2], sacc[f][2 * ks + 1][3]);
+                pf[f] = pk.v;
+            }
+#pragma unroll
+            for (int d = 0; d < DF; ++d) {
+                union {
+                    uint2 h[2];
+                    bf16x8_t v;
+                } vf;
+                const uint16_t* vrow = vt + (d * 16 + l15) * VT_PITCH + g * 4;
+                vf.h[0] = *reinterpret_cast<const uint2*>(vrow + (2 * ks) * 16);
+                vf.h[1] = *reinterpret_cast<const uint2*>(vrow + (2 * ks + 1) * 16);
+#pragma unroll
+                for (int f = 0; f < QF; ++f)
+                    oacc[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[f], vf.v, oacc[f][d], 0, 0, 0);
+            }
+        }
+    }
+    // epilogue: normalise and store.  oacc[f][d][r] = O[q = f*16 + g*4 + r][dim = d*16 + l15]
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        float l = lrun[f];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a = __shfl(inv, g * 4 + r, 64);
+            const int row = qbase + f * 16 + g * 4 + r;
+            if (row < q_len) {
+                bf16* op = out + (b * q_len + row) * ldo + (int64_t)head * D + l15;
+#pragma unroll
+                for (int d = 0; d < DF; ++d) op[d * 16].x = f32_to_bf16(oacc[f][d][r] * a);
+            }
+        }
+    }
+}
+
+// ---- host dispatch ------------------------------------------------------------------------------------------------------
+template <typename T, int D>
+static int launch_attend(int64_t B, int q_len, int heads, const void* qkv, int64_t ld_qkv, const void* kc, const void* vc,
+                         int64_t n_max, const int32_t* pos0_dev, int pos0_host, const uint8_t* mask, int64_t mask_ld,
+                         void* out, int64_t ldo, int n_split, float* ws, hipStream_t s) {
+    const float scale = 1.0f / sqrtf((float)D);
+    ProfScope ps(BT_PROF_ATTN_ROWS, s);
+    const int64_t cap = ceil_div(n_max, n_split);
+    const dim3 grid((unsigned)(B * heads * q_len), (unsigned)n_split);
+    if (n_max <= 64 && n_split == 1) {
+        const size_t shm = (4 + 1 * D + cap) * sizeof(float);
+        hipLaunchKernelGGL((attend_rows_kernel<T, D, 1>), grid, dim3(64), shm, s, (const T*)qkv, ld_qkv, (const T*)kc,
+                           (const T*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (T*)out, ldo, ws, q_len, heads,
+                           n_split, scale);
+    } else {
+        const size_t shm = (4 + 4 * D + cap) * sizeof(float);
+        if (shm > 64 * 1024) {
+            set_error("bt_attention: %lld keys per split need %zu B of LDS; raise n_split", (long long)cap, shm);
+            return BT_ERR_ARG;
+        }
+        hipLaunchKernelGGL((attend_rows_kernel<T, D, 4>), grid, dim3(256), shm, s, (const T*)qkv, ld_qkv, (const T*)kc,
+                           (const T*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (T*)out, ldo, ws, q_len, heads,
+                           n_split, scale);
+    }
+    BT_LAUNCH_CHECK("bt_attention(rows) launch");
+    if (n_split > 1) {
+        hipLaunchKernelGGL(attn_combine_kernel<T>, dim3((unsigned)(B * heads * q_len)), dim3(D < 64 ? 64 : D), 0, s, ws,
+                           (T*)out, ldo, q_len, heads, D, n_split);
+        BT_LAUNCH_CHECK("bt_attention(combine) launch");
+    }
+    return BT_OK;
+}
+
+template <int D>
+static int launch_flash(int64_t B, int q_len, int heads, const void* qkv, int64_t ld_qkv, const void* kc, const void* vc,
+                        int64_t n_max, const int32_t* pos0_dev, int pos0_host, const uint8_t* mask, int64_t mask_ld,
+                        void* out, int64_t ldo, hipStream_t s) {
+    const float scale = 1.0f / sqrtf((float)D);
+    ProfScope ps(BT_PROF_ATTN_FLASH, s);
+    const dim3 grid((unsigned)ceil_div(q_len, FQ_ROWS), (unsigned)heads, (unsigned)B);
+    hipLaunchKernelGGL(flash_prefill_kernel<D>, grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)kc,
+                       (const bf16*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (bf16*)out, ldo, q_len, heads, scale);
+    BT_LAUNCH_CHECK("bt_attention(flash) launch");
+    return BT_OK;
+}
+
+}  // namespace bt
+
+using namespace bt;
+
+extern "C" int bt_rope_kv_append(int dtype, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim, int32_t rot,
+                                 void* qkv, int64_t ld_qkv, void* k_cache, void* v_cache, int64_t n_max,
+                                 const int32_t* pos0_dev, int32_t pos0_host, const int32_t* pos_table,
+                                 const float* cos_tab, const float* sin_tab, bt_stream stream) {
+    BT_CHECK_ARG(dtype == BT_F32 || dtype == BT_BF16, "bt_rope_kv_append: bad dtype %d", dtype);
+    BT_CHECK_ARG(B >= 0 && q_len > 0 && heads > 0 && head_dim > 0, "bt_rope_kv_append: bad shape");
+    BT_CHECK_ARG(qkv && k_cache && v_cache && cos_tab && sin_tab, "bt_rope_kv_append: null pointer");
+    const int V = dtype == BT_BF16 ? 8 : 4;
+    const int half = rot / 2;
+    BT_CHECK_ARG(rot >= 2 && rot % 2 == 0 && rot <= head_dim, "bt_rope_kv_append: bad rotary_ndims %d", rot);
+    BT_CHECK_ARG(head_dim % V == 0 && ld_qkv % V == 0 && aligned16(qkv) && aligned16(k_cache) && aligned16(v_cache),
+                 "bt_rope_kv_append: head_dim/stride/pointers must be 16-byte granular");
+    BT_CHECK_ARG((half % V == 0) || (V % rot == 0), "bt_rope_kv_append: rotary_ndims %d not supported for this dtype", rot);
+    BT_CHECK_ARG(ld_qkv >= (int64_t)3 * heads * head_dim, "bt_rope_kv_append: qkv row stride too small");
+    BT_CHECK_ARG(pos0_dev || (pos0_host >= 0 && pos0_host + q_len <= n_max), "bt_rope_kv_append: cache overflow");
+    if (B == 0) return BT_OK;
+    const int64_t rows = B * q_len;
+    const int64_t total = rows * (heads * 3 * head_dim / V);
+    const unsigned grid = (unsigned)ceil_div(total, 256);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(BT_PROF_ROPE, s);
+    if (dtype == BT_BF16)
+        hipLaunchKernelGGL(rope_kv_append_kernel<bf16>, dim3(grid), dim3(256), 0, s, (bf16*)qkv, ld_qkv, (bf16*)k_cache,
+                           (bf16*)v_cache, n_max, rows, q_len, heads, head_dim, rot, pos0_dev, pos0_host, pos_table,
+                           cos_tab, sin_tab);
+    else
+        hipLaunchKernelGGL(rope_kv_append_kernel<float>, dim3(grid), dim3(256), 0, s, (float*)qkv, ld_qkv,
+                           (float*)k_cache, (float*)v_cache, n_max, rows, q_len, heads, head_dim, rot, pos0_dev,
+                           pos0_host, pos_table, cos_tab, sin_tab);
+    BT_LAUNCH_CHECK("bt_rope_kv_append launch");
+    return BT_OK;
+}
+
+extern "C" int bt_attention(int dtype, int mode, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim,
+                            const void* qkv, int64_t ld_qkv, const void* k_cache, const void* v_cache, int64_t n_max,
+                            const int32_t* pos0_dev, int32_t pos0_host, const uint8_t* mask, int64_t mask_ld, void* out,
+                            int64_t ldo, int32_t n_split, void* ws, int64_t ws_bytes, bt_stream stream) {
+    BT_CHECK_ARG(dtype == BT_F32 || dtype == BT_BF16, "bt_attention: bad dtype %d", dtype);
+    BT_CHECK_ARG(mode == 0 || mode == 1, "bt_attention: bad mode %d", mode);
+    BT_CHECK_ARG(B >= 0 && q_len > 0 && heads > 0, "bt_attention: bad shape");
+    BT_CHECK_ARG(qkv && k_cache && v_cache && out, "bt_attention: null pointer");
+    BT_CHECK_ARG(head_dim == 32 || head_dim == 64 || head_dim == 128, "bt_attention: head_dim %d not instantiated",
+                 head_dim);
+    const int V = dtype == BT_BF16 ? 8 : 4;
+    BT_CHECK_ARG(ld_qkv % V == 0 && ldo % V == 0 && aligned16(qkv) && aligned16(out) && aligned16(k_cache) &&
+                     aligned16(v_cache),
+                 "bt_attention: strides/pointers must be 16-byte granular");
+    BT_CHECK_ARG(pos0_dev || (pos0_host >= 0 && pos0_host + q_len <= n_max), "bt_attention: cache overflow");
+    BT_CHECK_ARG(!mask || mask_ld >= (pos0_dev ? 1 : pos0_host + q_len), "bt_attention: mask row too short");
+    if (B == 0) return BT_OK;
+    BT_CHECK_ARG(B * heads * q_len < (1ll << 31), "bt_attention: grid too large");
+    hipStream_t s = (hipStream_t)stream;
+    if (mode == 1 && dtype == BT_BF16) {
+        BT_CHECK_ARG(B < 65536 && heads < 65536, "bt_attention: flash grid too large");
+        switch (head_dim) {
+            case 32: return launch_flash<32>(B, q_len, heads, qkv, ld_qkv, k_cache, v_cache, n_max, pos0_dev, pos0_host, mask, mask_ld, out, ldo, s);
+            case 64: return launch_flash<64>(B, q_len, heads, qkv, ld_qkv, k_cache, v_cache, n_max, pos0_dev, pos0_host, mask, mask_ld, out, ldo, s);
+            default: return launch_flash<128>(B, q_len, heads, qkv, ld_qkv, k_cache, v_cache, n_max, pos0_dev, pos0_host, mask, mask_ld, out, ldo, s);
+        }
+    }
+    if (n_split < 1) n_split = 1;
+    // LDS score row capacity: raise the split count until one split's keys fit
+    while ((4 + 4 * (int64_t)head_dim + ceil_div(n_max, n_split)) * 4 > 64 * 1024) ++n_split;
+    if (n_split > 1) {
+        const int64_t need = B * heads * q_len * n_split * (head_dim + 2) * (int64_t)sizeof(float);
+        if (!ws || ws_bytes < need) {
+            set_error("bt_attention: split workspace too small (%lld < %lld bytes)", (long long)ws_bytes, (long long)need);
+            return BT_ERR_WORKSPACE;
+        }
+    }
+#define BT_ATT(T, D_) launch_attend<T, D_>(B, q_len, heads, qkv, ld_qkv, k_cache, v_cache, n_max, pos0_dev, pos0_host, mask, mask_ld, out, ldo, n_split, (float*)ws, s)
+    if (dtype == BT_BF16) {
+        switch (head_dim) {
+            case 32: return BT_ATT(bf16, 32);
+            case 64: return BT_ATT(bf16, 64);
+            default: return BT_ATT(bf16, 128);
+        }
+    }
+    switch (head_dim) {
+        case 32: return BT_ATT(float, 32);
+        case 64: return BT_ATT(float, 64);
+        default: return BT_ATT(float, 128);
+    }
+#undef BT_ATT
+}

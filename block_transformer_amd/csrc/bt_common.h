@@ -1,0 +1,153 @@
+// Shared device/host helpers for libbt_hip.so (gfx950 only; wave = 64 lanes).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/bt_hip.h"
+
+namespace bt {
+
+// ---- error plumbing --------------------------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define BT_CHECK_ARG(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            bt::set_error(__VA_ARGS__);         \
+            return BT_ERR_ARG;                  \
+        }                                       \
+    } while (0)
+
+#define BT_LAUNCH_CHECK(what)                               \
+    do {                                                    \
+        hipError_t e__ = hipGetLastError();                 \
+        if (e__ != hipSuccess) return bt::hip_fail(e__, what); \
+    } while (0)
+
+#define BT_TRY(expr)                 \
+    do {                             \
+        int rc__ = (expr);           \
+        if (rc__ != BT_OK) return rc__; \
+    } while (0)
+
+// ---- element types ---------------------------------------------------------------------------------------------
+struct bf16 {
+    uint16_t x;
+};
+
+__host__ __device__ inline float bf16_to_f32(uint16_t h) {
+    union {
+        uint32_t u;
+        float f;
+    } c;
+    c.u = ((uint32_t)h) << 16;
+    return c.f;
+}
+
+// round-to-nearest-even, NaN preserved (same as torch's float -> bfloat16)
+__host__ __device__ inline uint16_t f32_to_bf16(float f) {
+    union {
+        uint32_t u;
+        float f;
+    } c;
+    c.f = f;
+    uint32_t u = c.u;
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
+    uint32_t lsb = (u >> 16) & 1u;
+    u += 0x7fffu + lsb;
+    return (uint16_t)(u >> 16);
+}
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+    static constexpr int VEC = 4;  // elements per 16-byte vector
+    __device__ static inline float load(const float* p) { return *p; }
+    __device__ static inline void store(float* p, float v) { *p = v; }
+};
+template <>
+struct Elem<bf16> {
+    static constexpr int VEC = 8;
+    __device__ static inline float load(const bf16* p) { return bf16_to_f32(p->x); }
+    __device__ static inline void store(bf16* p, float v) { p->x = f32_to_bf16(v); }
+};
+
+// 16-byte vector load/store of Elem<T>::VEC elements to/from fp32 registers (pointer must be 16-byte aligned)
+template <typename T>
+__device__ inline void load_vec(const T* p, float (&v)[Elem<T>::VEC]);
+template <>
+__device__ inline void load_vec<float>(const float* p, float (&v)[4]) {
+    float4 t = *reinterpret_cast<const float4*>(p);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+template <>
+__device__ inline void load_vec<bf16>(const bf16* p, float (&v)[8]) {
+    uint4 t = *reinterpret_cast<const uint4*>(p);
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
+    v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+}
+template <typename T>
+__device__ inline void store_vec(T* p, const float (&v)[Elem<T>::VEC]);
+template <>
+__device__ inline void store_vec<float>(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ inline uint32_t pack_bf16x2(float lo, float hi) {
+    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+}
+template <>
+__device__ inline void store_vec<bf16>(bf16* p, const float (&v)[8]) {
+    uint4 t;
+    t.x = pack_bf16x2(v[0], v[1]); t.y = pack_bf16x2(v[2], v[3]);
+    t.z = pack_bf16x2(v[4], v[5]); t.w = pack_bf16x2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(p) = t;
+}
+
+// ---- wave / block reductions (wave64) ----------------------------------------------------------------------------
+template <int WIDTH = 64>
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int o = WIDTH / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int WIDTH = 64>
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int o = WIDTH / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- per-family kernel timer (core.hip) ------------------------------------------------------------------------
+extern bool g_prof_on;
+void prof_push(int family, hipEvent_t a, hipEvent_t b);
+hipEvent_t prof_event();
+struct ProfScope {
+    int fam;
+    hipStream_t s;
+    hipEvent_t a = nullptr;
+    ProfScope(int family, hipStream_t stream) : fam(family), s(stream) {
+        if (g_prof_on) {
+            a = prof_event();
+            (void)hipEventRecord(a, s);
+        }
+    }
+    ~ProfScope() {
+        if (a) {
+            hipEvent_t b = prof_event();
+            (void)hipEventRecord(b, s);
+            prof_push(fam, a, b);
+        }
+    }
+};
+
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+inline size_t dtype_size(int dtype) { return dtype == BT_BF16 ? 2 : 4; }
+
+}  // namespace bt

@@ -1,0 +1,80 @@
+// bt_decoder_forward: one GPT-NeoX stack (block decoder or token decoder) over M = B*q_len rows, as a fixed sequence of
+// kernel launches on one stream — the unit the Python host captures into a hipGraph per block step.
+//
+// Per layer (parallel residual, HF GPTNeoXLayer):
+//   LN1|LN2(x) -> qkv = LN1 Wqkv^T + b -> RoPE + KV append -> attention -> x += att Wd^T + bd (in place, fused epilogue)
+//   -> h = gelu(LN2 W1^T + b1) (fused epilogue) -> x += h W2^T + b2 (in place, fused epilogue)
+// 7 launches per layer instead of the reference's ~25 ATen kernels; no torch.cat cache copy.
+//
+// Activation workspace for M rows (elements): [ln1|att: M*H][ln2: M*H][qkv: M*3H][h4: M*I].
+#include "bt_common.h"
+
+using namespace bt;
+
+static int64_t ws_elems(const bt_decoder_dims* d, int64_t M) {
+    return M * ((int64_t)d->hidden * 5 + d->inter);
+}
+
+extern "C" int64_t bt_decoder_workspace_bytes(const bt_decoder_dims* dims, int dtype, int64_t M) {
+    if (!dims || M < 0) return -1;
+    return ws_elems(dims, M) * (int64_t)dtype_size(dtype) + 256;
+}
+
+extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const bt_decoder_weights* w, int64_t B,
+                                  int32_t q_len, void* x, const bt_attn_args* attn, int32_t first_out_row, void* out,
+                                  void* ws, int64_t ws_bytes, bt_stream stream) {
+    BT_CHECK_ARG(dims && w && w->layers_host && attn && x && out && ws, "bt_decoder_forward: null pointer");
+    BT_CHECK_ARG(dtype == BT_F32 || dtype == BT_BF16, "bt_decoder_forward: bad dtype %d", dtype);
+    BT_CHECK_ARG(B >= 0 && q_len > 0 && first_out_row >= 0 && first_out_row < q_len, "bt_decoder_forward: bad shape");
+    BT_CHECK_ARG(dims->hidden == dims->heads * dims->head_dim, "bt_decoder_forward: hidden != heads*head_dim");
+    if (B == 0) return BT_OK;
+    const int64_t M = B * q_len;
+    const int64_t H = dims->hidden, I = dims->inter;
+    const size_t es = dtype_size(dtype);
+    // 256-byte align the workspace base
+    uintptr_t base = (reinterpret_cast<uintptr_t>(ws) + 255u) & ~(uintptr_t)255u;
+    const int64_t avail = ws_bytes - (int64_t)(base - reinterpret_cast<uintptr_t>(ws));
+    if (avail < ws_elems(dims, M) * (int64_t)es) {
+        set_error("bt_decoder_forward: workspace too small: %lld bytes for M=%lld (need %lld)", (long long)ws_bytes,
+                  (long long)M, (long long)bt_decoder_workspace_bytes(dims, dtype, M));
+        return BT_ERR_WORKSPACE;
+    }
+    char* p = reinterpret_cast<char*>(base);
+    void* ln1 = p;              // also the attention output
+    void* ln2 = p + M * H * es;
+    void* qkv = p + 2 * M * H * es;
+    void* h4 = p + 5 * M * H * es;
+    void* att = ln1;
+
+    for (int l = 0; l < dims->layers; ++l) {
+        const bt_layer_weights& lw = w->layers_host[l];
+        char* kc = reinterpret_cast<char*>(attn->k_cache) + (int64_t)l * attn->layer_stride * es;
+        char* vc = reinterpret_cast<char*>(attn->v_cache) + (int64_t)l * attn->layer_stride * es;
+        BT_TRY(bt_layernorm(dtype, M, H, x, H, lw.ln1_w, lw.ln1_b, ln1, H, lw.ln2_w, lw.ln2_b, ln2, H, dims->ln_eps,
+                            stream));
+        BT_TRY(bt_linear(dtype, M, 3 * H, H, ln1, H, lw.qkv_w, lw.qkv_b, nullptr, 0, qkv, 3 * H, BT_ACT_NONE, stream));
+        BT_TRY(bt_rope_kv_append(dtype, B, q_len, dims->heads, dims->head_dim, dims->rot, qkv, 3 * H, kc, vc,
+                                 attn->n_max, attn->pos0_dev, attn->pos0_host, attn->pos_table, attn->cos_tab,
+                                 attn->sin_tab, stream));
+        BT_TRY(bt_attention(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc, attn->n_max,
+                            attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H, attn->n_split,
+                            attn->split_ws, attn->split_ws_bytes, stream));
+        BT_TRY(bt_linear(dtype, M, H, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, BT_ACT_NONE, stream));
+        BT_TRY(bt_linear(dtype, M, I, H, ln2, H, lw.h4_w, lw.h4_b, nullptr, 0, h4, I, BT_ACT_GELU, stream));
+        BT_TRY(bt_linear(dtype, M, H, I, h4, I, lw.h_w, lw.h_b, x, H, x, H, BT_ACT_NONE, stream));
+    }
+    // final_layer_norm of the rows the caller consumes
+    const int count = q_len - first_out_row;
+    if (first_out_row == 0) {
+        BT_TRY(bt_layernorm(dtype, M, H, x, H, w->lnf_w, w->lnf_b, out, H, nullptr, nullptr, nullptr, 0, dims->ln_eps,
+                            stream));
+    } else {
+        for (int t = 0; t < count; ++t) {
+            const char* xin = reinterpret_cast<const char*>(x) + (int64_t)(first_out_row + t) * H * es;
+            char* o = reinterpret_cast<char*>(out) + (int64_t)t * H * es;
+            BT_TRY(bt_layernorm(dtype, B, H, xin, (int64_t)q_len * H, w->lnf_w, w->lnf_b, o, (int64_t)count * H, nullptr,
+                                nullptr, nullptr, 0, dims->ln_eps, stream));
+        }
+    }
+    return BT_OK;
+}

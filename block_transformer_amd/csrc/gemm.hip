@@ -1,0 +1,275 @@
+// bt_linear: out[M,N] = act(A[M,K] . W[N,K]^T + bias) + residual
+//
+// Two kernels:
+//  * gemm_bf16_mfma_kernel  — the production path.  128x128x64 block tile, 4 waves (2x2), each wave a 64x64 output
+//    tile = 4x4 fragments of v_mfma_f32_16x16x32_bf16.  Both operands are K-contiguous (HF nn.Linear weights are
+//    [out,in]), so A and W tiles are streamed HBM -> LDS with 16-byte global_load_lds (no VGPR round trip), double
+//    buffered, one barrier per K-step.  LDS rows are 128 B (64 bf16); the 16-byte slot index is XOR-swizzled with
+//    (row & 7) on the *source* address and on the ds_read_b128 address (the LDS image of an LDS-DMA is lane-linear),
+//    which makes every ds_read_b128 lane group conflict-free.  The MFMA "A" operand is the WEIGHT tile and the "B"
+//    operand the activation tile, so each lane ends up with 4 consecutive output columns of one row: bias / GELU /
+//    residual are fused into an 8-byte-per-lane epilogue store.  Block ids are remapped XCD-aware (each XCD's L2 sees
+//    a contiguous slab of the tile grid) and grouped along M so a group's A tiles stay L2-resident while W streams.
+//  * gemm_generic_kernel<T> — any dtype/shape (fp32 parity path, and bf16 shapes with K % 64 != 0): 64x64x16 LDS
+//    tiled, fp32 FMA accumulation.
+//
+// Roofline: MFMA-bound for M >~ 300 rows (2*M*N*K flop vs 2*(M*K + N*K + M*N) bytes); HBM-bound on W below that.
+#include "bt_common.h"
+
+namespace bt {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
+constexpr int GROUP_M = 8;
+
+// logical tile id for this workgroup: bijective XCD remap (cdna guide T1) then GROUP_M grouping
+__device__ inline void tile_coords(int tiles_m, int tiles_n, int& tm, int& tn) {
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int group_sz = GROUP_M * tiles_n;
+    const int g = id / group_sz;
+    const int first_m = g * GROUP_M;
+    const int gm = min(tiles_m - first_m, GROUP_M);
+    const int in_g = id - g * group_sz;
+    tm = first_m + in_g % gm;
+    tn = in_g / gm;
+}
+
+// issue the LDS-DMA for one 128-row x 64-col bf16 tile: wave w covers rows [32w, 32w+32) in 4 instructions of 8 rows
+__device__ inline void stage_tile(const bf16* __restrict__ src, int64_t ld, int row0, int row_max, int k0, char* lds_tile,
+                                  int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int rbase = wave * 32 + i * 8;
+        const int row = rbase + (lane >> 3);
+        const int gslot = (lane & 7) ^ (row & 7);
+        int grow = row0 + row;
+        grow = grow < row_max ? grow : row_max - 1;
+        const bf16* g = src + (int64_t)grow * ld + k0 + gslot * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(lds_tile + rbase * 128), 16, 0, 0);
+    }
+}
+
+__device__ inline bf16x8_t read_frag(const char* lds_tile, int row_base, int kk, int lane) {
+    const int row = row_base + (lane & 15);
+    const int slot = (kk * 4 + (lane >> 4)) ^ (row & 7);
+    return *reinterpret_cast<const bf16x8_t*>(lds_tile + row * 128 + slot * 16);
+}
+
+__global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restrict__ A, int64_t lda,
+                                                            const bf16* __restrict__ W, int64_t ldw,
+                                                            const bf16* __restrict__ bias,
+                                                            const bf16* res, int64_t ldr,
+                                                            bf16* out, int64_t ldo, int M, int N, int K,
+                                                            int act, int tiles_m, int tiles_n) {
+    // [buf][A | W][128 rows][64 bf16]  = 64 KiB
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    stage_tile(A, lda, m0, M, 0, smem, wave, lane);
+    stage_tile(W, ldw, n0, N, 0, smem + TILE_BYTES, wave, lane);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int t = 0; t < nk; ++t) {
+        const int cur = t & 1;
+        char* a_cur = smem + cur * 2 * TILE_BYTES;
+        char* w_cur = a_cur + TILE_BYTES;
+        if (t + 1 < nk) {
+            char* a_nxt = smem + (cur ^ 1) * 2 * TILE_BYTES;
+            stage_tile(A, lda, m0, M, (t + 1) * BK, a_nxt, wave, lane);
+            stage_tile(W, ldw, n0, N, (t + 1) * BK, a_nxt + TILE_BYTES, wave, lane);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8_t wf[4], af[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) wf[i] = read_frag(w_cur, wn * 64 + i * 16, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) af[j] = read_frag(a_cur, wm * 64 + j * 16, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // epilogue: D[i = n][j = m]; lane holds column m = lane & 15 and rows n = (lane >> 4) * 4 + r
+    const bool vec_ok = ((N & 3) == 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+        if (m >= M) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+            if (n >= N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (vec_ok) {
+                if (bias) {
+                    const uint2 b2 = *reinterpret_cast<const uint2*>(bias + n);
+                    v[0] += __uint_as_float(b2.x << 16); v[1] += __uint_as_float(b2.x & 0xffff0000u);
+                    v[2] += __uint_as_float(b2.y << 16); v[3] += __uint_as_float(b2.y & 0xffff0000u);
+                }
+                if (act == BT_ACT_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                }
+                if (res) {
+                    const uint2 r2 = *reinterpret_cast<const uint2*>(res + (int64_t)m * ldr + n);
+                    v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
+                    v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+                }
+                uint2 o2;
+                o2.x = pack_bf16x2(v[0], v[1]);
+                o2.y = pack_bf16x2(v[2], v[3]);
+                *reinterpret_cast<uint2*>(out + (int64_t)m * ldo + n) = o2;
+            } else {
+                for (int r = 0; r < 4; ++r) {
+                    if (n + r >= N) break;
+                    float x = v[r];
+                    if (bias) x += bf16_to_f32(bias[n + r].x);
+                    if (act == BT_ACT_GELU) x = gelu_erf(x);
+                    if (res) x += bf16_to_f32(res[(int64_t)m * ldr + n + r].x);
+                    out[(int64_t)m * ldo + n + r].x = f32_to_bf16(x);
+                }
+            }
+        }
+    }
+}
+
+// ---- generic tiled kernel (fp32 parity path; any M, N, K, strides) --------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_generic_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ W,
+                                                          int64_t ldw, const T* __restrict__ bias,
+                                                          const T* res, int64_t ldr, T* out,
+                                                          int64_t ldo, int M, int N, int K, int act) {
+    __shared__ float As[16][65];
+    __shared__ float Ws[16][65];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    float acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + i * 256;
+            const int r = idx >> 4, kk = idx & 15;
+            const int k = k0 + kk;
+            float a = 0.f, w = 0.f;
+            if (k < K) {
+                if (m0 + r < M) a = Elem<T>::load(A + (int64_t)(m0 + r) * lda + k);
+                if (n0 + r < N) w = Elem<T>::load(W + (int64_t)(n0 + r) * ldw + k);
+            }
+            As[kk][r] = a;
+            Ws[kk][r] = w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            float a[4], w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = Ws[kk][tx * 4 + j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], w[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + ty * 4 + i;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + tx * 4 + j;
+            if (n >= N) continue;
+            float x = acc[i][j];
+            if (bias) x += Elem<T>::load(bias + n);
+            if (act == BT_ACT_GELU) x = gelu_erf(x);
+            if (res) x += Elem<T>::load(res + (int64_t)m * ldr + n);
+            Elem<T>::store(out + (int64_t)m * ldo + n, x);
+        }
+    }
+}
+
+static bool g_force_generic = false;
+
+}  // namespace bt
+
+using namespace bt;
+
+extern "C" int bt_linear(int dtype, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* W,
+                         const void* bias, const void* residual, int64_t ldr, void* out, int64_t ldo, int act,
+                         bt_stream stream) {
+    BT_CHECK_ARG(dtype == BT_F32 || dtype == BT_BF16, "bt_linear: bad dtype %d", dtype);
+    BT_CHECK_ARG(M >= 0 && N > 0 && K > 0, "bt_linear: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N,
+                 (long long)K);
+    BT_CHECK_ARG(A && W && out, "bt_linear: null pointer");
+    BT_CHECK_ARG(lda >= K && ldo >= N && (!residual || ldr >= N), "bt_linear: row stride smaller than row");
+    BT_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "bt_linear: dimension exceeds int32");
+    BT_CHECK_ARG(act == BT_ACT_NONE || act == BT_ACT_GELU, "bt_linear: bad activation %d", act);
+    if (M == 0) return BT_OK;
+    hipStream_t s = (hipStream_t)stream;
+    if (dtype == BT_BF16) {
+        const bool mfma_ok = !g_force_generic && (K % BK == 0) && (lda % 8 == 0) && aligned16(A) && aligned16(W) &&
+                             (ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 7u) == 0) &&
+                             (!residual || ((ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(residual) & 7u) == 0)) &&
+                             (!bias || (reinterpret_cast<uintptr_t>(bias) & 7u) == 0);
+        if (mfma_ok) {
+            ProfScope ps(BT_PROF_LINEAR_MFMA, s);
+            const int tiles_m = (int)ceil_div(M, BM), tiles_n = (int)ceil_div(N, BN);
+            BT_CHECK_ARG((int64_t)tiles_m * tiles_n < (1ll << 31), "bt_linear: grid too large");
+            hipLaunchKernelGGL(gemm_bf16_mfma_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, s, (const bf16*)A, lda,
+                               (const bf16*)W, K, (const bf16*)bias, (const bf16*)residual, ldr, (bf16*)out, ldo,
+                               (int)M, (int)N, (int)K, act, tiles_m, tiles_n);
+        } else {
+            ProfScope ps(BT_PROF_LINEAR_GENERIC, s);
+            dim3 grid((unsigned)ceil_div(N, 64), (unsigned)ceil_div(M, 64));
+            BT_CHECK_ARG(grid.y <= 65535u, "bt_linear: M too large for the generic kernel");
+            hipLaunchKernelGGL(gemm_generic_kernel<bf16>, grid, dim3(256), 0, s, (const bf16*)A, lda, (const bf16*)W,
+                               K, (const bf16*)bias, (const bf16*)residual, ldr, (bf16*)out, ldo, (int)M, (int)N,
+                               (int)K, act);
+        }
+    } else {
+        ProfScope ps(BT_PROF_LINEAR_GENERIC, s);
+        dim3 grid((unsigned)ceil_div(N, 64), (unsigned)ceil_div(M, 64));
+        BT_CHECK_ARG(grid.y <= 65535u, "bt_linear: M too large for the generic kernel");
+        hipLaunchKernelGGL(gemm_generic_kernel<float>, grid, dim3(256), 0, s, (const float*)A, lda, (const float*)W, K,
+                           (const float*)bias, (const float*)residual, ldr, (float*)out, ldo, (int)M, (int)N, (int)K,
+                           act);
+    }
+    BT_LAUNCH_CHECK("bt_linear launch");
+    return BT_OK;
+}
+
+// test hook: force the generic kernel for bf16 (A/B checks of the MFMA kernel against the simple one)
+extern "C" void bt_debug_force_generic_gemm(int on) { g_force_generic = on != 0; }

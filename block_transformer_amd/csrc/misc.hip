@@ -1,0 +1,353 @@
+// Row gather (embedder lookup+concat, embed_in), greedy argmax, top-k/temperature sampler and the roll-over bookkeeping
+// kernels.  All HBM-bound byte/index work: coalesced 16-byte accesses, one wave or one workgroup per row.
+#include "bt_common.h"
+
+namespace bt {
+
+// ---- bt_embed_rows ----------------------------------------------------------------------------------------------------
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void embed_rows_kernel(const int64_t* __restrict__ ids, int64_t ids_stride, int64_t vocab,
+                                                        const T* __restrict__ table, T* __restrict__ out, int64_t ldo,
+                                                        int64_t rows, int width, const int32_t* __restrict__ row_zero,
+                                                        int rows_per_seq) {
+    constexpr int V = Elem<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= rows) return;
+    const bool zero = row_zero != nullptr && row_zero[r / rows_per_seq] != 0;
+    int64_t id = ids[r * ids_stride];
+    id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);  // memory safety; torch would device-assert
+    const T* src = table + id * (int64_t)width;
+    T* dst = out + r * ldo;
+    if (VEC) {
+        for (int c = lane * V; c < width; c += 64 * V) {
+            uint4 v = zero ? make_uint4(0, 0, 0, 0) : *reinterpret_cast<const uint4*>(src + c);
+            *reinterpret_cast<uint4*>(dst + c) = v;
+        }
+    } else {
+        for (int c = lane; c < width; c += 64) Elem<T>::store(dst + c, zero ? 0.f : Elem<T>::load(src + c));
+    }
+}
+
+// ---- bt_argmax -----------------------------------------------------------------------------------------------------
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void argmax_kernel(const T* __restrict__ logits, int64_t ld, int V_,
+                                                    int64_t* __restrict__ ids_out, int64_t ids_stride) {
+    constexpr int V = Elem<T>::VEC;
+    __shared__ float s_val[4];
+    __shared__ int s_idx[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* row = logits + (int64_t)blockIdx.x * ld;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    if (VEC) {
+        for (int c = tid * V; c < V_; c += 256 * V) {
+            float v[V];
+            load_vec<T>(row + c, v);
+#pragma unroll
+            for (int i = 0; i < V; ++i)
+                if (v[i] > best || bidx == 0x7fffffff) { best = v[i]; bidx = c + i; }
+        }
+    } else {
+        for (int c = tid; c < V_; c += 256) {
+            const float v = Elem<T>::load(row + c);
+            if (v > best || bidx == 0x7fffffff) { best = v; bidx = c; }
+        }
+    }
+    // wave reduce: larger value wins, ties -> smaller index (torch.argmax returns the first maximal index)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bidx, o, 64);
+        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+    if (lane == 0) { s_val[wave] = best; s_idx[wave] = bidx; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (s_val[w] > best || (s_val[w] == best && s_idx[w] < bidx)) { best = s_val[w]; bidx = s_idx[w]; }
+        ids_out[(int64_t)blockIdx.x * ids_stride] = bidx == 0x7fffffff ? 0 : bidx;
+    }
+}
+
+// ---- bt_topk_sample ----------------------------------------------------------------------------------------------------
+__device__ inline uint32_t float_key(float x) {  // order-preserving float -> uint
+    const uint32_t u = __float_as_uint(x);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ inline uint64_t splitmix64(uint64_t z) {
+    z += 0x9e3779b97f4a7c15ull;
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+
+constexpr int MAX_CAND = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(256) void topk_sample_kernel(const T* __restrict__ logits, int64_t ld, int V_, float inv_temp,
+                                                         int top_k, uint64_t seed, const int32_t* __restrict__ step_dev,
+                                                         int64_t* __restrict__ ids_out, int64_t ids_stride) {
+    __shared__ int hist[256];
+    __shared__ uint32_t s_prefix, s_mask;
+    __shared__ int s_k, s_ncand;
+    __shared__ float c_val[MAX_CAND];
+    __shared__ int c_idx[MAX_CAND];
+    __shared__ float red[4];
+    __shared__ float s_part[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const T* row = logits + (int64_t)blockIdx.x * ld;
+    const uint64_t rnd = splitmix64(splitmix64(seed ^ (uint64_t)(step_dev ? *step_dev : 0) * 0x100000001b3ull) +
+                                    (uint64_t)blockIdx.x);
+    const float u01 = (float)((rnd >> 40) & 0xffffff) * (1.0f / 16777216.0f);
+
+    if (top_k > 0 && top_k < V_) {
+        // radix select of the top_k-th largest key, 8 bits per pass
+        if (tid == 0) { s_prefix = 0; s_mask = 0; s_k = top_k; }
+        for (int pass = 3; pass >= 0; --pass) {
+            hist[tid] = 0;
+            __syncthreads();
+            const uint32_t prefix = s_prefix, mask = s_mask;
+            for (int c = tid; c < V_; c += 256) {
+                const uint32_t key = float_key(Elem<T>::load(row + c) * inv_temp);
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> (8 * pass)) & 255], 1);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int k = s_k, cum = 0, b = 255;
+                for (; b > 0; --b) {
+                    if (cum + hist[b] >= k) break;
+                    cum += hist[b];
+                }
+                s_k = k - cum;
+                s_prefix = prefix | ((uint32_t)b << (8 * pass));
+                s_mask = mask | (0xffu << (8 * pass));
+            }
+            __syncthreads();
+        }
+        // HF TopKLogitsWarper keeps every score >= the k-th largest (ties included)
+        const uint32_t thr = s_prefix;
+        if (tid == 0) s_ncand = 0;
+        __syncthreads();
+        for (int c = tid; c < V_; c += 256) {
+            const float v = Elem<T>::load(row + c) * inv_temp;
+            if (float_key(v) >= thr) {
+                const int slot = atomicAdd(&s_ncand, 1);
+                if (slot < MAX_CAND) { c_val[slot] = v; c_idx[slot] = c; }
+            }
+        }
+        __syncthreads();
+        const int n = min(s_ncand, MAX_CAND);
+        // softmax over the candidates + inverse-CDF draw in index order (deterministic for a given (seed, step, row))
+        if (tid == 0) {
+            float mx = -INFINITY;
+            for (int i = 0; i < n; ++i) mx = fmaxf(mx, c_val[i]);
+            float tot = 0.f;
+            for (int i = 0; i < n; ++i) tot += expf(c_val[i] - mx);
+            const float target = u01 * tot;
+            // walk candidates in increasing vocabulary index
+            float cum = 0.f;
+            int chosen = -1, last = -1;
+            for (int step = 0; step < n; ++step) {
+                int best = -1;
+                for (int i = 0; i < n; ++i)
+                    if (c_idx[i] > last && (best < 0 || c_idx[i] < c_idx[best])) best = i;
+                last = c_idx[best];
+                cum += expf(c_val[best] - mx);
+                chosen = c_idx[best];
+                if (cum > target) break;
+            }
+            ids_out[(int64_t)blockIdx.x * ids_stride] = chosen < 0 ? 0 : chosen;
+        }
+        return;
+    }
+    // no top-k filter: full softmax, chunked inverse CDF
+    float mx = -INFINITY;
+    for (int c = tid; c < V_; c += 256) mx = fmaxf(mx, Elem<T>::load(row + c) * inv_temp);
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    const int chunk = (V_ + 255) / 256;
+    const int c0 = tid * chunk, c1 = min(V_, c0 + chunk);
+    float part = 0.f;
+    for (int c = c0; c < c1; ++c) part += expf(Elem<T>::load(row + c) * inv_temp - mx);
+    s_part[tid] = part;
+    __syncthreads();
+    if (tid == 0) {
+        float tot = 0.f;
+        for (int i = 0; i < 256; ++i) tot += s_part[i];
+        const float target = u01 * tot;
+        float cum = 0.f;
+        int t = 0;
+        for (; t < 255; ++t) {
+            if (cum + s_part[t] > target) break;
+            cum += s_part[t];
+        }
+        const int a0 = t * chunk, a1 = min(V_, a0 + chunk);
+        int chosen = a1 > a0 ? a1 - 1 : V_ - 1;
+        for (int c = a0; c < a1; ++c) {
+            cum += expf(Elem<T>::load(row + c) * inv_temp - mx);
+            if (cum > target) { chosen = c; break; }
+        }
+        ids_out[(int64_t)blockIdx.x * ids_stride] = chosen;
+    }
+}
+
+// ---- bt_finish_block ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void finish_block_kernel(int64_t B, int L, int count, int64_t* __restrict__ raw,
+                                                           int64_t* __restrict__ out_ids, int64_t nb_max,
+                                                           const int32_t* __restrict__ blk_dev,
+                                                           int32_t* __restrict__ finished,
+                                                           int32_t* __restrict__ finished_prev,
+                                                           uint8_t* __restrict__ mask, int64_t mask_ld,
+                                                           int64_t config_pad, int64_t gen_eos, int64_t gen_pad) {
+    __shared__ int s_stop;
+    const int blk = *blk_dev;
+    if (threadIdx.x == 0) s_stop = -1;
+    __syncthreads();
+    // HF greedy_search stops right after the first step at which every active row has produced EOS (Q6)
+    if (gen_eos >= 0) {
+        for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
+            if (finished[b]) continue;
+            int e = count;
+            for (int t = 0; t < count; ++t)
+                if (raw[b * L + t] == gen_eos) { e = t; break; }
+            atomicMax(&s_stop, e);
+        }
+    }
+    __syncthreads();
+    const int ncols = (gen_eos < 0 || s_stop < 0) ? count : min(s_stop + 1, count);
+    for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
+        bool fin = finished[b] != 0;
+        if (finished_prev) finished_prev[b] = fin ? 1 : 0;
+        if (fin) {
+            for (int t = 0; t < L; ++t) {
+                raw[b * L + t] = config_pad;
+                out_ids[(b * nb_max + blk) * L + t] = config_pad;
+            }
+        } else {
+            bool seen = false, any_eos = false;
+            for (int t = 0; t < L; ++t) {
+                int64_t tok;
+                if (t < ncols) {
+                    tok = seen ? gen_pad : raw[b * L + t];
+                    if (gen_eos >= 0 && tok == gen_eos) seen = true;
+                } else {
+                    tok = config_pad;
+                }
+                any_eos = any_eos || (gen_eos >= 0 && tok == gen_eos);
+                raw[b * L + t] = tok;
+                out_ids[(b * nb_max + blk) * L + t] = tok;
+            }
+            fin = any_eos;  // unfinished *= next_tokens.ne(eos).all(-1)   (block_transformer.py:411-412)
+            finished[b] = fin ? 1 : 0;
+        }
+        if (mask) mask[b * mask_ld + blk] = fin ? 0 : 1;
+    }
+}
+
+__global__ void bump_kernel(int32_t* c, int32_t d) { *c += d; }
+
+template <typename T>
+static int launch_embed(int64_t rows, int64_t width, const int64_t* ids, int64_t ids_stride, int64_t vocab,
+                        const void* table, void* out,
+                        int64_t ldo, const int32_t* row_zero, int rows_per_seq, hipStream_t s) {
+    constexpr int V = Elem<T>::VEC;
+    const bool vec = (width % V == 0) && (ldo % V == 0) && aligned16(table) && aligned16(out);
+    const unsigned grid = (unsigned)ceil_div(rows, 4);
+    ProfScope ps(BT_PROF_EMBED, s);
+    if (vec)
+        hipLaunchKernelGGL((embed_rows_kernel<T, true>), dim3(grid), dim3(256), 0, s, ids, ids_stride, vocab, (const T*)table,
+                           (T*)out, ldo, rows, (int)width, row_zero, rows_per_seq);
+    else
+        hipLaunchKernelGGL((embed_rows_kernel<T, false>), dim3(grid), dim3(256), 0, s, ids, ids_stride, vocab, (const T*)table,
+                           (T*)out, ldo, rows, (int)width, row_zero, rows_per_seq);
+    BT_LAUNCH_CHECK("bt_embed_rows launch");
+    return BT_OK;
+}
+
+template <typename T>
+static int launch_argmax(int64_t M, int64_t V_, const void* logits, int64_t ld, int64_t* ids_out, int64_t ids_stride,
+                         hipStream_t s) {
+    constexpr int V = Elem<T>::VEC;
+    const bool vec = (V_ % V == 0) && (ld % V == 0) && aligned16(logits);
+    ProfScope ps(BT_PROF_ARGMAX, s);
+    if (vec)
+        hipLaunchKernelGGL((argmax_kernel<T, true>), dim3((unsigned)M), dim3(256), 0, s, (const T*)logits, ld, (int)V_,
+                           ids_out, ids_stride);
+    else
+        hipLaunchKernelGGL((argmax_kernel<T, false>), dim3((unsigned)M), dim3(256), 0, s, (const T*)logits, ld, (int)V_,
+                           ids_out, ids_stride);
+    BT_LAUNCH_CHECK("bt_argmax launch");
+    return BT_OK;
+}
+
+}  // namespace bt
+
+using namespace bt;
+
+extern "C" int bt_embed_rows(int dtype, int64_t rows, int64_t width, const int64_t* ids, int64_t ids_stride,
+                             int64_t vocab, const void* table, void* out, int64_t ldo, const int32_t* row_zero,
+                             int32_t rows_per_seq, bt_stream stream) {
+    BT_CHECK_ARG(dtype == BT_F32 || dtype == BT_BF16, "bt_embed_rows: bad dtype %d", dtype);
+    BT_CHECK_ARG(rows >= 0 && width > 0 && width < (1ll << 31) && vocab > 0, "bt_embed_rows: bad shape");
+    BT_CHECK_ARG(ids && table && out && ldo >= width, "bt_embed_rows: null pointer or short row stride");
+    BT_CHECK_ARG(!row_zero || rows_per_seq > 0, "bt_embed_rows: rows_per_seq must be > 0 with row_zero");
+    if (rows == 0) return BT_OK;
+    if (dtype == BT_BF16)
+        return launch_embed<bf16>(rows, width, ids, ids_stride, vocab, table, out, ldo, row_zero, rows_per_seq, (hipStream_t)stream);
+    return launch_embed<float>(rows, width, ids, ids_stride, vocab, table, out, ldo, row_zero, rows_per_seq, (hipStream_t)stream);
+}
+
+extern "C" int bt_argmax(int dtype, int64_t M, int64_t V, const void* logits, int64_t ld, int64_t* ids_out,
+                         int64_t ids_stride, bt_stream stream) {
+    BT_CHECK_ARG(dtype == BT_F32 || dtype == BT_BF16, "bt_argmax: bad dtype %d", dtype);
+    BT_CHECK_ARG(M >= 0 && V > 0 && V < (1ll << 31) && ld >= V && M < (1ll << 31), "bt_argmax: bad shape");
+    BT_CHECK_ARG(logits && ids_out, "bt_argmax: null pointer");
+    if (M == 0) return BT_OK;
+    if (dtype == BT_BF16) return launch_argmax<bf16>(M, V, logits, ld, ids_out, ids_stride, (hipStream_t)stream);
+    return launch_argmax<float>(M, V, logits, ld, ids_out, ids_stride, (hipStream_t)stream);
+}
+
+extern "C" int bt_topk_sample(int dtype, int64_t M, int64_t V, const void* logits, int64_t ld, float temperature,
+                              int32_t top_k, uint64_t seed, const int32_t* step_dev, int64_t* ids_out,
+                              int64_t ids_stride, bt_stream stream) {
+    BT_CHECK_ARG(dtype == BT_F32 || dtype == BT_BF16, "bt_topk_sample: bad dtype %d", dtype);
+    BT_CHECK_ARG(M >= 0 && V > 0 && V < (1ll << 31) && ld >= V && M < (1ll << 31), "bt_topk_sample: bad shape");
+    BT_CHECK_ARG(logits && ids_out, "bt_topk_sample: null pointer");
+    BT_CHECK_ARG(temperature > 0.f, "bt_topk_sample: temperature must be > 0");
+    if (M == 0) return BT_OK;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(BT_PROF_SAMPLE, s);
+    if (dtype == BT_BF16)
+        hipLaunchKernelGGL(topk_sample_kernel<bf16>, dim3((unsigned)M), dim3(256), 0, s, (const bf16*)logits, ld, (int)V,
+                           1.0f / temperature, top_k, seed, step_dev, ids_out, ids_stride);
+    else
+        hipLaunchKernelGGL(topk_sample_kernel<float>, dim3((unsigned)M), dim3(256), 0, s, (const float*)logits, ld,
+                           (int)V, 1.0f / temperature, top_k, seed, step_dev, ids_out, ids_stride);
+    BT_LAUNCH_CHECK("bt_topk_sample launch");
+    return BT_OK;
+}
+
+extern "C" int bt_finish_block(int64_t B, int32_t L, int32_t count, int64_t* raw, int64_t* out_ids, int64_t nb_max,
+                               const int32_t* blk_dev, int32_t* finished, int32_t* finished_prev, uint8_t* mask,
+                               int64_t mask_ld, int64_t config_pad, int64_t gen_eos, int64_t gen_pad,
+                               bt_stream stream) {
+    BT_CHECK_ARG(B >= 0 && L > 0 && count >= 0 && count <= L, "bt_finish_block: bad shape B=%lld L=%d count=%d",
+                 (long long)B, L, count);
+    BT_CHECK_ARG(raw && out_ids && blk_dev && finished, "bt_finish_block: null pointer");
+    if (B == 0) return BT_OK;
+    ProfScope ps(BT_PROF_FINISH, (hipStream_t)stream);
+    hipLaunchKernelGGL(finish_block_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, L, count, raw, out_ids,
+                       nb_max, blk_dev, finished, finished_prev, mask, mask_ld, config_pad, gen_eos, gen_pad);
+    BT_LAUNCH_CHECK("bt_finish_block launch");
+    return BT_OK;
+}
+
+extern "C" int bt_bump(int32_t* counter, int32_t delta, bt_stream stream) {
+    BT_CHECK_ARG(counter, "bt_bump: null pointer");
+    hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, delta);
+    BT_LAUNCH_CHECK("bt_bump launch");
+    return BT_OK;
+}

@@ -1,0 +1,40 @@
+"""Embedder base class: constructor contract of the reference's BaseEmbedder (model/embedder/base.py:11-105).
+
+Only the ``concat`` projection is on the decode hot path (every block_main_* config); ``projection_layer`` is an
+ablation the reference itself never uses for generation and is rejected loudly."""
+from __future__ import annotations
+
+import warnings
+
+SUPPORTED_PROJECTION_METHODS = ["projection_layer", "concat"]
+
+
+class BaseEmbedder:
+    def __init__(self, config, block_length=4, n_embedding_tokens=1, projection_method=None,
+                 projection_hidden_size=None, init_projection=True):
+        self.block_length = block_length
+        self.n_embedding_tokens = n_embedding_tokens
+        self.hidden_size = config.hidden_size
+        self.projection_method = projection_method
+        self.projection_hidden_size = projection_hidden_size
+        if self.projection_method is None:
+            self.projection_method = "concat"
+            warnings.warn("[BaseEmbedder] projection_method is None, defaulting to concat")
+        self.projection_layer = None
+        if self.projection_method == "concat":
+            if block_length % n_embedding_tokens != 0:
+                raise NotImplementedError(f"block_length must be divisible by n_embedding_tokens, but got "
+                                          f"{block_length} and {n_embedding_tokens}")
+            input_tokens_per_block = block_length // n_embedding_tokens
+            if config.hidden_size is None:
+                raise ValueError("config.hidden_size must be specified when projection_method is concat")
+            if projection_hidden_size != config.hidden_size * input_tokens_per_block:
+                raise ValueError(f"projection_hidden_size must be equal to config.hidden_size * (block_length // "
+                                 f"n_embedding_tokens), but got {projection_hidden_size} and "
+                                 f"{config.hidden_size * (block_length // n_embedding_tokens)}")
+        elif self.projection_method == "projection_layer":
+            raise NotImplementedError("projection_method='projection_layer' is outside the MI355X decode path "
+                                      "(SURVEY.md section 2, row 2): block_main_* configs use 'concat'")
+        else:
+            raise ValueError(f"projection_method must be one of {SUPPORTED_PROJECTION_METHODS}, "
+                             f"got {self.projection_method}")

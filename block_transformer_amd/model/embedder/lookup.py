@@ -1,0 +1,68 @@
+"""LookupEmbedder — same constructor, attributes and forward contract as the reference's
+model/embedder/lookup.py:10-87; the gather + concat runs in libbt_hip.so (bt_embed_rows)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch import nn
+
+from ... import ops
+from .base import BaseEmbedder
+
+
+class LookupConfig:
+    model_type = "lookup"
+
+    def __init__(self, bos_token_id=None, eos_token_id=None, pad_token_id=None, vocab_size=None, hidden_size=None,
+                 initializer_range=0.02, **kwargs):
+        self.bos_token_id = bos_token_id
+        self.eos_token_id = eos_token_id
+        self.pad_token_id = pad_token_id
+        self.vocab_size = vocab_size
+        self.hidden_size = hidden_size
+        self.initializer_range = initializer_range
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+
+class LookupEmbedder(nn.Module, BaseEmbedder):
+    config_class = LookupConfig
+
+    def __init__(self, config: LookupConfig, block_length=8, n_embedding_tokens=8, projection_method=None,
+                 projection_hidden_size=None, init_projection=True):
+        if config.vocab_size is None:
+            raise ValueError("config.vocab_size must be specified")
+        if projection_method is None:
+            projection_method = "concat"
+        if projection_hidden_size is None:
+            raise ValueError("projection_hidden_size must be specified")
+        input_tokens_per_block = block_length // n_embedding_tokens
+        hidden_size = projection_hidden_size // input_tokens_per_block
+        if config.hidden_size is None:
+            print(f"Setting hidden_size of embedder to {hidden_size}")
+            config.hidden_size = hidden_size
+        elif projection_method == "concat" and config.hidden_size != hidden_size:
+            raise ValueError(f"config.hidden_size must be equal to projection_hidden_size // "
+                             f"(block_length // n_embedding_tokens), but got {config.hidden_size} and {hidden_size}")
+        nn.Module.__init__(self)
+        self.config = config
+        self.embeddings = nn.Embedding(config.vocab_size, config.hidden_size, padding_idx=config.pad_token_id)
+        BaseEmbedder.__init__(self, config, block_length, n_embedding_tokens, projection_method,
+                              projection_hidden_size, init_projection)
+        self.embeddings.weight.data.normal_(mean=0.0, std=config.initializer_range)
+        if self.embeddings.padding_idx is not None:
+            self.embeddings.weight.data[self.embeddings.padding_idx].zero_()
+
+    @torch.no_grad()
+    def forward(self, input_ids: Optional[torch.Tensor] = None, attention_mask: Optional[torch.Tensor] = None,
+                **kwargs):
+        """[..., block_length] ids -> [N, n_embedding_tokens, projection_hidden_size].  The attention mask is ignored,
+        exactly like the reference's lookup embedder (Q4)."""
+        if input_ids is None:
+            raise ValueError("input_ids must be specified")
+        input_ids = input_ids.reshape(-1, input_ids.shape[-1])
+        if input_ids.shape[-1] != self.block_length:
+            raise ValueError(f"Sequence length must be {self.block_length}, but got {input_ids.shape[-1]}")
+        rows = ops.embed_rows(input_ids, self.embeddings.weight)  # [N, L, h_e]
+        return rows.view(input_ids.shape[0], self.n_embedding_tokens, -1)

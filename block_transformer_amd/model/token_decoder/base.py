@@ -1,0 +1,55 @@
+"""Token decoder base: constructor contract of the reference's BaseTokenDecoder (model/token_decoder/base.py:11-75).
+
+Only decoding_strategy='prefix' with expansion_method='expansion_layer' is on the decode hot path (every
+block_main_* config); the summation / cross-attention ablation strategies (:504-552) are rejected loudly."""
+from __future__ import annotations
+
+import warnings
+
+from torch import nn
+
+
+class BaseTokenDecoder:
+    def __init__(self, config, block_length, n_embedding_tokens=None, projection_hidden_size=None,
+                 expansion_method=None, expansion_ratio: int = None, init_expansion=True, decoding_strategy=None):
+        self.config = config
+        self.block_length = block_length
+        self.n_embedding_tokens = n_embedding_tokens
+        self.expansion_ratio = expansion_ratio
+        if self.expansion_ratio is None:
+            if decoding_strategy in ["summation", "cross_attention"]:
+                self.expansion_ratio = block_length
+            elif decoding_strategy == "prefix":
+                raise ValueError("`expansion_ratio` must be specified for decoding_strategy='prefix'")
+            else:
+                raise ValueError(f"Invalid decoding_strategy {decoding_strategy}")
+        if decoding_strategy != "prefix":
+            raise NotImplementedError(f"decoding_strategy={decoding_strategy!r} is outside the MI355X decode path "
+                                      "(SURVEY.md section 2, row 4): block_main_* configs use 'prefix'")
+        if n_embedding_tokens != 1:
+            raise NotImplementedError("generation currently only implemented for n_embedding_tokens == 1")
+        self.n_expanded_emb = self.n_embedding_tokens * self.expansion_ratio
+        self.hidden_size = config.hidden_size
+        self.projection_hidden_size = projection_hidden_size
+        self.expansion_method = expansion_method
+        self.decoding_strategy = decoding_strategy
+        if self.config.bos_token_id is None:
+            self.config.bos_token_id = self.config.eos_token_id
+        if self.expansion_method == "expansion_layer":
+            self.expansion_layer = nn.Conv1d(in_channels=self.projection_hidden_size,
+                                             out_channels=self.hidden_size * self.expansion_ratio,
+                                             kernel_size=1, stride=1, padding=0)
+            if init_expansion:
+                self._init_expansion_layer()
+            else:
+                warnings.warn("[BaseTokenDecoder] `init_expansion=False`")
+        else:
+            raise NotImplementedError("expansion_method=None (repeat_interleave) is outside the MI355X decode path: "
+                                      "block_main_* configs use 'expansion_layer'")
+        if config.pad_token_id is None:
+            config.pad_token_id = config.eos_token_id
+
+    def _init_expansion_layer(self):
+        self.expansion_layer.weight.data.normal_(mean=0.0, std=self.projection_hidden_size ** -0.5)
+        if self.expansion_layer.bias is not None:
+            self.expansion_layer.bias.data.zero_()

@@ -1,0 +1,104 @@
+"""Data-parallel request sharding for the decode engine: one process per GPU, independent request shards.
+
+The decode path shards naturally: sequences share no state, weights are replicated read-only, so the
+steady state has NO data-path collective.  ``torch.distributed`` (backend "nccl" == RCCL over xGMI on ROCm, "gloo" on
+CPU for tests) is used only for: the launch/timing barrier, the max-over-ranks elapsed time, the sum of generated
+tokens, and (optionally) gathering the generated ids on rank 0."""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_world() -> Tuple[int, int, int]:
+    """(rank, world_size, local_rank) from the torchrun environment (defaults: single process)."""
+    return (int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0)))
+
+
+def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
+    rank, world, local = env_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard_bounds(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous balanced shard [lo, hi) of ``n_items`` requests for ``rank`` (first n % world ranks get one more)."""
+    if not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world of {world}")
+    q, r = divmod(n_items, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def shard_requests(input_ids: torch.Tensor, rank: int, world: int, *others: Optional[torch.Tensor]):
+    lo, hi = shard_bounds(input_ids.shape[0], rank, world)
+    out = [input_ids[lo:hi]] + [None if o is None else o[lo:hi] for o in others]
+    return out[0] if not others else tuple(out)
+
+
+def _device_for_collectives() -> torch.device:
+    if dist.is_initialized() and dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
+def barrier() -> None:
+    """Launch barrier: one tiny all-reduce (RCCL over xGMI on the GPU box)."""
+    if dist.is_initialized():
+        t = torch.zeros(1, dtype=torch.int32, device=_device_for_collectives())
+        dist.all_reduce(t)
+        if t.is_cuda:
+            torch.cuda.synchronize()
+
+
+def max_over_ranks(value: float) -> float:
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=_device_for_collectives())
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def sum_over_ranks(value: float) -> float:
+    if not dist.is_initialized():
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=_device_for_collectives())
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return float(t.item())
+
+
+def gather_ids(local_ids: torch.Tensor, n_total: int) -> Optional[torch.Tensor]:
+    """Concatenate every rank's generated ids (shard order == request order); returned on every rank."""
+    if not dist.is_initialized():
+        return local_ids
+    world = dist.get_world_size()
+    dev = _device_for_collectives()
+    width = local_ids.shape[1]
+    per = -(-n_total // world)
+    buf = torch.zeros(per, width, dtype=torch.int64, device=dev)
+    buf[: local_ids.shape[0]] = local_ids.to(dev)
+    parts: List[torch.Tensor] = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(parts, buf)
+    out = []
+    for r in range(world):
+        lo, hi = shard_bounds(n_total, r, world)
+        out.append(parts[r][: hi - lo])
+    return torch.cat(out, dim=0)
+
+
+def generate_sharded(generate_fn, input_ids: torch.Tensor, **kw) -> torch.Tensor:
+    """Run ``generate_fn`` on this rank's request shard and gather the full result."""
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+    lo, hi = shard_bounds(input_ids.shape[0], rank, world)
+    local = generate_fn(input_ids[lo:hi], **kw) if hi > lo else input_ids.new_zeros(0, kw.get("max_length", 0))
+    return gather_ids(local, input_ids.shape[0])

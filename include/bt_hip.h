@@ -1,0 +1,207 @@
+/*
+ * bt_hip.h — C-ABI of libbt_hip.so, the MI355X (gfx950) kernel library behind the Block Transformer decode path.
+ *
+ * This is the drop-in boundary B2 of SURVEY.md section 8(b).  The reference (itsnamgyu/block-transformer) has no
+ * native code: its decode arithmetic is issued through PyTorch/HF `transformers==4.39.3` GPT-NeoX modules and
+ * flash-attn.  Each entry point below therefore cites the reference *Python* interface whose arithmetic it
+ * replaces (paths relative to the reference repo root).  The Python host side (block_transformer_amd/model/...)
+ * keeps the reference's module API and binds these symbols with ctypes.
+ *
+ * Contract (every entry point):
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless the name ends in `_host`;
+ *   - never allocates or frees device memory (the caller passes workspaces), never synchronises the stream,
+ *     no internal threads; re-entrant per (device, stream);
+ *   - enqueues its kernels on `stream` (a hipStream_t passed as void*; NULL = the null stream) and returns
+ *     BT_OK (0) or a negative bt_status; `bt_last_error()` returns a thread-local message;
+ *   - safe inside hipStreamBeginCapture / hipGraph capture (no host reads of device memory): values that change
+ *     between graph replays (number of cached global positions) are read from device scalars.
+ *
+ * Data layout in HBM (dtype T = float or bf16, selected by `dtype`):
+ *   activations      x[M, H]                 row-major, explicit row stride (elements)
+ *   fused QKV rows   qkv[M, 3H]              HF GPT-NeoX per-head interleaved: col = head*3d + {q:0..d-1,k:d..2d-1,v:2d..3d-1}
+ *   weights          W[N, K]                 HF nn.Linear layout (out_features, in_features), row-major, unchanged
+ *   global KV cache  K,V[layer][B][heads][Nmax][d]   one (k,v) per L-token block; K stored post-RoPE
+ *   local  KV cache  K,V[layer][B][heads][E+L-1][d]  token-decoder window; "reset" = start writing at row 0 again
+ *   block mask       mask[B, mask_ld] uint8  1 = key visible (reference block_attention_mask)
+ *   RoPE tables      cos,sin[max_pos, rot/2] float32, angle = pos * base^(-2j/rot)
+ *   token ids        int64 (torch.long)
+ */
+#ifndef BT_HIP_H
+#define BT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BT_VERSION 100 /* 0.1.0 */
+
+typedef void* bt_stream; /* hipStream_t */
+
+enum bt_dtype { BT_F32 = 0, BT_BF16 = 1 };
+enum bt_act { BT_ACT_NONE = 0, BT_ACT_GELU = 1 /* exact erf GELU, HF hidden_act="gelu" */ };
+enum bt_status {
+    BT_OK = 0,
+    BT_ERR_ARG = -1,         /* bad shape / null pointer / misalignment */
+    BT_ERR_UNSUPPORTED = -2, /* dtype or head_dim not instantiated */
+    BT_ERR_WORKSPACE = -3,   /* workspace too small */
+    BT_ERR_HIP = -4          /* a HIP runtime call failed (message has hipGetErrorString) */
+};
+
+/* Shape of one GPT-NeoX stack (HF GPTNeoXConfig fields the decode path reads). */
+typedef struct bt_decoder_dims {
+    int32_t hidden;   /* H */
+    int32_t heads;
+    int32_t head_dim; /* d = H / heads: 32, 64 or 128 */
+    int32_t rot;      /* rotary_ndims = int(d * rotary_pct) */
+    int32_t inter;    /* intermediate_size */
+    int32_t layers;
+    float ln_eps;
+} bt_decoder_dims;
+
+/* One layer's parameters, HF names: input_layernorm, post_attention_layernorm, attention.query_key_value,
+ * attention.dense, mlp.dense_h_to_4h, mlp.dense_4h_to_h (weight [out,in], bias [out]). */
+typedef struct bt_layer_weights {
+    const void *ln1_w, *ln1_b, *ln2_w, *ln2_b;
+    const void *qkv_w, *qkv_b;
+    const void *dense_w, *dense_b;
+    const void *h4_w, *h4_b;
+    const void *h_w, *h_b;
+} bt_layer_weights;
+
+typedef struct bt_decoder_weights {
+    const bt_layer_weights* layers_host; /* HOST array of `dims.layers` entries (device pointers inside) */
+    const void *lnf_w, *lnf_b;           /* final_layer_norm */
+} bt_decoder_weights;
+
+/* ------------------------------------------------------------------------------------------------------------ */
+int bt_version(void);
+const char* bt_last_error(void);
+/* Number of bytes of activation workspace bt_decoder_forward needs for M rows. */
+int64_t bt_decoder_workspace_bytes(const bt_decoder_dims* dims, int dtype, int64_t M);
+
+/* ---- single ops (each replaces one ATen/cuBLAS/flash-attn call pattern of SURVEY.md section 2.2) -------------- */
+
+/* out[M,N] = act(A[M,K] . W[N,K]^T + bias[N]) + residual[M,N]     (C3, C7, C8, C9, C10, C11)
+ * Replaces nn.Linear / Conv1d(k=1) calls inside HF GPTNeoXAttention/GPTNeoXMLP (reference call sites
+ * model/block_decoder/gpt_neo_x.py:100-111, model/token_decoder/gpt_neo_x.py:59-74) and
+ * BaseTokenDecoder.expand_block_embeddings (model/token_decoder/base.py:118-139).
+ * bias/residual may be NULL.  bf16: MFMA kernel when K % 64 == 0 and rows are 16-byte aligned. */
+int bt_linear(int dtype, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* W,
+              const void* bias, const void* residual, int64_t ldr, void* out, int64_t ldo, int act,
+              bt_stream stream);
+
+/* LayerNorm of the same row with one or two affine sets (parallel residual reads LN1(x) and LN2(x)):  (C2)
+ * out1 = LN(x)*w1+b1, out2 = LN(x)*w2+b2 (out2/w2/b2 may be NULL).  HF GPTNeoXLayer.input_layernorm /
+ * post_attention_layernorm / GPTNeoXModel.final_layer_norm. */
+int bt_layernorm(int dtype, int64_t M, int64_t H, const void* x, int64_t ldx, const void* w1, const void* b1,
+                 void* out1, int64_t ldo1, const void* w2, const void* b2, void* out2, int64_t ldo2, float eps,
+                 bt_stream stream);
+
+/* out[r, :] = table[ids[r*ids_stride], :] (width elements per row); if row_zero != NULL and row_zero[r / rows_per_seq] != 0
+ * the row is zero-filled.  With ids[B*L] and width h_e the output viewed as [B, L*h_e] IS the concat projection:
+ * LookupEmbedder.forward (model/embedder/lookup.py:71-87) + BaseEmbedder.project_hidden_state concat branch
+ * (model/embedder/base.py:79-89); with width H it is GPTNeoXTokenDecoder.embed_input_ids
+ * (model/token_decoder/gpt_neo_x.py:52-53).  (C1) */
+int bt_embed_rows(int dtype, int64_t rows, int64_t width, const int64_t* ids, int64_t ids_stride, int64_t vocab,
+                  const void* table, void* out, int64_t ldo, const int32_t* row_zero, int32_t rows_per_seq,
+                  bt_stream stream);
+
+/* Partial RoPE on q and k of `q_len` new rows per sequence, in place in qkv, and append of (k_rot, v) to a KV cache:
+ *   cache row = pos0 + t (t < q_len), RoPE angle position = pos_table ? pos_table[pos0+t] : pos0 + t,
+ *   pos0 = pos0_dev ? *pos0_dev : pos0_host.
+ * Replaces HF apply_rotary_pos_emb + the torch.cat KV growth (C4, C5).  qkv rows are ordered [b][t]. */
+int bt_rope_kv_append(int dtype, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim, int32_t rot, void* qkv,
+                      int64_t ld_qkv, void* k_cache, void* v_cache, int64_t n_max, const int32_t* pos0_dev,
+                      int32_t pos0_host, const int32_t* pos_table, const float* cos_tab, const float* sin_tab,
+                      bt_stream stream);
+
+/* Causal softmax attention of q_len (already rotated) query rows per sequence over the cache:
+ *   query t sees keys j <= pos0 + t with mask[b, j] != 0 (mask may be NULL);  out[b*q_len+t, head*d + :]
+ * mode: 0 = row-wise streaming kernel (decode: q_len = 1 global step, or the token decoder's <= E+L-1 window);
+ *       1 = MFMA flash kernel (bf16 prefill).  Replaces flash-attn fwd / eager baddbmm+softmax+matmul (C6).
+ * `ws`/`ws_bytes`: scratch for split-N partials (may be NULL when n_split == 1).  Rows whose keys are all masked
+ * produce zeros (the reference leaves them unspecified: finfo.min arithmetic). */
+int bt_attention(int dtype, int mode, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim, const void* qkv,
+                 int64_t ld_qkv, const void* k_cache, const void* v_cache, int64_t n_max, const int32_t* pos0_dev,
+                 int32_t pos0_host, const uint8_t* mask, int64_t mask_ld, void* out, int64_t ldo, int32_t n_split,
+                 void* ws, int64_t ws_bytes, bt_stream stream);
+
+/* ids_out[r*ids_stride] = argmax_j logits[r, j] (first maximal index, torch.argmax semantics).  HF greedy_search (C12). */
+int bt_argmax(int dtype, int64_t M, int64_t V, const void* logits, int64_t ld, int64_t* ids_out, int64_t ids_stride,
+              bt_stream stream);
+
+/* HF sample(): logits/temperature -> top-k filter -> softmax -> multinomial, one draw per row with a counter-based
+ * RNG keyed by (seed, *step_dev, row).  Distributional parity only (sampling).  (C12) */
+int bt_topk_sample(int dtype, int64_t M, int64_t V, const void* logits, int64_t ld, float temperature, int32_t top_k,
+                   uint64_t seed, const int32_t* step_dev, int64_t* ids_out, int64_t ids_stride, bt_stream stream);
+
+/* ---- composite: one GPT-NeoX stack over M = B*q_len rows (what GPTNeoXModel.forward does for inputs_embeds) ---- */
+typedef struct bt_attn_args {
+    void* k_cache;           /* [layers][B_alloc][heads][n_max][d]; points at this call's first sequence */
+    void* v_cache;
+    int64_t layer_stride;    /* elements between consecutive layers (= B_alloc*heads*n_max*d) */
+    int64_t n_max;
+    const int32_t* pos0_dev; /* device scalar: first cache row written by this call (NULL -> pos0_host) */
+    int32_t pos0_host;
+    const int32_t* pos_table; /* optional RoPE position indirection (token decoder policy table) */
+    const uint8_t* mask;      /* [B, mask_ld] or NULL */
+    int64_t mask_ld;
+    const float* cos_tab;
+    const float* sin_tab;
+    int32_t mode;    /* bt_attention mode */
+    int32_t n_split; /* split-N factor for mode 0 */
+    void* split_ws;
+    int64_t split_ws_bytes;
+} bt_attn_args;
+
+/* x[M,H] (row stride H) -> NL x {LN1|LN2, QKV, RoPE+append, attention, dense(+x), h_to_4h+GELU, 4h_to_h(+)} ->
+ * final LN of rows (row % q_len) >= first_out_row into out[B*(q_len-first_out_row), H].
+ * x is overwritten (residual stream).  GPTNeoXBlockDecoder.forward (model/block_decoder/gpt_neo_x.py:71-126) and
+ * GPTNeoXTokenDecoder.model_forward (model/token_decoder/gpt_neo_x.py:55-71). */
+int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const bt_decoder_weights* w, int64_t B, int32_t q_len,
+                       void* x, const bt_attn_args* attn, int32_t first_out_row, void* out, void* ws,
+                       int64_t ws_bytes, bt_stream stream);
+
+/* ---- roll-over bookkeeping (BlockTransformer.generate, model/block_transformer.py:381-426) -------------------- */
+/* Finish one generated block on device: apply the HF greedy_search EOS/pad rules to raw tokens raw[B, L]
+ * (first `count` columns valid; rewritten in place with the final tokens), write them to out_ids[b, *blk_dev, :],
+ * copy finished[] to finished_prev[] (the reference's decode_mask of this iteration: rows that get re-embedded),
+ * update finished[b], and append the block mask column mask[b, *blk_dev] = !finished[b] (mask may be NULL).
+ * gen_eos < 0 disables EOS handling (benchmark protocol, measure_generation_time.py:90). */
+int bt_finish_block(int64_t B, int32_t L, int32_t count, int64_t* raw, int64_t* out_ids, int64_t nb_max,
+                    const int32_t* blk_dev, int32_t* finished, int32_t* finished_prev, uint8_t* mask,
+                    int64_t mask_ld, int64_t config_pad, int64_t gen_eos, int64_t gen_pad, bt_stream stream);
+/* *counter += delta (device scalar bump inside a captured graph). */
+int bt_bump(int32_t* counter, int32_t delta, bt_stream stream);
+
+/* ---- hipGraph helpers (capture the block step once, replay per block) ------------------------------------------ */
+typedef struct bt_graph bt_graph;
+int bt_graph_begin_capture(bt_stream stream);
+int bt_graph_end_capture(bt_stream stream, bt_graph** out);
+int bt_graph_launch(bt_graph* g, bt_stream stream);
+int bt_graph_destroy(bt_graph* g);
+
+/* ---- timing helpers for bench.py (HIP events on the launch stream) ---------------------------------------------- */
+typedef struct bt_event bt_event;
+int bt_event_create(bt_event** out);
+int bt_event_record(bt_event* e, bt_stream stream);
+int bt_event_elapsed_ms(bt_event* start, bt_event* stop, float* ms_out); /* synchronises on `stop` */
+int bt_event_destroy(bt_event* e);
+
+/* ---- built-in per-kernel-family timer (bench.py roofline leg; eager launches only, not inside graph capture) ----------
+ * When enabled every op brackets its kernel(s) with a hipEvent pair on the launch stream; bt_prof_collect()
+ * synchronises and returns accumulated milliseconds and launch counts per family. */
+enum bt_prof_family {
+    BT_PROF_LINEAR_MFMA = 0, BT_PROF_LINEAR_GENERIC = 1, BT_PROF_LAYERNORM = 2, BT_PROF_EMBED = 3, BT_PROF_ROPE = 4,
+    BT_PROF_ATTN_ROWS = 5, BT_PROF_ATTN_FLASH = 6, BT_PROF_ARGMAX = 7, BT_PROF_SAMPLE = 8, BT_PROF_FINISH = 9,
+    BT_PROF_NFAM = 10
+};
+int bt_prof_enable(int on);                                          /* clears previous records */
+int bt_prof_collect(double* ms_out, int64_t* count_out, int n_fam); /* n_fam = BT_PROF_NFAM */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BT_HIP_H */

@@ -1,0 +1,385 @@
+"""Per-kernel parity tests (GPU): every C-ABI op against an fp32/fp64 CPU reference of the same op on the same seeded
+inputs.  fp32 instantiations: <= 1e-4 abs/rel; bf16 instantiations: compared with the reference evaluated on the
+bf16-rounded inputs, tolerance ~2 bf16 ulps of the output scale (stated per test)."""
+import ctypes
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from block_transformer_amd import _lib, ops  # noqa: E402
+from block_transformer_amd._lib import check, current_stream, dtype_code, lib, ptr  # noqa: E402
+
+DEV = "cuda"
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=g(seed)) * scale
+
+
+def rel_err(a, b):
+    return ((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-12)).item()
+
+
+# ---- bt_linear --------------------------------------------------------------------------------------------------------------
+LINEAR_SHAPES = [(1, 64, 64), (5, 192, 64), (128, 128, 64), (130, 260, 128), (64, 256, 1024), (300, 6144, 256),
+                 (257, 2048, 2048), (3, 100, 40), (33, 50304 // 8, 128)]
+
+
+@pytest.mark.parametrize("M,N,K", LINEAR_SHAPES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("variant", ["plain", "bias_gelu", "bias_res"])
+def test_linear(M, N, K, dtype, variant):
+    x = rnd(M, K, seed=1).to(dtype)
+    w = rnd(N, K, seed=2, scale=K ** -0.5).to(dtype)
+    b = rnd(N, seed=3).to(dtype) if variant != "plain" else None
+    r = rnd(M, N, seed=4).to(dtype) if variant == "bias_res" else None
+    ref = x.double() @ w.double().T
+    if b is not None:
+        ref = ref + b.double()
+    if variant == "bias_gelu":
+        ref = F.gelu(ref)
+    if r is not None:
+        ref = ref + r.double()
+    out = ops.linear(x.to(DEV), w.to(DEV), None if b is None else b.to(DEV), None if r is None else r.to(DEV),
+                     act="gelu" if variant == "bias_gelu" else "none").cpu()
+    tol = 2e-5 if dtype == torch.float32 else 1.2e-2   # bf16: output rounding (2^-8) + accumulation order
+    assert rel_err(out, ref) <= tol, (rel_err(out, ref), tol)
+
+
+def test_linear_mfma_equals_generic_bf16():
+    """A/B of the MFMA kernel against the simple tiled kernel on identical bf16 inputs (same fp32 accumulate)."""
+    x = rnd(200, 512, seed=5).bfloat16().to(DEV)
+    w = rnd(384, 512, seed=6, scale=0.05).bfloat16().to(DEV)
+    b = rnd(384, seed=7).bfloat16().to(DEV)
+    a = ops.linear(x, w, b, act="gelu").float().cpu()
+    lib().bt_debug_force_generic_gemm(1)
+    try:
+        c = ops.linear(x, w, b, act="gelu").float().cpu()
+    finally:
+        lib().bt_debug_force_generic_gemm(0)
+    assert (a - c).abs().max() <= 2e-2 * c.abs().max()
+    # asymmetric operands catch an n/m transposed C-write: compare against the exact reference too
+    ref = F.gelu(x.double().cpu() @ w.double().cpu().T + b.double().cpu())
+    assert rel_err(a, ref) <= 1.2e-2
+
+
+def test_linear_strided_inplace_residual():
+    """Row strides + in-place residual (x += att @ Wd^T + b), the way bt_decoder_forward calls it."""
+    for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 1.2e-2)):
+        big = rnd(40, 2 * 128, seed=8).to(dtype).to(DEV)
+        a = big[:, 128:]                       # lda = 256, rows start mid-row
+        w = rnd(128, 128, seed=9, scale=0.1).to(dtype).to(DEV)
+        b = rnd(128, seed=10).to(dtype).to(DEV)
+        x = rnd(40, 128, seed=11).to(dtype).to(DEV)
+        ref = x.double().cpu() + a.double().cpu() @ w.double().cpu().T + b.double().cpu()
+        ops.linear(a, w, b, residual=x, out=x)
+        assert rel_err(x.cpu(), ref) <= tol
+
+
+# ---- bt_layernorm -----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,H", [(1, 64), (7, 256), (33, 2048), (5, 100)])
+def test_layernorm_dual(dtype, M, H):
+    x = (rnd(M, H, seed=1) * 3 + 0.5).to(dtype)
+    w1, b1, w2, b2 = [(rnd(H, seed=s) * 0.5 + (1 if s % 2 == 0 else 0)).to(dtype) for s in (2, 3, 4, 5)]
+    o1, o2 = ops.layernorm(x.to(DEV), w1.to(DEV), b1.to(DEV), 1e-5, w2.to(DEV), b2.to(DEV))
+    r1 = F.layer_norm(x.double(), (H,), w1.double(), b1.double(), 1e-5)
+    r2 = F.layer_norm(x.double(), (H,), w2.double(), b2.double(), 1e-5)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert rel_err(o1.cpu(), r1) <= tol and rel_err(o2.cpu(), r2) <= tol
+    o = ops.layernorm(x.to(DEV), w1.to(DEV), b1.to(DEV), 1e-5)
+    assert rel_err(o.cpu(), r1) <= tol
+
+
+def test_layernorm_strided_rows():
+    """final_layer_norm of the last prefix row only: input row stride q_len*H."""
+    B, q, H = 6, 2, 128
+    x = rnd(B * q, H, seed=1).to(DEV)
+    w, b = rnd(H, seed=2).to(DEV), rnd(H, seed=3).to(DEV)
+    out = torch.empty(B, H, device=DEV)
+    xin = x[1::q]
+    check(lib().bt_layernorm(_lib.BT_F32, B, H, ptr(xin), q * H, ptr(w), ptr(b), ptr(out), H, None, None, None, 0, 1e-5,
+                             current_stream()))
+    ref = F.layer_norm(x.cpu()[1::q].double(), (H,), w.cpu().double(), b.cpu().double(), 1e-5)
+    assert rel_err(out.cpu(), ref) <= 1e-5
+
+
+# ---- bt_embed_rows ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("width", [16, 64, 512, 6])
+def test_embed_rows(dtype, width):
+    V, B, L = 300, 9, 4
+    table = rnd(V, width, seed=1).to(dtype)
+    ids = torch.randint(0, V, (B, L), generator=g(2))
+    out = ops.embed_rows(ids.to(DEV), table.to(DEV)).cpu()
+    assert torch.equal(out, table[ids])                       # gather is bit-exact
+    # concat projection view + zero rows for finished sequences
+    zero = torch.tensor([0, 1, 0, 0, 1, 0, 0, 0, 1], dtype=torch.int32)
+    o2 = torch.empty(B, L * width, dtype=dtype, device=DEV)
+    ops.embed_rows(ids.to(DEV).view(-1), table.to(DEV), out=o2.view(B * L, width), row_zero=zero.to(DEV), rows_per_seq=L)
+    ref = table[ids].reshape(B, L * width).clone()
+    ref[zero.bool()] = 0
+    assert torch.equal(o2.cpu(), ref)
+    # strided ids (column of a [B, L] buffer), as the token loop reads its previous token
+    col = ids.to(DEV)[:, 2]
+    o3 = ops.embed_rows(col, table.to(DEV)).cpu()
+    assert torch.equal(o3, table[ids[:, 2]])
+
+
+# ---- bt_rope_kv_append ------------------------------------------------------------------------------------------------------
+def rope_ref(x, pos, rot, base=10000.0):
+    """x [..., d] double; HF rotate_half pairs (j, j + rot/2)."""
+    half = rot // 2
+    inv = 1.0 / (base ** (torch.arange(0, rot, 2, dtype=torch.float64) / rot))
+    ang = pos.double()[..., None] * inv
+    c, s = ang.cos(), ang.sin()
+    x1, x2, rest = x[..., :half], x[..., half:rot], x[..., rot:]
+    return torch.cat([x1 * c - x2 * s, x2 * c + x1 * s, rest], -1)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("d,rot", [(32, 8), (64, 16), (128, 32)])
+@pytest.mark.parametrize("use_dev_pos,use_table", [(False, False), (True, False), (False, True)])
+def test_rope_kv_append(dtype, d, rot, use_dev_pos, use_table):
+    B, q, heads, n_max, pos0 = 3, 2, 2, 12, 5
+    H = heads * d
+    qkv = rnd(B * q, 3 * H, seed=1).to(dtype)
+    kc = torch.zeros(B, heads, n_max, d, dtype=dtype, device=DEV)
+    vc = torch.zeros_like(kc)
+    tab = ops.rope_tables(64, rot, 10000.0, DEV)
+    table = torch.tensor([0, 0, 1, 2, 3, 7, 9, 4, 1, 2, 3, 4], dtype=torch.int32, device=DEV) if use_table else None
+    pos_dev = torch.tensor([pos0], dtype=torch.int32, device=DEV) if use_dev_pos else None
+    qd = qkv.to(DEV).clone()
+    check(lib().bt_rope_kv_append(dtype_code(dtype), B, q, heads, d, rot, ptr(qd), 3 * H, ptr(kc), ptr(vc), n_max,
+                                  ptr(pos_dev), 0 if use_dev_pos else pos0, ptr(table), ptr(tab[0]), ptr(tab[1]),
+                                  current_stream()))
+    x = qkv.double().view(B, q, heads, 3, d)
+    rows = torch.arange(pos0, pos0 + q)
+    rp = table.cpu()[rows].long() if use_table else rows
+    pos = rp.view(1, q, 1).expand(B, q, heads)
+    q_ref = rope_ref(x[..., 0, :], pos, rot)
+    k_ref = rope_ref(x[..., 1, :], pos, rot)
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    got = qd.cpu().double().view(B, q, heads, 3, d)
+    assert rel_err(got[..., 0, :], q_ref) <= tol
+    assert torch.equal(got[..., 1:, :], x[..., 1:, :].to(dtype).double()), "k/v columns of qkv must be untouched"
+    kcc, vcc = kc.cpu().double(), vc.cpu().double()
+    assert rel_err(kcc[:, :, pos0:pos0 + q].permute(0, 2, 1, 3), k_ref) <= tol
+    assert torch.equal(vcc[:, :, pos0:pos0 + q].permute(0, 2, 1, 3), x[..., 2, :])
+    assert kcc[:, :, :pos0].abs().max() == 0 and kcc[:, :, pos0 + q:].abs().max() == 0
+
+
+# ---- bt_attention -------------------------------------------------------------------------------------------------------------
+def attn_ref(qkv, kc, vc, B, q, heads, d, pos0, mask):
+    """fp64 reference: query t sees keys j <= pos0+t with mask[b, j]; fully-masked rows -> 0."""
+    x = qkv.double().view(B, q, heads, 3, d)
+    qh = x[..., 0, :].permute(0, 2, 1, 3)                    # [B, heads, q, d]
+    n = pos0 + q
+    k, v = kc.double()[:, :, :n], vc.double()[:, :, :n]
+    s = qh @ k.transpose(-1, -2) / math.sqrt(d)
+    vis = torch.ones(q, n, dtype=torch.bool).tril(diagonal=pos0)[None, None].expand(B, heads, q, n).clone()
+    if mask is not None:
+        vis &= mask.bool()[:, None, None, :n]
+    s = s.masked_fill(~vis, float("-inf"))
+    p = torch.softmax(s, -1)
+    p = torch.nan_to_num(p, nan=0.0)
+    return (p @ v).permute(0, 2, 1, 3).reshape(B * q, heads * d)
+
+
+def run_attention(dtype, mode, B, q, heads, d, pos0, n_max, mask, n_split=1, dev_pos=False, seed=0):
+    H = heads * d
+    qkv = rnd(B * q, 3 * H, seed=seed + 1).to(dtype)
+    kc = rnd(B, heads, n_max, d, seed=seed + 2).to(dtype)
+    vc = rnd(B, heads, n_max, d, seed=seed + 3).to(dtype)
+    out = torch.full((B * q, H), float("nan"), dtype=dtype, device=DEV)
+    ws = torch.empty(B * heads * q * max(n_split, 32) * (d + 2), dtype=torch.float32, device=DEV)
+    pos_dev = torch.tensor([pos0], dtype=torch.int32, device=DEV) if dev_pos else None
+    m = None if mask is None else mask.to(torch.uint8).to(DEV)
+    check(lib().bt_attention(dtype_code(dtype), mode, B, q, heads, d, ptr(qkv.to(DEV)), 3 * H, ptr(kc.to(DEV)),
+                             ptr(vc.to(DEV)), n_max, ptr(pos_dev), 0 if dev_pos else pos0, ptr(m),
+                             0 if m is None else m.stride(0), ptr(out), H, n_split, ptr(ws), ws.numel() * 4,
+                             current_stream()))
+    ref = attn_ref(qkv, kc, vc, B, q, heads, d, pos0, mask)
+    return out.cpu(), ref
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("d", [32, 64, 128])
+@pytest.mark.parametrize("q,pos0,n_max", [(1, 0, 5), (1, 4, 5), (2, 0, 5), (1, 37, 64), (1, 543, 544), (3, 250, 300),
+                                          (1, 1000, 1100)])
+def test_attention_rows(dtype, d, q, pos0, n_max):
+    out, ref = run_attention(dtype, 0, 3, q, 2, d, pos0, n_max, None)
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    assert rel_err(out, ref) <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n_split", [2, 5, 16])
+def test_attention_rows_split_and_device_position(dtype, n_split):
+    out, ref = run_attention(dtype, 0, 2, 1, 2, 128, 300, 512, None, n_split=n_split, dev_pos=True)
+    tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+    assert rel_err(out, ref) <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attention_rows_mask(dtype):
+    B, n_max, pos0 = 4, 96, 80
+    mask = (torch.rand(B, n_max, generator=g(5)) > 0.3).long()
+    mask[1, :] = 0            # a fully masked sequence -> zeros
+    mask[2, : pos0 + 1] = 1
+    for n_split in (1, 3):
+        out, ref = run_attention(dtype, 0, B, 1, 2, 64, pos0, n_max, mask, n_split=n_split)
+        tol = 2e-5 if dtype == torch.float32 else 1.5e-2
+        assert rel_err(out, ref) <= tol
+        assert out.view(B, -1)[1].abs().max() == 0
+
+
+@pytest.mark.parametrize("d", [32, 64, 128])
+@pytest.mark.parametrize("q,pos0", [(5, 0), (64, 0), (130, 0), (512, 0), (200, 56)])
+def test_attention_flash_prefill(d, q, pos0):
+    """bf16 MFMA flash kernel vs fp64 reference (tolerance: P is rounded to bf16 before PV, ~2^-8 relative)."""
+    n_max = pos0 + q + 3
+    out, ref = run_attention(torch.bfloat16, 1, 2, q, 2, d, pos0, n_max, None, seed=q)
+    assert rel_err(out, ref) <= 2e-2, rel_err(out, ref)
+
+
+def test_attention_flash_prefill_mask_matches_rows_kernel():
+    B, q = 3, 150
+    mask = (torch.rand(B, q + 2, generator=g(9)) > 0.25).long()
+    mask[:, 0] = 1
+    mask[2, :40] = 0          # left-padded sequence: its first 40 queries see nothing
+    out_f, ref = run_attention(torch.bfloat16, 1, B, q, 2, 128, 0, q + 2, mask, seed=3)
+    out_r, _ = run_attention(torch.bfloat16, 0, B, q, 2, 128, 0, q + 2, mask, seed=3)
+    assert rel_err(out_f, ref) <= 2e-2 and rel_err(out_r, ref) <= 1.5e-2
+    assert out_f.view(B, q, -1)[2, :40].abs().max() == 0
+
+
+def test_attention_online_softmax_rescale_branch():
+    """Force the running max to jump late (rule 26 of the CDNA guide): spike one key far into the sequence."""
+    B, q, heads, d = 1, 192, 1, 128
+    H = heads * d
+    qkv = rnd(B * q, 3 * H, seed=1).bfloat16()
+    kc = rnd(B, heads, q, d, seed=2).bfloat16()
+    vc = rnd(B, heads, q, d, seed=3).bfloat16()
+    kc[0, 0, 150] = qkv.view(q, 3, d)[180, 0] * 4.0       # query 180 . key 150 >> everything else
+    out = torch.empty(B * q, H, dtype=torch.bfloat16, device=DEV)
+    check(lib().bt_attention(_lib.BT_BF16, 1, B, q, heads, d, ptr(qkv.to(DEV)), 3 * H, ptr(kc.to(DEV)), ptr(vc.to(DEV)), q,
+                             None, 0, None, 0, ptr(out), H, 1, None, 0, current_stream()))
+    ref = attn_ref(qkv, kc, vc, B, q, heads, d, 0, None)
+    assert rel_err(out.cpu(), ref) <= 2e-2
+
+
+# ---- bt_argmax / bt_topk_sample -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("V", [256, 50304, 1001])
+def test_argmax(dtype, V):
+    x = rnd(7, V, seed=1).to(dtype)
+    x[3, 5] = x[3, 900 % V] = 9.0          # tie: first index wins (torch.argmax semantics)
+    out = ops.argmax(x.to(DEV)).cpu()
+    assert torch.equal(out, x.float().argmax(-1))
+    # strided destination: column t of the [B, L] token buffer
+    buf = torch.zeros(7, 4, dtype=torch.int64, device=DEV)
+    ops.argmax(x.to(DEV), out=buf[:, 2])
+    assert torch.equal(buf[:, 2].cpu(), x.float().argmax(-1)) and int(buf[:, [0, 1, 3]].abs().sum()) == 0
+
+
+def test_topk_sample_distribution():
+    """Distributional check: draws stay inside the top-k set and their frequencies follow softmax(logits/T)[top-k]."""
+    V, k, T, n = 1000, 5, 0.7, 4000
+    logits = rnd(1, V, seed=3) * 2
+    rows = logits.repeat(n, 1).to(DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    draws = ops.topk_sample(rows, temperature=T, top_k=k, seed=123, step=step).cpu()
+    top = logits[0].topk(k)
+    assert set(draws.tolist()) <= set(top.indices.tolist())
+    p = torch.softmax(top.values / T, -1)
+    freq = torch.tensor([(draws == i).float().mean() for i in top.indices])
+    assert (freq - p).abs().max() < 0.04
+    d2 = ops.topk_sample(rows, temperature=T, top_k=k, seed=123, step=step).cpu()
+    assert torch.equal(draws, d2), "same (seed, step, row) -> same draw"
+    step.fill_(1)
+    d3 = ops.topk_sample(rows, temperature=T, top_k=k, seed=123, step=step).cpu()
+    assert not torch.equal(draws, d3)
+    # top_k = 0: full distribution
+    small = (rnd(1, 8, seed=4)).repeat(n, 1).to(DEV)
+    d4 = ops.topk_sample(small, temperature=1.0, top_k=0, seed=7).cpu()
+    p4 = torch.softmax(small[0].cpu(), -1)
+    f4 = torch.tensor([(d4 == i).float().mean() for i in range(8)])
+    assert (f4 - p4).abs().max() < 0.04
+
+
+# ---- bt_finish_block ------------------------------------------------------------------------------------------------------
+def finish_ref(raw, finished, count, L, cfg_pad, eos, gen_pad):
+    """The oracle's token_decoder_generate + BlockTransformer.generate bookkeeping for one block (Q5/Q6)."""
+    B = raw.shape[0]
+    out = torch.full((B, L), cfg_pad, dtype=torch.long)
+    active = [b for b in range(B) if not finished[b]]
+    new_fin = finished.clone()
+    if eos < 0:
+        for b in active:
+            out[b, :count] = raw[b, :count]
+        return out, new_fin
+    unf = {b: 1 for b in active}
+    for tcol in range(count):
+        for b in active:
+            tok = int(raw[b, tcol]) if unf[b] else gen_pad
+            out[b, tcol] = tok
+            if tok == eos:
+                unf[b] = 0
+        if active and all(v == 0 for v in unf.values()):
+            break
+    for b in active:
+        if (out[b] == eos).any():
+            new_fin[b] = 1
+    return out, new_fin
+
+
+@pytest.mark.parametrize("eos,cfg_pad,gen_pad", [(-1, 1, 1), (7, 0, 1), (7, 7, 7), (0, 0, 1)])
+@pytest.mark.parametrize("count", [4, 2])
+def test_finish_block(eos, cfg_pad, gen_pad, count):
+    B, L, NB, blk = 50, 4, 6, 3
+    gen = g(11 + count)
+    raw = torch.randint(0, 10, (B, L), generator=gen)
+    finished = (torch.rand(B, generator=gen) < 0.2).int()
+    if eos >= 0:
+        raw[5] = eos            # finishes at column 0
+    for trial in range(2):
+        if trial == 1 and eos >= 0:    # every active row hits EOS at column <= 1 -> HF stops early (Q6)
+            raw[:, 1] = eos
+        out_ids = torch.full((B, NB, L), -5, dtype=torch.long, device=DEV)
+        fin = finished.clone().to(DEV)
+        prev = torch.full((B,), -1, dtype=torch.int32, device=DEV)
+        mask = torch.full((B, NB + 1), 9, dtype=torch.uint8, device=DEV)
+        rawd = raw.clone().to(DEV)
+        blk_dev = torch.tensor([blk], dtype=torch.int32, device=DEV)
+        check(lib().bt_finish_block(B, L, count, ptr(rawd), ptr(out_ids), NB, ptr(blk_dev), ptr(fin), ptr(prev),
+                                    ptr(mask), mask.stride(0), cfg_pad, eos, gen_pad, current_stream()))
+        ref_out, ref_fin = finish_ref(raw, finished, count, L, cfg_pad, eos, gen_pad)
+        assert torch.equal(out_ids[:, blk].cpu(), ref_out)
+        assert torch.equal(rawd.cpu(), ref_out), "final tokens are written back for the roll-over embed"
+        assert torch.equal(fin.cpu(), ref_fin.int()) and torch.equal(prev.cpu(), finished)
+        assert torch.equal(mask[:, blk].cpu(), (1 - ref_fin).to(torch.uint8))
+        assert int((out_ids[:, :blk] != -5).sum()) == 0 and int((mask[:, :blk] != 9).sum()) == 0
+
+
+def test_graph_capture_replay():
+    """hipGraph helpers: capture two launches reading a device scalar, replay with a bumped scalar."""
+    from block_transformer_amd.runtime import Graph
+    ctr = torch.zeros(1, dtype=torch.int32, device=DEV)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        with Graph() as gr:
+            check(lib().bt_bump(ptr(ctr), 3, current_stream()))
+            check(lib().bt_bump(ptr(ctr), 4, current_stream()))
+        for _ in range(5):
+            gr.launch()
+    s.synchronize()
+    assert int(ctr.item()) == 35
