@@ -86,11 +86,19 @@ def build_model(dims, dtype_name: str, device, seed: int):
     return model
 
 
+def log(msg: str) -> None:
+    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+T_START = time.perf_counter()
+
+
 def cpu_baseline(model, dims, sample_prefill: int, sample_decode: int):
     """The CPU oracle (a port of the reference's eager path) timed on this box's host cores, on a bounded sample of
-    the same workload: same weights (copied from the GPU model, fp32), batch 1."""
+    the same workload: same weights (copied from the GPU model, fp32), batch 1.  Threads are capped at 32: the per-op
+    work at batch 1 (GEMV-sized) does not scale past that and oversubscription makes eager PyTorch slower."""
     from oracle.cpu_ref import oracle_from_dims
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 32)
     torch.set_num_threads(cores)
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     o = oracle_from_dims(dims, sd, pad_token_id=1)
@@ -120,7 +128,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
-    ap.add_argument("--cpu-sample", default="128,32", help="prefill,decode of the CPU baseline sample")
+    ap.add_argument("--cpu-sample", default="128,128", help="prefill,decode of the CPU baseline sample")
     args = ap.parse_args()
 
     rank, world, local = parallel.init_distributed()
@@ -134,7 +142,9 @@ def main():
     B, P, D, L = args.batch, args.prefill, args.decode, dims.L
     max_length = get_max_length(L, P, D)
 
+    log(f"rank {rank}/{world}: building {args.config} ({args.dtype}) on {device}")
     model = build_model(dims, args.dtype, device, args.seed)   # same weights on every rank (replicated)
+    log("model built")
     model.use_graphs = not args.no_graphs
     gen = torch.Generator().manual_seed(args.seed + 1000 * rank)
     input_ids = torch.randint(0, dims.vocab, (B, P), generator=gen).to(device)
@@ -142,8 +152,10 @@ def main():
     def step():
         return model.generate(input_ids, max_length=max_length)
 
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
         out = step()
+        torch.cuda.synchronize()
+        log(f"warmup {i} done")
     parallel.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -153,6 +165,7 @@ def main():
     parallel.barrier()
     elapsed = time.perf_counter() - t0
     assert out.shape == (B, max_length), out.shape
+    log(f"{args.steps} timed steps: {elapsed:.3f}s")
     elapsed = parallel.max_over_ranks(elapsed)
     ms_per_step = elapsed / args.steps * 1e3
     tokens_per_step = parallel.sum_over_ranks(B * D)
@@ -179,6 +192,7 @@ def main():
         result["prefill_ms"] = prefill_ms
         result["decode_ms"] = decode_ms
         result["decode_phase_tokens_per_s_per_gpu"] = B * D / (decode_ms / 1e3)
+        log(f"phase split: prefill {prefill_ms:.1f} ms, decode {decode_ms:.1f} ms")
 
     if rank == 0 and not args.no_roofline:
         # per-kernel-family GPU time of ONE generate, launched eagerly with a hipEvent pair around every kernel on the
@@ -223,6 +237,7 @@ def main():
             return {"kernel": name, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": None, "traffic": None, "launches": int(n), "avg_launch_us": ms / n * 1e3}
 
+        log(f"kernel families (ms): {fam_ms}")
         result["roofline"] = roof(dominant)
         if "attn_rows" in fam_ms and dominant != "attn_rows":
             result["roofline_global_attention"] = roof("attn_rows")   # the north-star HBM-bound global path
@@ -232,7 +247,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sp, sdn = (int(v) for v in args.cpu_sample.split(","))
         model.release_buffers()
+        log("cpu baseline (oracle on host cores) ...")
         base, cpu_out, cpu_ids = cpu_baseline(model, dims, sp, sdn)
+        log(f"cpu baseline done: {base['seconds']:.1f}s")
         # parity on identical inputs, same run: GPU greedy tokens vs the CPU eager path (bf16 vs fp32: agreement rate)
         gpu_out = model.generate(cpu_ids.to(device), max_length=cpu_out.shape[1]).cpu()
         base["gpu_vs_cpu_token_agreement"] = float((gpu_out[:, sp:] == cpu_out[:, sp:]).float().mean())

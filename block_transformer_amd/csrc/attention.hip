@@ -337,9 +337,10 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const bf16* __restri
         for (int i = 0; i < (FK_TILE * D / 8) / 256; ++i) {
             const int ch = tid + i * 256;
             const int key = ch / (D / 8), dc = ch % (D / 8);
-            int kr = key0 + key;
-            kr = kr < n_max ? kr : (int)n_max - 1;
-            const uint4 v = *reinterpret_cast<const uint4*>(vbase + (int64_t)kr * D + dc * 8);
+            const int kr = key0 + key;
+            // rows >= n_keys were never written (uninitialised cache memory): P is 0 there, but 0 * NaN = NaN
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (kr < n_keys) v = *reinterpret_cast<const uint4*>(vbase + (int64_t)kr * D + dc * 8);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {

@@ -163,3 +163,32 @@ def test_constructor_contracts():
 def test_td_position_table():
     assert td_position_table("train", 2, 8) == list(range(9))
     assert td_position_table("hf439_generate", 2, 8) == [0, 0, 1, 2, 3, 4, 5, 6, 7]
+
+
+def test_batch_tuner_bookkeeping():
+    """The reference's batch auto-tune is pure arithmetic over measurement records (measure_generation_time.py:250-372)."""
+    from block_transformer_amd import measure_generation_time as H
+    assert H.get_number_of_repetitions(255) == 10 and H.get_number_of_repetitions(256) == 5
+    assert [H.round_batch(v) for v in (31, 33, 130, 600, 3000)] == [31, 32, 128, 576, 3072]
+    rec = lambda b, m=None, oom=False: {"prefill_length": 2048, "decode_length": 128, "batch_size": b, "oom": oom,  # noqa: E731
+                                        "max_memory_allocated": m}
+    data = [rec(1, 3.05), rec(2, 3.10)]
+    assert H.predict_memory_per_sample(data, 2048, 128) == pytest.approx(0.05)
+    assert H.predict_memory_per_sample(data[:1], 2048, 128) is None
+    # no OOM yet: aim halfway to the predicted 100 % VRAM batch: b2 = 2 + int((288-3.1)/0.05) = 5700 -> middle 2851 -> 2816
+    assert H.find_next_batch_size(data, 2048, 128, 288.0) == 2816
+    data.append(rec(2816, 143.9))
+    nxt = H.find_next_batch_size(data, 2048, 128, 288.0)
+    assert nxt is not None and nxt > 2816
+    data.append(rec(nxt, None, oom=True))
+    assert H.predict_oom(data, nxt + 1, 2048, 128) and not H.predict_oom(data, nxt - 1, 2048, 128)
+    mid = H.find_next_batch_size(data, 2048, 128, 288.0)
+    assert 2816 < mid < nxt
+    assert H.measurement_exists(data, 2816, 2048, 128) and not H.measurement_exists(data, 2816, 128, 2048)
+    assert H.get_max_batch_size_row(data, 2048, 128)["batch_size"] == 2816
+    assert H.get_max_batch_size_row(data, 2048, 128, oom=True)["batch_size"] == nxt
+    # degenerate slope at B=1,2 -> 0.1 GiB, like the reference
+    assert H.predict_memory_per_sample([rec(1, 3.0), rec(2, 3.0)], 2048, 128) == 0.1
+    # search ends when the bracket closes
+    closed = [rec(1, 1.0), rec(2, 2.0), rec(3, None, oom=True)]
+    assert H.find_next_batch_size(closed, 2048, 128, 288.0) is None

@@ -203,10 +203,14 @@ def run_attention(dtype, mode, B, q, heads, d, pos0, n_max, mask, n_split=1, dev
     ws = torch.empty(B * heads * q * max(n_split, 32) * (d + 2), dtype=torch.float32, device=DEV)
     pos_dev = torch.tensor([pos0], dtype=torch.int32, device=DEV) if dev_pos else None
     m = None if mask is None else mask.to(torch.uint8).to(DEV)
-    check(lib().bt_attention(dtype_code(dtype), mode, B, q, heads, d, ptr(qkv.to(DEV)), 3 * H, ptr(kc.to(DEV)),
-                             ptr(vc.to(DEV)), n_max, ptr(pos_dev), 0 if dev_pos else pos0, ptr(m),
-                             0 if m is None else m.stride(0), ptr(out), H, n_split, ptr(ws), ws.numel() * 4,
-                             current_stream()))
+    qd, kd, vd = qkv.to(DEV), kc.to(DEV), vc.to(DEV)   # keep alive: the call is asynchronous
+    # rows beyond the visible range must never influence the result, whatever bits they hold (uninitialised cache)
+    kd[:, :, pos0 + q:] = float("nan")
+    vd[:, :, pos0 + q:] = float("nan")
+    check(lib().bt_attention(dtype_code(dtype), mode, B, q, heads, d, ptr(qd), 3 * H, ptr(kd), ptr(vd), n_max,
+                             ptr(pos_dev), 0 if dev_pos else pos0, ptr(m), 0 if m is None else m.stride(0), ptr(out), H,
+                             n_split, ptr(ws), ws.numel() * 4, current_stream()))
+    torch.cuda.synchronize()
     ref = attn_ref(qkv, kc, vc, B, q, heads, d, pos0, mask)
     return out.cpu(), ref
 
@@ -271,8 +275,10 @@ def test_attention_online_softmax_rescale_branch():
     vc = rnd(B, heads, q, d, seed=3).bfloat16()
     kc[0, 0, 150] = qkv.view(q, 3, d)[180, 0] * 4.0       # query 180 . key 150 >> everything else
     out = torch.empty(B * q, H, dtype=torch.bfloat16, device=DEV)
-    check(lib().bt_attention(_lib.BT_BF16, 1, B, q, heads, d, ptr(qkv.to(DEV)), 3 * H, ptr(kc.to(DEV)), ptr(vc.to(DEV)), q,
+    qd, kd, vd = qkv.to(DEV), kc.to(DEV), vc.to(DEV)
+    check(lib().bt_attention(_lib.BT_BF16, 1, B, q, heads, d, ptr(qd), 3 * H, ptr(kd), ptr(vd), q,
                              None, 0, None, 0, ptr(out), H, 1, None, 0, current_stream()))
+    torch.cuda.synchronize()
     ref = attn_ref(qkv, kc, vc, B, q, heads, d, 0, None)
     assert rel_err(out.cpu(), ref) <= 2e-2
 

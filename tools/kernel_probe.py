@@ -1,0 +1,138 @@
+#!/usr/bin/env python
+"""Stand-alone kernel probe: times single C-ABI ops at benchmark shapes with HIP events on the launch stream, and is the
+target of the rocprofv3 PMC passes (small, deterministic dispatch list).
+
+    python tools/kernel_probe.py gemm  [--m 32768 --n 6144 --k 2048] [--iters 20]
+    python tools/kernel_probe.py attn  [--batch 1024 --n 528]           # global decode step, 1.2B head geometry
+    python tools/kernel_probe.py flash [--batch 64 --n 512]
+    python tools/kernel_probe.py suite                                   # the shapes of block_main_b4_1.2b
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from block_transformer_amd import _lib, ops  # noqa: E402
+from block_transformer_amd._lib import check, current_stream, lib, ptr  # noqa: E402
+
+DEV = "cuda"
+
+
+def timed(fn, iters, warmup=3):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    b.synchronize()
+    return a.elapsed_time(b) / iters  # ms
+
+
+def probe_gemm(M, N, K, iters, act="none", bias=True, res=False):
+    x = (torch.randn(M, K, device=DEV) * 1.0).bfloat16()
+    w = (torch.randn(N, K, device=DEV) * K ** -0.5).bfloat16()
+    b = torch.randn(N, device=DEV).bfloat16() if bias else None
+    r = torch.randn(M, N, device=DEV).bfloat16() if res else None
+    out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+    ms = timed(lambda: ops.linear(x, w, b, r, act=act, out=out), iters)
+    tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+    return {"op": "gemm", "M": M, "N": N, "K": K, "act": act, "ms": round(ms, 4), "TFLOPs": round(tf, 1),
+            "frac_mfma_peak": round(tf / 2500.0, 3)}
+
+
+def probe_attn(B, n, iters, heads=16, d=128, n_split=1, dtype=torch.bfloat16):
+    H = heads * d
+    n_max = n + 1
+    qkv = torch.randn(B, 3 * H, device=DEV).to(dtype)
+    kc = torch.randn(B, heads, n_max, d, device=DEV).to(dtype)
+    vc = torch.randn(B, heads, n_max, d, device=DEV).to(dtype)
+    out = torch.empty(B, H, device=DEV, dtype=dtype)
+    pos = torch.tensor([n - 1], dtype=torch.int32, device=DEV)
+    ws = torch.empty(B * heads * max(n_split, 1) * (d + 2), dtype=torch.float32, device=DEV)
+
+    def run():
+        check(lib().bt_attention(_lib.dtype_code(dtype), 0, B, 1, heads, d, ptr(qkv), 3 * H, ptr(kc), ptr(vc), n_max,
+                                 ptr(pos), 0, None, 0, ptr(out), H, n_split, ptr(ws), ws.numel() * 4, current_stream()))
+
+    ms = timed(run, iters)
+    nbytes = 2.0 * B * heads * n * d * qkv.element_size()
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    return {"op": "attn_rows_global", "B": B, "n_keys": n, "n_split": n_split, "ms": round(ms, 4),
+            "algorithmic_MB": round(nbytes / 1e6, 1), "GBps": round(gbs, 1), "frac_hbm_peak": round(gbs / 8000.0, 3)}
+
+
+def probe_flash(B, n, iters, heads=16, d=128):
+    H = heads * d
+    qkv = torch.randn(B * n, 3 * H, device=DEV).bfloat16()
+    kc = torch.randn(B, heads, n, d, device=DEV).bfloat16()
+    vc = torch.randn(B, heads, n, d, device=DEV).bfloat16()
+    out = torch.empty(B * n, H, device=DEV, dtype=torch.bfloat16)
+
+    def run():
+        check(lib().bt_attention(_lib.BT_BF16, 1, B, n, heads, d, ptr(qkv), 3 * H, ptr(kc), ptr(vc), n, None, 0, None, 0,
+                                 ptr(out), H, 1, None, 0, current_stream()))
+
+    ms = timed(run, iters)
+    fl = 4.0 * B * heads * d * (n * (n + 1) / 2)
+    tf = fl / (ms * 1e-3) / 1e12
+    return {"op": "attn_flash_prefill", "B": B, "n": n, "ms": round(ms, 4), "TFLOPs": round(tf, 1),
+            "frac_mfma_peak": round(tf / 2500.0, 3)}
+
+
+def probe_copy(nbytes, iters):
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=DEV).normal_()
+    b = torch.empty_like(a)
+    ms = timed(lambda: b.copy_(a), iters)
+    return {"op": "copy_ceiling", "MB": nbytes / 1e6, "ms": round(ms, 4), "GBps": round(2 * nbytes / (ms * 1e-3) / 1e9, 1)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("what", choices=["gemm", "attn", "flash", "suite", "copy"])
+    ap.add_argument("--m", type=int, default=32768)
+    ap.add_argument("--n", type=int, default=6144)
+    ap.add_argument("--k", type=int, default=2048)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--keys", type=int, default=528)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--split", type=int, default=1)
+    args = ap.parse_args()
+    res = []
+    if args.what == "gemm":
+        res.append(probe_gemm(args.m, args.n, args.k, args.iters))
+    elif args.what == "attn":
+        res.append(probe_attn(args.batch, args.keys, args.iters, n_split=args.split))
+    elif args.what == "flash":
+        res.append(probe_flash(args.batch, args.keys, args.iters))
+    elif args.what == "copy":
+        res.append(probe_copy(1 << 30, args.iters))
+    else:
+        res.append(probe_copy(1 << 30, 10))
+        for M in (32768, 4096, 2048, 1024, 256, 64, 1):
+            it = 10 if M >= 4096 else 30
+            res.append(probe_gemm(M, 6144, 2048, it))
+            res.append(probe_gemm(M, 2048, 2048, it, res=True))
+            res.append(probe_gemm(M, 8192, 2048, it, act="gelu"))
+            res.append(probe_gemm(M, 2048, 8192, it, res=True))
+        for M in (4096, 1024, 256):
+            res.append(probe_gemm(M, 50304, 2048, 10, bias=False))
+        for B in (4096, 1024, 256, 16, 1):
+            res.append(probe_attn(B, 528, 20))
+        res.append(probe_attn(1, 528, 20, n_split=16))
+        res.append(probe_attn(16, 528, 20, n_split=4))
+        res.append(probe_flash(64, 512, 10))
+    for r in res:
+        print(json.dumps(r), flush=True)
+
+
+if __name__ == "__main__":
+    main()
