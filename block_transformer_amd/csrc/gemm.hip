@@ -160,6 +160,211 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restr
     }
 }
 
+// ---- 256x256 deep-pipelined kernel ---------------------------------------------------------------------------------------
+// For grids that fill the chip with one 8-wave workgroup per CU.  Arithmetic intensity per workgroup doubles vs the 128^2
+// tile (128 flop per L2->LDS byte), which takes the kernel off the L2-bandwidth roof the small tile sits under.
+//
+// K-loop = phases of 16 MFMAs per wave (one 64x32 quadrant of the wave's 128x64 output, K = 64).  LDS holds two K-tile
+// buffers of four 16 KiB HALF-tiles [A rows 0-127 | A rows 128-255 | W rows 0-127 | W rows 128-255]; a wave's 128 output
+// rows are 64 rows of each A half and its 64 output columns 32 rows of each W half, so a half-tile is last read in a
+// known phase and can be refilled by LDS-DMA long before the buffer as a whole is free:
+//     phase p of K-tile t:  p0 reads A0,W0 -> MFMA(A0,W0)   p1 reads W1 -> MFMA(A0,W1)
+//                           p2 reads A1    -> MFMA(A1,W1)   p3 (no reads) -> MFMA(A1,W0)        (both W halves stay in VGPRs)
+// Half-tile loads are issued one per phase, PD = 6 phases ahead of the phase that first needs them, in consumption order
+// A0,W0,W1,A1.  Each phase is  [s_waitcnt vmcnt(counted) ; s_barrier ; issue 1 half-tile DMA ; ds_reads ; 16 MFMA]:
+//   RAW: the data a phase reads was waited for (counted vmcnt, never 0 in steady state: 4 half-tiles = 8 DMA instructions
+//        stay in flight) by EVERY wave before the barrier that opens the phase;
+//   WAR: a half-tile slot is refilled >= 2 barriers after its last ds_read (reads complete before the MFMAs that consume
+//        them, i.e. before the reading wave reaches the next barrier).
+constexpr int BM2 = 256, BN2 = 256;
+constexpr int HALF_BYTES = 128 * BK * 2;   // 16 KiB
+constexpr int PD = 6;                      // prefetch distance in phases
+constexpr int GROUP_M2 = 4;
+
+template <int N>
+__device__ inline void wait_vmcnt() {
+    if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// half-tile load s (global sequence number): K-tile t = s / 4, kind = s % 4 in consumption order A0, W0, W1, A1
+__device__ inline void stage_half(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ W, int64_t ldw,
+                                  int m0, int n0, int M, int N, int s, char* smem, int wave, int lane) {
+    const int t = s >> 2, kind = s & 3;
+    const bool is_a = (kind == 0) || (kind == 3);
+    const int half = (kind == 2 || kind == 3) ? 1 : 0;
+    const bf16* src = is_a ? A : W;
+    const int64_t ld = is_a ? lda : ldw;
+    const int row0 = (is_a ? m0 : n0) + half * 128;
+    const int row_max = is_a ? M : N;
+    char* slot = smem + (t & 1) * 4 * HALF_BYTES + ((is_a ? 0 : 2) + half) * HALF_BYTES;
+    const int k0 = t * BK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rbase = wave * 16 + i * 8;
+        const int row = rbase + (lane >> 3);
+        const int gslot = (lane & 7) ^ (row & 7);
+        int grow = row0 + row;
+        grow = grow < row_max ? grow : row_max - 1;
+        const bf16* g = src + (int64_t)grow * ld + k0 + gslot * 8;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(slot + rbase * 128), 16, 0, 0);
+    }
+}
+
+// wait until every half-tile load that phase g reads has landed (this wave's DMA share), leaving the younger ones in flight
+__device__ inline void wait_for_phase(int g, int total) {
+    if (g >= total) return;  // past the last phase: nothing to wait for (total = 4 * nk phases == loads)
+    const int p = g & 3;
+    const int need = (g & ~3) + (p == 0 ? 1 : (p == 1 ? 2 : 3));
+    const int issued = min(g - 1 + PD, total - 1);
+    const int allow = issued - need;  // half-tile loads that may stay in flight (2 DMA instructions each)
+    if (allow >= 4) wait_vmcnt<8>();
+    else if (allow == 3) wait_vmcnt<6>();
+    else if (allow == 2) wait_vmcnt<4>();
+    else if (allow == 1) wait_vmcnt<2>();
+    else wait_vmcnt<0>();
+}
+
+__device__ inline void cbarrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// STAGGER: waves 4-7 run half a phase behind waves 0-3 (two barriers per phase): while one wave of a SIMD is in its
+// 16-MFMA cluster (s_setprio 1) its partner issues the DMA and ds_reads of its own phase, so the matrix pipe does not
+// idle during LDS latency.  Group 1 therefore waits for phase g+1's data before the barrier that opens group 0's phase
+// g+1 (every wave must have waited for its DMA share before ANY wave reads).
+template <bool STAGGER>
+__global__ __launch_bounds__(512) void gemm_bf16_mfma256_kernel(const bf16* __restrict__ A, int64_t lda,
+                                                               const bf16* __restrict__ W, int64_t ldw,
+                                                               const bf16* __restrict__ bias, const bf16* res,
+                                                               int64_t ldr, bf16* out, int64_t ldo, int M, int N, int K,
+                                                               int act, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char smem[8 * HALF_BYTES];  // 128 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool grp1 = STAGGER && (__builtin_amdgcn_readfirstlane(tid >> 8) != 0);
+    // tile coordinates: bijective XCD remap, then GROUP_M2 grouping
+    int tm, tn;
+    {
+        const int nwg = tiles_m * tiles_n;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int group_sz = GROUP_M2 * tiles_n;
+        const int g = id / group_sz;
+        const int first_m = g * GROUP_M2;
+        const int gm = min(tiles_m - first_m, GROUP_M2);
+        const int in_g = id - g * group_sz;
+        tm = first_m + in_g % gm;
+        tn = in_g / gm;
+    }
+    const int m0 = tm * BM2, n0 = tn * BN2;
+
+    f32x4_t acc[8][4];  // [A half * 4 + m-frag][W half * 2 + n-frag]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    const int total = 4 * nk;  // half-tile loads == phases
+#pragma unroll
+    for (int s = 0; s < PD; ++s)
+        if (s < total) stage_half(A, lda, W, ldw, m0, n0, M, N, s, smem, wave, lane);
+
+    bf16x8_t af[4][2];      // current A half: [m-frag][kk]
+    bf16x8_t wf[2][2][2];   // both W halves:  [half][n-frag][kk]
+
+    if (grp1) {
+        wait_for_phase(0, total);
+        cbarrier();
+    }
+    for (int t = 0; t < nk; ++t) {
+        const char* buf = smem + (t & 1) * 4 * HALF_BYTES;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int g = 4 * t + p;
+            if (!grp1) wait_for_phase(g, total);
+            cbarrier();
+            if (g + PD < total) stage_half(A, lda, W, ldw, m0, n0, M, N, g + PD, smem, wave, lane);
+            if (p == 0) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) wf[0][j][kk] = read_frag(buf + 2 * HALF_BYTES, wn * 32 + j * 16, kk, lane);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[i][kk] = read_frag(buf, wm * 64 + i * 16, kk, lane);
+                }
+            } else if (p == 1) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) wf[1][j][kk] = read_frag(buf + 3 * HALF_BYTES, wn * 32 + j * 16, kk, lane);
+            } else if (p == 2) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[i][kk] = read_frag(buf + HALF_BYTES, wm * 64 + i * 16, kk, lane);
+            }
+            if (STAGGER) {
+                if (grp1) wait_for_phase(g + 1, total);
+                cbarrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int ah = (p >= 2) ? 1 : 0;
+            const int wh = (p == 1 || p == 2) ? 1 : 0;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[ah * 4 + i][wh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            wf[wh][j][kk], af[i][kk], acc[ah * 4 + i][wh * 2 + j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+    if (STAGGER && !grp1) cbarrier();
+
+    // epilogue: D[i = n][j = m]; lane holds column m = lane & 15 and rows n = (lane >> 4) * 4 + r  (N % 4 == 0 required)
+#pragma unroll
+    for (int ai = 0; ai < 8; ++ai) {
+        const int m = m0 + (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16 + (lane & 15);
+        if (m >= M) continue;
+#pragma unroll
+        for (int wj = 0; wj < 4; ++wj) {
+            const int n = n0 + (wj >> 1) * 128 + wn * 32 + (wj & 1) * 16 + (lane >> 4) * 4;
+            if (n >= N) continue;
+            float v[4] = {acc[ai][wj][0], acc[ai][wj][1], acc[ai][wj][2], acc[ai][wj][3]};
+            if (bias) {
+                const uint2 b2 = *reinterpret_cast<const uint2*>(bias + n);
+                v[0] += __uint_as_float(b2.x << 16); v[1] += __uint_as_float(b2.x & 0xffff0000u);
+                v[2] += __uint_as_float(b2.y << 16); v[3] += __uint_as_float(b2.y & 0xffff0000u);
+            }
+            if (act == BT_ACT_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            }
+            if (res) {
+                const uint2 r2 = *reinterpret_cast<const uint2*>(res + (int64_t)m * ldr + n);
+                v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
+                v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+            }
+            uint2 o2;
+            o2.x = pack_bf16x2(v[0], v[1]);
+            o2.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(out + (int64_t)m * ldo + n) = o2;
+        }
+    }
+}
+
 // ---- generic tiled kernel (fp32 parity path; any M, N, K, strides) --------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_generic_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ W,
@@ -222,6 +427,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const T* __restrict__
 }
 
 static bool g_force_generic = false;
+static int g_gemm_variant = 0;  // 0 auto, 1 force 128^2, 2 force 256^2 (no stagger), 3 force 256^2 staggered (tests / A-B probes)
 
 }  // namespace bt
 
@@ -244,7 +450,23 @@ extern "C" int bt_linear(int dtype, int64_t M, int64_t N, int64_t K, const void*
                              (ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 7u) == 0) &&
                              (!residual || ((ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(residual) & 7u) == 0)) &&
                              (!bias || (reinterpret_cast<uintptr_t>(bias) & 7u) == 0);
-        if (mfma_ok) {
+        const int64_t tiles256 = ceil_div(M, BM2) * ceil_div(N, BN2);
+        // big-tile kernel: one 8-wave workgroup per CU -> needs >= ~1 full wave of 256 tiles and little tail quantisation
+        const bool use256 = mfma_ok && g_gemm_variant != 1 && (N % 4 == 0) &&
+                            (g_gemm_variant >= 2 || (tiles256 >= 240 && (tiles256 % 256 == 0 || tiles256 >= 1024 ||
+                                                                         (tiles256 % 256) >= 160)));
+        if (use256) {
+            ProfScope ps(BT_PROF_LINEAR_MFMA, s);
+            const int tiles_m = (int)ceil_div(M, BM2), tiles_n = (int)ceil_div(N, BN2);
+            if (g_gemm_variant == 2)
+                hipLaunchKernelGGL(gemm_bf16_mfma256_kernel<false>, dim3(tiles_m * tiles_n), dim3(512), 0, s,
+                                   (const bf16*)A, lda, (const bf16*)W, K, (const bf16*)bias, (const bf16*)residual, ldr,
+                                   (bf16*)out, ldo, (int)M, (int)N, (int)K, act, tiles_m, tiles_n);
+            else
+                hipLaunchKernelGGL(gemm_bf16_mfma256_kernel<true>, dim3(tiles_m * tiles_n), dim3(512), 0, s,
+                                   (const bf16*)A, lda, (const bf16*)W, K, (const bf16*)bias, (const bf16*)residual, ldr,
+                                   (bf16*)out, ldo, (int)M, (int)N, (int)K, act, tiles_m, tiles_n);
+        } else if (mfma_ok) {
             ProfScope ps(BT_PROF_LINEAR_MFMA, s);
             const int tiles_m = (int)ceil_div(M, BM), tiles_n = (int)ceil_div(N, BN);
             BT_CHECK_ARG((int64_t)tiles_m * tiles_n < (1ll << 31), "bt_linear: grid too large");
@@ -273,3 +495,4 @@ extern "C" int bt_linear(int dtype, int64_t M, int64_t N, int64_t K, const void*
 
 // test hook: force the generic kernel for bf16 (A/B checks of the MFMA kernel against the simple one)
 extern "C" void bt_debug_force_generic_gemm(int on) { g_force_generic = on != 0; }
+extern "C" void bt_debug_gemm_variant(int v) { g_gemm_variant = v; }

@@ -249,6 +249,17 @@ __global__ __launch_bounds__(1024) void finish_block_kernel(int64_t B, int L, in
 
 __global__ void bump_kernel(int32_t* c, int32_t d) { *c += d; }
 
+// debug probe of ds_read_b64_tr_b16: lds[i] = in[i] (4096 shorts); lane l reads at element offset addr[l]; out[l*4 + j]
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+__global__ void tr_probe_kernel(const short* in, const int* addr, short* out) {
+    __shared__ __attribute__((aligned(16))) short lds[4096];
+    for (int i = threadIdx.x; i < 4096; i += 64) lds[i] = in[i];
+    __syncthreads();
+    const s16x4_t v = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) s16x4_t*)(lds + addr[threadIdx.x]));
+    for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = v[j];
+}
+
 template <typename T>
 static int launch_embed(int64_t rows, int64_t width, const int64_t* ids, int64_t ids_stride, int64_t vocab,
                         const void* table, void* out,
@@ -349,5 +360,12 @@ extern "C" int bt_bump(int32_t* counter, int32_t delta, bt_stream stream) {
     BT_CHECK_ARG(counter, "bt_bump: null pointer");
     hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, delta);
     BT_LAUNCH_CHECK("bt_bump launch");
+    return BT_OK;
+}
+
+extern "C" int bt_debug_tr_probe(const void* in, const void* addr, void* out, bt_stream stream) {
+    hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const short*)in, (const int*)addr,
+                       (short*)out);
+    BT_LAUNCH_CHECK("tr_probe launch");
     return BT_OK;
 }

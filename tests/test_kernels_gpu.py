@@ -71,6 +71,50 @@ def test_linear_mfma_equals_generic_bf16():
     assert rel_err(a, ref) <= 1.2e-2
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 520, 128), (512, 768, 2048), (1000, 260, 448), (64, 1024, 192)])
+@pytest.mark.parametrize("variant", ["plain", "bias_gelu", "bias_res"])
+@pytest.mark.parametrize("kernel", [2, 3])
+def test_linear_256_tile_kernel(M, N, K, variant, kernel):
+    """The deep-pipelined 256x256 kernel (forced) against fp64, incl. M/N tails and every pipeline length nk = K/64
+    (nk = 1..7 exercise the prologue/epilogue wait counts of the half-tile ring)."""
+    x = rnd(M, K, seed=1).bfloat16()
+    w = rnd(N, K, seed=2, scale=K ** -0.5).bfloat16()
+    b = rnd(N, seed=3).bfloat16() if variant != "plain" else None
+    r = rnd(M, N, seed=4).bfloat16() if variant == "bias_res" else None
+    ref = x.double() @ w.double().T
+    if b is not None:
+        ref = ref + b.double()
+    if variant == "bias_gelu":
+        ref = F.gelu(ref)
+    if r is not None:
+        ref = ref + r.double()
+    lib().bt_debug_gemm_variant(kernel)   # 2 = half-tile ring, 3 = ring + staggered wave groups
+    try:
+        out = ops.linear(x.to(DEV), w.to(DEV), None if b is None else b.to(DEV), None if r is None else r.to(DEV),
+                         act="gelu" if variant == "bias_gelu" else "none").cpu()
+    finally:
+        lib().bt_debug_gemm_variant(0)
+    assert rel_err(out, ref) <= 1.2e-2, rel_err(out, ref)
+
+
+def test_linear_256_tile_kernel_repeatable():
+    """Race screen: the ring schedule must give bit-identical results run to run (and equal to the 128x128 kernel)."""
+    x = rnd(1024, 1024, seed=5).bfloat16().to(DEV)
+    w = rnd(1536, 1024, seed=6, scale=0.03).bfloat16().to(DEV)
+    lib().bt_debug_gemm_variant(1)
+    base = ops.linear(x, w)
+    try:
+        for kernel in (2, 3):
+            lib().bt_debug_gemm_variant(kernel)
+            outs = [ops.linear(x, w) for _ in range(20)]
+            torch.cuda.synchronize()
+            for o in outs:
+                assert torch.equal(o, outs[0]), kernel
+            assert torch.equal(outs[0], base), "same fp32 accumulation order per output element -> identical bits"
+    finally:
+        lib().bt_debug_gemm_variant(0)
+
+
 def test_linear_strided_inplace_residual():
     """Row strides + in-place residual (x += att @ Wd^T + b), the way bt_decoder_forward calls it."""
     for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 1.2e-2)):

@@ -97,7 +97,7 @@ def probe_copy(nbytes, iters):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["gemm", "attn", "flash", "suite", "copy"])
+    ap.add_argument("what", choices=["gemm", "attn", "flash", "suite", "copy", "ab"])
     ap.add_argument("--m", type=int, default=32768)
     ap.add_argument("--n", type=int, default=6144)
     ap.add_argument("--k", type=int, default=2048)
@@ -105,8 +105,10 @@ def main():
     ap.add_argument("--keys", type=int, default=528)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--split", type=int, default=1)
+    ap.add_argument("--variant", type=int, default=0, help="bt_debug_gemm_variant: 0 auto, 1 128^2 kernel, 2 256^2 kernel")
     args = ap.parse_args()
     res = []
+    lib().bt_debug_gemm_variant(args.variant)
     if args.what == "gemm":
         res.append(probe_gemm(args.m, args.n, args.k, args.iters))
     elif args.what == "attn":
@@ -115,6 +117,17 @@ def main():
         res.append(probe_flash(args.batch, args.keys, args.iters))
     elif args.what == "copy":
         res.append(probe_copy(1 << 30, args.iters))
+    elif args.what == "ab":
+        # interleaved A/B of the two MFMA kernels on the prefill / large-batch decode shapes
+        for (M, N, K) in ((32768, 6144, 2048), (32768, 2048, 2048), (32768, 8192, 2048), (32768, 2048, 8192),
+                          (4096, 6144, 2048), (4096, 8192, 2048), (4096, 2048, 8192), (4096, 50304, 2048),
+                          (8192, 2048, 2048)):
+            for v in (1, 2, 3, 1, 2, 3):
+                lib().bt_debug_gemm_variant(v)
+                r = probe_gemm(M, N, K, 10 if M > 8000 else 20)
+                r["variant"] = v
+                res.append(r)
+        lib().bt_debug_gemm_variant(0)
     else:
         res.append(probe_copy(1 << 30, 10))
         for M in (32768, 4096, 2048, 1024, 256, 64, 1):
