@@ -75,6 +75,7 @@ _SIGS = {
     "bt_prof_collect": (c_int, [POINTER(ctypes.c_double), POINTER(c_int64), c_int]),
     "bt_debug_force_generic_gemm": (None, [c_int]),
     "bt_debug_gemm_variant": (None, [c_int]),
+    "bt_debug_flash_variant": (None, [c_int]),
     "bt_debug_tr_probe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 

@@ -465,6 +465,223 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const bf16* __restri
     }
 }
 
+// ---- bf16 MFMA flash prefill, v2 ------------------------------------------------------------------------------------------
+// Same math and fragment mapping as flash_prefill_kernel, different data movement:
+//   * K and V tiles (64 keys x D) are streamed HBM/L2 -> LDS with 16-byte global_load_lds (no VGPR round trip), double
+//     buffered: tile t+1 is in flight while tile t is computed; one barrier per tile;
+//   * K fragments (MFMA A operand of S^T = K Q^T) are ds_read_b128 from rows XOR-swizzled over the row's 16-byte slots;
+//   * V is kept ROW-MAJOR in LDS and consumed through ds_read_b64_tr_b16 (hardware 4x16 transpose read: lane c of a
+//     16-lane group receives V[k0..k0+3][c] — semantics probed on gfx950, profiles/r1_ds_read_tr_b16_semantics_probe.txt),
+//     32-byte segments XOR-swizzled with (row & 7) so the four rows a group touches land on distinct banks;
+//   * waves whose 32 query rows all precede a key tile skip its MFMAs (causal), but still take part in staging.
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+
+template <int D>
+__device__ inline void flash_stage_tile(const bf16* __restrict__ kbase, const bf16* __restrict__ vbase, int key0,
+                                        int n_keys, char* kbuf, char* vbuf, int wave, int lane) {
+    constexpr int ROWB = D * 2;            // bytes per row
+    constexpr int SLOTS = ROWB / 16;       // 16-byte slots per row (16 / 8 / 4)
+    constexpr int RPI = 1024 / ROWB;       // rows per wave-instruction (4 / 8 / 16)
+    constexpr int NI = 64 / RPI / 4;       // instructions per wave per operand (4 / 2 / 1)
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int rbase = (wave * NI + i) * RPI;
+        const int row = rbase + lane / SLOTS;
+        const int p = lane % SLOTS;
+        int kr = key0 + row;
+        // rows >= n_keys were never written (uninitialised cache memory; 0 * NaN = NaN in P.V): re-read the last visible
+        // row instead — its score is masked to -inf, so the duplicate gets weight exactly 0
+        kr = kr < n_keys ? kr : n_keys - 1;
+        const int ks = p ^ (row & (SLOTS - 1));                       // K: slot swizzle
+        const int vs = p ^ (((row & 7) << 1) & (SLOTS - 1));          // V: 32-byte segment swizzle
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kbase + (int64_t)kr * D + ks * 8),
+                                         (__attribute__((address_space(3))) void*)(kbuf + rbase * ROWB), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vbase + (int64_t)kr * D + vs * 8),
+                                         (__attribute__((address_space(3))) void*)(vbuf + rbase * ROWB), 16, 0, 0);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(256, 2) void flash_prefill_v2_kernel(const bf16* __restrict__ qkv, int64_t ld_qkv,
+                                                              const bf16* __restrict__ kc, const bf16* __restrict__ vc,
+                                                              int64_t n_max, const int32_t* __restrict__ pos0_dev,
+                                                              int pos0_host, const uint8_t* __restrict__ mask,
+                                                              int64_t mask_ld, bf16* __restrict__ out, int64_t ldo,
+                                                              int q_len, int heads, float scale) {
+    constexpr int KK = D / 32, DF = D / 16, QF = 2;
+    constexpr int ROWB = D * 2, SLOTS = ROWB / 16;
+    constexpr int TILE_B = FK_TILE * ROWB;  // bytes of one K (or V) tile
+    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];  // [buf][K | V]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int qb = blockIdx.x, head = blockIdx.y;
+    const int64_t b = blockIdx.z;
+    const int pos0 = pos0_dev ? *pos0_dev : pos0_host;
+    const int qbase = qb * FQ_ROWS + wave * (QF * 16);
+
+    const bf16* kbase = kc + (b * heads + head) * n_max * D;
+    const bf16* vbase = vc + (b * heads + head) * n_max * D;
+    const uint8_t* mrow = mask ? mask + b * mask_ld : nullptr;
+    const int last_q = min(q_len, (qb + 1) * FQ_ROWS) - 1;
+    const int n_keys = pos0 + last_q + 1;
+    const int n_tiles = (n_keys + FK_TILE - 1) / FK_TILE;
+    const int wave_last_pos = pos0 + min(qbase + QF * 16, q_len) - 1;  // last query position this wave owns
+
+    flash_stage_tile<D>(kbase, vbase, 0, n_keys, smem, smem + TILE_B, wave, lane);
+
+    bf16x8_t qf[QF][KK];
+    int qrow[QF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        qrow[f] = qbase + f * 16 + l15;
+        const int r = qrow[f] < q_len ? qrow[f] : q_len - 1;
+        const bf16* qp = qkv + (b * q_len + r) * ld_qkv + (int64_t)head * 3 * D + g * 8;
+#pragma unroll
+        for (int kk = 0; kk < KK; ++kk) qf[f][kk] = *reinterpret_cast<const bf16x8_t*>(qp + kk * 32);
+    }
+    f32x4_t oacc[QF][DF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f)
+#pragma unroll
+        for (int d = 0; d < DF; ++d) oacc[f][d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float mrun[QF], lrun[QF];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        mrun[f] = -INFINITY;
+        lrun[f] = 0.f;
+    }
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int kt = 0; kt < n_tiles; ++kt) {
+        const int key0 = kt * FK_TILE;
+        const char* kb = smem + (kt & 1) * 2 * TILE_B;
+        const char* vb = kb + TILE_B;
+        if (kt + 1 < n_tiles) {
+            char* nb = smem + ((kt + 1) & 1) * 2 * TILE_B;
+            flash_stage_tile<D>(kbase, vbase, key0 + FK_TILE, n_keys, nb, nb + TILE_B, wave, lane);
+        }
+        if (key0 <= wave_last_pos) {  // wave-uniform: some query of this wave can see this tile
+            f32x4_t sacc[QF][4];
+#pragma unroll
+            for (int f = 0; f < QF; ++f)
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf) sacc[f][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf) {
+                const int row = kf * 16 + l15;
+#pragma unroll
+                for (int kk = 0; kk < KK; ++kk) {
+                    const int slot = (kk * 4 + g) ^ (row & (SLOTS - 1));
+                    const bf16x8_t kfr = *reinterpret_cast<const bf16x8_t*>(kb + row * ROWB + slot * 16);
+#pragma unroll
+                    for (int f = 0; f < QF; ++f)
+                        sacc[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[f][kk], sacc[f][kf], 0, 0, 0);
+                }
+            }
+            bool kvis[4][4];
+#pragma unroll
+            for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = key0 + kf * 16 + g * 4 + r;
+                    kvis[kf][r] = (key < n_keys) && (mrow == nullptr || mrow[key] != 0);
+                }
+#pragma unroll
+            for (int f = 0; f < QF; ++f) {
+                const int qpos = pos0 + qrow[f];
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = key0 + kf * 16 + g * 4 + r;
+                        const float sv = (key <= qpos && kvis[kf][r]) ? sacc[f][kf][r] * scale : -INFINITY;
+                        sacc[f][kf][r] = sv;
+                        tmax = fmaxf(tmax, sv);
+                    }
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+                tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                const float mnew = fmaxf(mrun[f], tmax);
+                const float alpha = (mnew == -INFINITY) ? 1.0f : __expf(mrun[f] - mnew);
+                float psum = 0.f;
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = (mnew == -INFINITY) ? 0.f : __expf(sacc[f][kf][r] - mnew);
+                        sacc[f][kf][r] = pv;
+                        psum += pv;
+                    }
+                lrun[f] = lrun[f] * alpha + psum;
+                mrun[f] = mnew;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float a = __shfl(alpha, g * 4 + r, 64);
+#pragma unroll
+                    for (int d = 0; d < DF; ++d) oacc[f][d][r] *= a;
+                }
+            }
+            // O += P V.  key slot (g, e): e < 4 -> tile key (2ks)*16 + g*4 + e ; e >= 4 -> (2ks+1)*16 + g*4 + (e-4)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8_t pf[QF];
+#pragma unroll
+                for (int f = 0; f < QF; ++f) {
+                    union {
+                        uint32_t u[4];
+                        bf16x8_t v;
+                    } pk;
+                    pk.u[0] = pack_bf16x2(sacc[f][2 * ks][0], sacc[f][2 * ks][1]);
+                    pk.u[1] = pack_bf16x2(sacc[f][2 * ks][2], sacc[f][2 * ks][3]);
+                    pk.u[2] = pack_bf16x2(sacc[f][2 * ks + 1][0], sacc[f][2 * ks + 1][1]);
+                    pk.u[3] = pack_bf16x2(sacc[f][2 * ks + 1][2], sacc[f][2 * ks + 1][3]);
+                    pf[f] = pk.v;
+                }
+                // transpose-read addresses: lane i of a 16-lane group supplies row kb + (i >> 2), columns (i & 3) * 4
+                const int r1 = (2 * ks) * 16 + g * 4 + (l15 >> 2);
+                const int r2 = r1 + 16;
+#pragma unroll
+                for (int d = 0; d < DF; ++d) {
+                    const int colb = (d * 16 + (l15 & 3) * 4) * 2;  // byte offset of the 8-byte chunk inside the row
+                    const int a1 = r1 * ROWB + (colb ^ ((((r1 & 7) << 1) & (SLOTS - 1)) << 4));
+                    const int a2 = r2 * ROWB + (colb ^ ((((r2 & 7) << 1) & (SLOTS - 1)) << 4));
+                    union {
+                        s16x4_t h[2];
+                        bf16x8_t v;
+                    } vf;
+                    vf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vb + a1));
+                    vf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vb + a2));
+#pragma unroll
+                    for (int f = 0; f < QF; ++f)
+                        oacc[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[f], vf.v, oacc[f][d], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+        float l = lrun[f];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float a = __shfl(inv, g * 4 + r, 64);
+            const int row = qbase + f * 16 + g * 4 + r;
+            if (row < q_len) {
+                bf16* op = out + (b * q_len + row) * ldo + (int64_t)head * D + l15;
+#pragma unroll
+                for (int d = 0; d < DF; ++d) op[d * 16].x = f32_to_bf16(oacc[f][d][r] * a);
+            }
+        }
+    }
+}
+
 // ---- host dispatch ------------------------------------------------------------------------------------------------------
 template <typename T, int D>
 static int launch_attend(int64_t B, int q_len, int heads, const void* qkv, int64_t ld_qkv, const void* kc, const void* vc,
@@ -498,6 +715,8 @@ static int launch_attend(int64_t B, int q_len, int heads, const void* qkv, int64
     return BT_OK;
 }
 
+static int g_flash_variant = 0;  // 0 = v2 (LDS-DMA + transpose reads), 1 = v1 (register/LDS-transposed V)
+
 template <int D>
 static int launch_flash(int64_t B, int q_len, int heads, const void* qkv, int64_t ld_qkv, const void* kc, const void* vc,
                         int64_t n_max, const int32_t* pos0_dev, int pos0_host, const uint8_t* mask, int64_t mask_ld,
@@ -505,8 +724,14 @@ static int launch_flash(int64_t B, int q_len, int heads, const void* qkv, int64_
     const float scale = 1.0f / sqrtf((float)D);
     ProfScope ps(BT_PROF_ATTN_FLASH, s);
     const dim3 grid((unsigned)ceil_div(q_len, FQ_ROWS), (unsigned)heads, (unsigned)B);
-    hipLaunchKernelGGL(flash_prefill_kernel<D>, grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)kc,
-                       (const bf16*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (bf16*)out, ldo, q_len, heads, scale);
+    if (g_flash_variant == 1)
+        hipLaunchKernelGGL(flash_prefill_kernel<D>, grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)kc,
+                           (const bf16*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (bf16*)out, ldo, q_len, heads,
+                           scale);
+    else
+        hipLaunchKernelGGL(flash_prefill_v2_kernel<D>, grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)kc,
+                           (const bf16*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (bf16*)out, ldo, q_len, heads,
+                           scale);
     BT_LAUNCH_CHECK("bt_attention(flash) launch");
     return BT_OK;
 }
@@ -600,3 +825,5 @@ extern "C" int bt_attention(int dtype, int mode, int64_t B, int32_t q_len, int32
     }
 #undef BT_ATT
 }
+
+extern "C" void bt_debug_flash_variant(int v) { bt::g_flash_variant = v; }

@@ -24,7 +24,6 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 __device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
 constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand tile
 constexpr int GROUP_M = 8;
 
 // logical tile id for this workgroup: bijective XCD remap (cdna guide T1) then GROUP_M grouping
@@ -42,12 +41,14 @@ __device__ inline void tile_coords(int tiles_m, int tiles_n, int& tm, int& tn) {
     tn = in_g / gm;
 }
 
-// issue the LDS-DMA for one 128-row x 64-col bf16 tile: wave w covers rows [32w, 32w+32) in 4 instructions of 8 rows
+// issue the LDS-DMA for one ROWS-row x 64-col bf16 tile: each wave-instruction moves 8 rows of 128 B
+template <int ROWS>
 __device__ inline void stage_tile(const bf16* __restrict__ src, int64_t ld, int row0, int row_max, int k0, char* lds_tile,
                                   int wave, int lane) {
+    constexpr int NI = ROWS / 32;  // instructions per wave (4 waves)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int rbase = wave * 32 + i * 8;
+    for (int i = 0; i < NI; ++i) {
+        const int rbase = (wave * NI + i) * 8;
         const int row = rbase + (lane >> 3);
         const int gslot = (lane & 7) ^ (row & 7);
         int grow = row0 + row;
@@ -64,52 +65,55 @@ __device__ inline bf16x8_t read_frag(const char* lds_tile, int row_base, int kk,
     return *reinterpret_cast<const bf16x8_t*>(lds_tile + row * 128 + slot * 16);
 }
 
+// TBM x TBN x 64 tile, 4 waves (2 x 2); 128x128 for full grids, 128x64 / 64x64 when the grid would not fill 256 CUs
+template <int TBM, int TBN>
 __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restrict__ A, int64_t lda,
                                                             const bf16* __restrict__ W, int64_t ldw,
                                                             const bf16* __restrict__ bias,
                                                             const bf16* res, int64_t ldr,
                                                             bf16* out, int64_t ldo, int M, int N, int K,
                                                             int act, int tiles_m, int tiles_n) {
-    // [buf][A | W][128 rows][64 bf16]  = 64 KiB
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_BYTES];
+    constexpr int A_BYTES = TBM * BK * 2, W_BYTES = TBN * BK * 2, STAGE = A_BYTES + W_BYTES;
+    constexpr int FM = TBM / 32, FN = TBN / 32;  // 16x16 fragments per wave along m / n
+    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int tm, tn;
     tile_coords(tiles_m, tiles_n, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * TBM, n0 = tn * TBN;
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[FN][FM];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FN; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nk = K / BK;
-    stage_tile(A, lda, m0, M, 0, smem, wave, lane);
-    stage_tile(W, ldw, n0, N, 0, smem + TILE_BYTES, wave, lane);
+    stage_tile<TBM>(A, lda, m0, M, 0, smem, wave, lane);
+    stage_tile<TBN>(W, ldw, n0, N, 0, smem + A_BYTES, wave, lane);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int t = 0; t < nk; ++t) {
         const int cur = t & 1;
-        char* a_cur = smem + cur * 2 * TILE_BYTES;
-        char* w_cur = a_cur + TILE_BYTES;
+        char* a_cur = smem + cur * STAGE;
+        char* w_cur = a_cur + A_BYTES;
         if (t + 1 < nk) {
-            char* a_nxt = smem + (cur ^ 1) * 2 * TILE_BYTES;
-            stage_tile(A, lda, m0, M, (t + 1) * BK, a_nxt, wave, lane);
-            stage_tile(W, ldw, n0, N, (t + 1) * BK, a_nxt + TILE_BYTES, wave, lane);
+            char* a_nxt = smem + (cur ^ 1) * STAGE;
+            stage_tile<TBM>(A, lda, m0, M, (t + 1) * BK, a_nxt, wave, lane);
+            stage_tile<TBN>(W, ldw, n0, N, (t + 1) * BK, a_nxt + A_BYTES, wave, lane);
         }
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            bf16x8_t wf[4], af[4];
+            bf16x8_t wf[FN], af[FM];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) wf[i] = read_frag(w_cur, wn * 64 + i * 16, kk, lane);
+            for (int i = 0; i < FN; ++i) wf[i] = read_frag(w_cur, wn * (TBN / 2) + i * 16, kk, lane);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) af[j] = read_frag(a_cur, wm * 64 + j * 16, kk, lane);
+            for (int j = 0; j < FM; ++j) af[j] = read_frag(a_cur, wm * (TBM / 2) + j * 16, kk, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < FN; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < FM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -119,12 +123,12 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restr
     // epilogue: D[i = n][j = m]; lane holds column m = lane & 15 and rows n = (lane >> 4) * 4 + r
     const bool vec_ok = ((N & 3) == 0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + wm * 64 + j * 16 + (lane & 15);
+    for (int j = 0; j < FM; ++j) {
+        const int m = m0 + wm * (TBM / 2) + j * 16 + (lane & 15);
         if (m >= M) continue;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int n = n0 + wn * 64 + i * 16 + (lane >> 4) * 4;
+        for (int i = 0; i < FN; ++i) {
+            const int n = n0 + wn * (TBN / 2) + i * 16 + (lane >> 4) * 4;
             if (n >= N) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (vec_ok) {
@@ -468,11 +472,22 @@ extern "C" int bt_linear(int dtype, int64_t M, int64_t N, int64_t K, const void*
                                    (bf16*)out, ldo, (int)M, (int)N, (int)K, act, tiles_m, tiles_n);
         } else if (mfma_ok) {
             ProfScope ps(BT_PROF_LINEAR_MFMA, s);
-            const int tiles_m = (int)ceil_div(M, BM), tiles_n = (int)ceil_div(N, BN);
+            // pick the largest tile that still gives every CU a workgroup (256 CUs): 128x128 -> 128x64 -> 64x64
+            int tbm = 128, tbn = 128;
+            if (g_gemm_variant != 1) {
+                if (ceil_div(M, 128) * ceil_div(N, 128) < 256) tbn = 64;
+                if (ceil_div(M, 128) * ceil_div(N, 64) < 256 && tbn == 64) tbm = 64;
+            }
+            const int tiles_m = (int)ceil_div(M, tbm), tiles_n = (int)ceil_div(N, tbn);
             BT_CHECK_ARG((int64_t)tiles_m * tiles_n < (1ll << 31), "bt_linear: grid too large");
-            hipLaunchKernelGGL(gemm_bf16_mfma_kernel, dim3(tiles_m * tiles_n), dim3(256), 0, s, (const bf16*)A, lda,
-                               (const bf16*)W, K, (const bf16*)bias, (const bf16*)residual, ldr, (bf16*)out, ldo,
-                               (int)M, (int)N, (int)K, act, tiles_m, tiles_n);
+#define BT_LAUNCH_GEMM(TM_, TN_)                                                                                        \
+    hipLaunchKernelGGL((gemm_bf16_mfma_kernel<TM_, TN_>), dim3(tiles_m * tiles_n), dim3(256), 0, s, (const bf16*)A, lda, \
+                       (const bf16*)W, K, (const bf16*)bias, (const bf16*)residual, ldr, (bf16*)out, ldo, (int)M, (int)N, \
+                       (int)K, act, tiles_m, tiles_n)
+            if (tbm == 128 && tbn == 128) BT_LAUNCH_GEMM(128, 128);
+            else if (tbm == 128) BT_LAUNCH_GEMM(128, 64);
+            else BT_LAUNCH_GEMM(64, 64);
+#undef BT_LAUNCH_GEMM
         } else {
             ProfScope ps(BT_PROF_LINEAR_GENERIC, s);
             dim3 grid((unsigned)ceil_div(N, 64), (unsigned)ceil_div(M, 64));

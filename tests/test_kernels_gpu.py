@@ -290,16 +290,24 @@ def test_attention_rows_mask(dtype):
         assert out.view(B, -1)[1].abs().max() == 0
 
 
+@pytest.fixture(params=[0, 1], ids=["flash_v2", "flash_v1"])
+def flash_variant(request):
+    """0 = LDS-DMA + ds_read_b64_tr_b16 kernel (default), 1 = first-generation kernel (kept for A/B)."""
+    lib().bt_debug_flash_variant(request.param)
+    yield request.param
+    lib().bt_debug_flash_variant(0)
+
+
 @pytest.mark.parametrize("d", [32, 64, 128])
-@pytest.mark.parametrize("q,pos0", [(5, 0), (64, 0), (130, 0), (512, 0), (200, 56)])
-def test_attention_flash_prefill(d, q, pos0):
-    """bf16 MFMA flash kernel vs fp64 reference (tolerance: P is rounded to bf16 before PV, ~2^-8 relative)."""
+@pytest.mark.parametrize("q,pos0", [(5, 0), (64, 0), (130, 0), (512, 0), (200, 56), (257, 0)])
+def test_attention_flash_prefill(d, q, pos0, flash_variant):
+    """bf16 MFMA flash kernels vs fp64 reference (tolerance: P is rounded to bf16 before PV, ~2^-8 relative)."""
     n_max = pos0 + q + 3
     out, ref = run_attention(torch.bfloat16, 1, 2, q, 2, d, pos0, n_max, None, seed=q)
     assert rel_err(out, ref) <= 2e-2, rel_err(out, ref)
 
 
-def test_attention_flash_prefill_mask_matches_rows_kernel():
+def test_attention_flash_prefill_mask_matches_rows_kernel(flash_variant):
     B, q = 3, 150
     mask = (torch.rand(B, q + 2, generator=g(9)) > 0.25).long()
     mask[:, 0] = 1
@@ -310,7 +318,7 @@ def test_attention_flash_prefill_mask_matches_rows_kernel():
     assert out_f.view(B, q, -1)[2, :40].abs().max() == 0
 
 
-def test_attention_online_softmax_rescale_branch():
+def test_attention_online_softmax_rescale_branch(flash_variant):
     """Force the running max to jump late (rule 26 of the CDNA guide): spike one key far into the sequence."""
     B, q, heads, d = 1, 192, 1, 128
     H = heads * d

@@ -114,7 +114,12 @@ def main():
     elif args.what == "attn":
         res.append(probe_attn(args.batch, args.keys, args.iters, n_split=args.split))
     elif args.what == "flash":
-        res.append(probe_flash(args.batch, args.keys, args.iters))
+        for v in (0, 1, 0, 1):
+            lib().bt_debug_flash_variant(v)
+            r = probe_flash(args.batch, args.keys, args.iters)
+            r["variant"] = "v2" if v == 0 else "v1"
+            res.append(r)
+        lib().bt_debug_flash_variant(0)
     elif args.what == "copy":
         res.append(probe_copy(1 << 30, args.iters))
     elif args.what == "ab":
