@@ -122,7 +122,8 @@ def main():
     ap.add_argument("--config", default="block_main_b4_1.2b")
     ap.add_argument("--prefill", type=int, default=2048)
     ap.add_argument("--decode", type=int, default=128)
-    ap.add_argument("--batch", type=int, default=1024, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--batch", type=int, default=4096,
+                    help="per-GPU batch (weak scaling); 4096 x 544 block positions x 98 304 B = 219 GB of global KV")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")

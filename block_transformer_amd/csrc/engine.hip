@@ -46,22 +46,62 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
     void* h4 = p + 5 * M * H * es;
     void* att = ln1;
 
+    // When the caller consumes only the LAST row of every sequence (prefill -> context embedding; token-decoder step 0),
+    // the last layer's attention output / dense / MLP are needed for that row alone: the other rows of that layer only
+    // contribute their K,V (cache) — skip 9/12 of the last layer's GEMM flops and its attention, exactly.
+    const bool tail_only = (q_len > 1) && (first_out_row == q_len - 1);
     for (int l = 0; l < dims->layers; ++l) {
         const bt_layer_weights& lw = w->layers_host[l];
         char* kc = reinterpret_cast<char*>(attn->k_cache) + (int64_t)l * attn->layer_stride * es;
         char* vc = reinterpret_cast<char*>(attn->v_cache) + (int64_t)l * attn->layer_stride * es;
-        BT_TRY(bt_layernorm(dtype, M, H, x, H, lw.ln1_w, lw.ln1_b, ln1, H, lw.ln2_w, lw.ln2_b, ln2, H, dims->ln_eps,
-                            stream));
+        const bool last = tail_only && (l == dims->layers - 1);
+        if (!last) {
+            BT_TRY(bt_layernorm(dtype, M, H, x, H, lw.ln1_w, lw.ln1_b, ln1, H, lw.ln2_w, lw.ln2_b, ln2, H, dims->ln_eps,
+                                stream));
+        } else {
+            // LN1 for every row (QKV needs it), LN2 only for the consumed rows (compacted into ln2[0..B))
+            BT_TRY(bt_layernorm(dtype, M, H, x, H, lw.ln1_w, lw.ln1_b, ln1, H, nullptr, nullptr, nullptr, 0, dims->ln_eps,
+                                stream));
+            const char* xl = reinterpret_cast<const char*>(x) + (int64_t)(q_len - 1) * H * es;
+            BT_TRY(bt_layernorm(dtype, B, H, xl, (int64_t)q_len * H, lw.ln2_w, lw.ln2_b, ln2, H, nullptr, nullptr, nullptr,
+                                0, dims->ln_eps, stream));
+        }
         BT_TRY(bt_linear(dtype, M, 3 * H, H, ln1, H, lw.qkv_w, lw.qkv_b, nullptr, 0, qkv, 3 * H, BT_ACT_NONE, stream));
         BT_TRY(bt_rope_kv_append(dtype, B, q_len, dims->heads, dims->head_dim, dims->rot, qkv, 3 * H, kc, vc,
                                  attn->n_max, attn->pos0_dev, attn->pos0_host, attn->pos_table, attn->cos_tab,
                                  attn->sin_tab, stream));
-        BT_TRY(bt_attention(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc, attn->n_max,
-                            attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H, attn->n_split,
-                            attn->split_ws, attn->split_ws_bytes, stream));
-        BT_TRY(bt_linear(dtype, M, H, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, BT_ACT_NONE, stream));
-        BT_TRY(bt_linear(dtype, M, I, H, ln2, H, lw.h4_w, lw.h4_b, nullptr, 0, h4, I, BT_ACT_GELU, stream));
-        BT_TRY(bt_linear(dtype, M, H, I, h4, I, lw.h_w, lw.h_b, x, H, x, H, BT_ACT_NONE, stream));
+        if (!last) {
+            BT_TRY(bt_attention(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc,
+                                attn->n_max, attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H,
+                                attn->n_split, attn->split_ws, attn->split_ws_bytes, stream));
+            BT_TRY(bt_linear(dtype, M, H, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, BT_ACT_NONE, stream));
+            BT_TRY(bt_linear(dtype, M, I, H, ln2, H, lw.h4_w, lw.h4_b, nullptr, 0, h4, I, BT_ACT_GELU, stream));
+            BT_TRY(bt_linear(dtype, M, H, I, h4, I, lw.h_w, lw.h_b, x, H, x, H, BT_ACT_NONE, stream));
+        } else {
+            // one query row per sequence: row (q_len - 1) at cache position pos0 + q_len - 1; row-wise kernel, q_len = 1
+            const char* ql = reinterpret_cast<const char*>(qkv) + (int64_t)(q_len - 1) * 3 * H * es;
+            char* xl = reinterpret_cast<char*>(x) + (int64_t)(q_len - 1) * H * es;
+            int32_t split = attn->mode == 0 ? attn->n_split : 1;
+            // the device-side start position (if any) counts from the first new row: shift it by q_len - 1 on the host
+            // side only when it is a host value; a device scalar cannot be shifted here, so fall back to the full path
+            if (attn->pos0_dev != nullptr) {
+                BT_TRY(bt_attention(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc,
+                                    attn->n_max, attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H,
+                                    attn->n_split, attn->split_ws, attn->split_ws_bytes, stream));
+                const char* al = reinterpret_cast<const char*>(att) + (int64_t)(q_len - 1) * H * es;
+                BT_TRY(bt_linear(dtype, B, H, H, al, (int64_t)q_len * H, lw.dense_w, lw.dense_b, xl, (int64_t)q_len * H,
+                                 xl, (int64_t)q_len * H, BT_ACT_NONE, stream));
+            } else {
+                BT_TRY(bt_attention(dtype, 0, B, 1, dims->heads, dims->head_dim, ql, (int64_t)q_len * 3 * H, kc, vc,
+                                    attn->n_max, nullptr, attn->pos0_host + q_len - 1, attn->mask, attn->mask_ld, att, H,
+                                    split, attn->split_ws, attn->split_ws_bytes, stream));
+                BT_TRY(bt_linear(dtype, B, H, H, att, H, lw.dense_w, lw.dense_b, xl, (int64_t)q_len * H, xl,
+                                 (int64_t)q_len * H, BT_ACT_NONE, stream));
+            }
+            BT_TRY(bt_linear(dtype, B, I, H, ln2, H, lw.h4_w, lw.h4_b, nullptr, 0, h4, I, BT_ACT_GELU, stream));
+            BT_TRY(bt_linear(dtype, B, H, I, h4, I, lw.h_w, lw.h_b, xl, (int64_t)q_len * H, xl, (int64_t)q_len * H,
+                             BT_ACT_NONE, stream));
+        }
     }
     // final_layer_norm of the rows the caller consumes
     const int count = q_len - first_out_row;

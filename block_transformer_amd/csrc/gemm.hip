@@ -243,7 +243,9 @@ __device__ inline void cbarrier() {
 // 16-MFMA cluster (s_setprio 1) its partner issues the DMA and ds_reads of its own phase, so the matrix pipe does not
 // idle during LDS latency.  Group 1 therefore waits for phase g+1's data before the barrier that opens group 0's phase
 // g+1 (every wave must have waited for its DMA share before ANY wave reads).
-template <bool STAGGER>
+// ABL (timing experiments only, results are wrong for 1 and 2): 1 = no DMA in the loop, 2 = no ds_reads in the loop,
+// 4 = ds_reads before the DMA issue, 8 = DMA issued in the middle of the MFMA cluster
+template <bool STAGGER, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_mfma256_kernel(const bf16* __restrict__ A, int64_t lda,
                                                                const bf16* __restrict__ W, int64_t ldw,
                                                                const bf16* __restrict__ bias, const bf16* res,
@@ -296,8 +298,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256_kernel(const bf16* __re
             const int g = 4 * t + p;
             if (!grp1) wait_for_phase(g, total);
             cbarrier();
-            if (g + PD < total) stage_half(A, lda, W, ldw, m0, n0, M, N, g + PD, smem, wave, lane);
-            if (p == 0) {
+            if (!(ABL & (1 | 4 | 8)) && g + PD < total) stage_half(A, lda, W, ldw, m0, n0, M, N, g + PD, smem, wave, lane);
+            if (ABL & 2) {
+                if (t == 0 && p == 0) {
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            wf[0][j][kk] = read_frag(buf + 2 * HALF_BYTES, wn * 32 + j * 16, kk, lane);
+                            wf[1][j][kk] = read_frag(buf + 3 * HALF_BYTES, wn * 32 + j * 16, kk, lane);
+                        }
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) af[i][kk] = read_frag(buf, wm * 64 + i * 16, kk, lane);
+                    }
+                }
+            } else if (p == 0) {
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
@@ -316,6 +331,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256_kernel(const bf16* __re
 #pragma unroll
                     for (int i = 0; i < 4; ++i) af[i][kk] = read_frag(buf + HALF_BYTES, wm * 64 + i * 16, kk, lane);
             }
+            if ((ABL & 4) && g + PD < total) stage_half(A, lda, W, ldw, m0, n0, M, N, g + PD, smem, wave, lane);
             if (STAGGER) {
                 if (grp1) wait_for_phase(g + 1, total);
                 cbarrier();
@@ -325,19 +341,181 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256_kernel(const bf16* __re
             const int wh = (p == 1 || p == 2) ? 1 : 0;
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
+            for (int kk = 0; kk < 2; ++kk) {
+                if ((ABL & 8) && kk == 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g + PD < total) stage_half(A, lda, W, ldw, m0, n0, M, N, g + PD, smem, wave, lane);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[ah * 4 + i][wh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                             wf[wh][j][kk], af[i][kk], acc[ah * 4 + i][wh * 2 + j], 0, 0, 0);
+            }
             __builtin_amdgcn_s_setprio(0);
         }
     }
     if (STAGGER && !grp1) cbarrier();
 
     // epilogue: D[i = n][j = m]; lane holds column m = lane & 15 and rows n = (lane >> 4) * 4 + r  (N % 4 == 0 required)
+#pragma unroll
+    for (int ai = 0; ai < 8; ++ai) {
+        const int m = m0 + (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16 + (lane & 15);
+        if (m >= M) continue;
+#pragma unroll
+        for (int wj = 0; wj < 4; ++wj) {
+            const int n = n0 + (wj >> 1) * 128 + wn * 32 + (wj & 1) * 16 + (lane >> 4) * 4;
+            if (n >= N) continue;
+            float v[4] = {acc[ai][wj][0], acc[ai][wj][1], acc[ai][wj][2], acc[ai][wj][3]};
+            if (bias) {
+                const uint2 b2 = *reinterpret_cast<const uint2*>(bias + n);
+                v[0] += __uint_as_float(b2.x << 16); v[1] += __uint_as_float(b2.x & 0xffff0000u);
+                v[2] += __uint_as_float(b2.y << 16); v[3] += __uint_as_float(b2.y & 0xffff0000u);
+            }
+            if (act == BT_ACT_GELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            }
+            if (res) {
+                const uint2 r2 = *reinterpret_cast<const uint2*>(res + (int64_t)m * ldr + n);
+                v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
+                v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+            }
+            uint2 o2;
+            o2.x = pack_bf16x2(v[0], v[1]);
+            o2.y = pack_bf16x2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(out + (int64_t)m * ldo + n) = o2;
+        }
+    }
+}
+
+// ---- 256x256, two 32-MFMA phases per K-tile ---------------------------------------------------------------------------------
+// Same tile, LDS ring and fragment mapping as gemm_bf16_mfma256_kernel, but a phase is 32 MFMAs (half of the wave's output
+// x K = 64) so a K-tile costs 4 barriers instead of 8:
+//     phase 2t  : reads A0, W0, W1 -> MFMA(A0,W0), MFMA(A0,W1)        phase 2t+1: reads A1 -> MFMA(A1,W1), MFMA(A1,W0)
+// Two half-tile loads are issued per phase, PD2 = 6 loads ahead (consumption order A0,W0,W1,A1).
+//   RAW: before the barrier that opens phase g every wave has waited for the loads that phase reads;
+//   WAR: load s+8 reuses the slot of load s and is issued >= 1 barrier after the last read of s (checked by simulation,
+//        tests/test_host_logic.py::test_gemm_ring_schedules).
+constexpr int PD2 = 6;
+
+__device__ inline void wait_for_phase2(int g, int total_loads) {
+    // loads phase g needs: all of K-tile t's A0,W0,W1 (s <= 4t+2) for even g, plus A1 (s <= 4t+3) for odd g
+    const int t = g >> 1;
+    if (4 * t >= total_loads) return;
+    const int need = 4 * t + ((g & 1) ? 3 : 2);
+    const int issued = min(2 * (g - 1) + 1 + PD2, total_loads - 1);   // through phase g-1 (prologue: s < PD2)
+    const int allow = issued - need;
+    if (allow >= 4) wait_vmcnt<8>();
+    else if (allow == 3) wait_vmcnt<6>();
+    else if (allow == 2) wait_vmcnt<4>();
+    else if (allow == 1) wait_vmcnt<2>();
+    else wait_vmcnt<0>();
+}
+
+template <bool STAGGER>
+__global__ __launch_bounds__(512) void gemm_bf16_mfma256p2_kernel(const bf16* __restrict__ A, int64_t lda,
+                                                                 const bf16* __restrict__ W, int64_t ldw,
+                                                                 const bf16* __restrict__ bias, const bf16* res,
+                                                                 int64_t ldr, bf16* out, int64_t ldo, int M, int N, int K,
+                                                                 int act, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char smem[8 * HALF_BYTES];  // 128 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool grp1 = STAGGER && (__builtin_amdgcn_readfirstlane(tid >> 8) != 0);
+    int tm, tn;
+    {
+        const int nwg = tiles_m * tiles_n;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int group_sz = GROUP_M2 * tiles_n;
+        const int g = id / group_sz;
+        const int first_m = g * GROUP_M2;
+        const int gm = min(tiles_m - first_m, GROUP_M2);
+        const int in_g = id - g * group_sz;
+        tm = first_m + in_g % gm;
+        tn = in_g / gm;
+    }
+    const int m0 = tm * BM2, n0 = tn * BN2;
+
+    f32x4_t acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = K / BK;
+    const int total = 4 * nk;      // half-tile loads
+    const int phases = 2 * nk;
+#pragma unroll
+    for (int s = 0; s < PD2; ++s)
+        if (s < total) stage_half(A, lda, W, ldw, m0, n0, M, N, s, smem, wave, lane);
+
+    bf16x8_t af[4][2];
+    bf16x8_t wf[2][2][2];
+
+    if (grp1) {
+        wait_for_phase2(0, total);
+        cbarrier();
+    }
+    for (int t = 0; t < nk; ++t) {
+        const char* buf = smem + (t & 1) * 4 * HALF_BYTES;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int g = 2 * t + p;
+            if (!grp1) wait_for_phase2(g, total);
+            cbarrier();
+            if (p == 0) {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        wf[0][j][kk] = read_frag(buf + 2 * HALF_BYTES, wn * 32 + j * 16, kk, lane);
+                        wf[1][j][kk] = read_frag(buf + 3 * HALF_BYTES, wn * 32 + j * 16, kk, lane);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[i][kk] = read_frag(buf, wm * 64 + i * 16, kk, lane);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[i][kk] = read_frag(buf + HALF_BYTES, wm * 64 + i * 16, kk, lane);
+            }
+            // two half-tile DMAs per phase, after the ds_reads were issued (their issue cost hides LDS latency)
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int s = 2 * g + e + PD2;
+                if (s < total) stage_half(A, lda, W, ldw, m0, n0, M, N, s, smem, wave, lane);
+            }
+            if (STAGGER) {
+                if (grp1) wait_for_phase2(g + 1, total);
+                cbarrier();
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const int ah = p;
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int wh = (p == 0) ? h : 1 - h;   // A0: W0 then W1 ; A1: W1 then W0
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[ah * 4 + i][wh * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                wf[wh][j][kk], af[i][kk], acc[ah * 4 + i][wh * 2 + j], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+    (void)phases;
+    if (STAGGER && !grp1) cbarrier();
+
 #pragma unroll
     for (int ai = 0; ai < 8; ++ai) {
         const int m = m0 + (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16 + (lane & 15);
@@ -431,7 +609,8 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const T* __restrict__
 }
 
 static bool g_force_generic = false;
-static int g_gemm_variant = 0;  // 0 auto, 1 force 128^2, 2 force 256^2 (no stagger), 3 force 256^2 staggered (tests / A-B probes)
+static int g_gemm_variant = 0;  // 0 auto; 1 force 128^2; 2/3 256^2 four-phase ring (plain/staggered); 4-8 timing ablations; 9/10 256^2 two-phase
+// ring (staggered/plain).  Tests and A/B probes only.
 
 }  // namespace bt
 
@@ -462,14 +641,35 @@ extern "C" int bt_linear(int dtype, int64_t M, int64_t N, int64_t K, const void*
         if (use256) {
             ProfScope ps(BT_PROF_LINEAR_MFMA, s);
             const int tiles_m = (int)ceil_div(M, BM2), tiles_n = (int)ceil_div(N, BN2);
-            if (g_gemm_variant == 2)
-                hipLaunchKernelGGL(gemm_bf16_mfma256_kernel<false>, dim3(tiles_m * tiles_n), dim3(512), 0, s,
-                                   (const bf16*)A, lda, (const bf16*)W, K, (const bf16*)bias, (const bf16*)residual, ldr,
-                                   (bf16*)out, ldo, (int)M, (int)N, (int)K, act, tiles_m, tiles_n);
-            else
-                hipLaunchKernelGGL(gemm_bf16_mfma256_kernel<true>, dim3(tiles_m * tiles_n), dim3(512), 0, s,
-                                   (const bf16*)A, lda, (const bf16*)W, K, (const bf16*)bias, (const bf16*)residual, ldr,
-                                   (bf16*)out, ldo, (int)M, (int)N, (int)K, act, tiles_m, tiles_n);
+#define BT_LAUNCH_256(ST_, ABL_)                                                                                          \
+    hipLaunchKernelGGL((gemm_bf16_mfma256_kernel<ST_, ABL_>), dim3(tiles_m * tiles_n), dim3(512), 0, s, (const bf16*)A, lda, \
+                       (const bf16*)W, K, (const bf16*)bias, (const bf16*)residual, ldr, (bf16*)out, ldo, (int)M, (int)N,  \
+                       (int)K, act, tiles_m, tiles_n)
+            switch (g_gemm_variant) {
+                case 2: BT_LAUNCH_256(false, 0); break;
+                case 4: BT_LAUNCH_256(true, 1); break;   // timing ablation: no DMA        (wrong results)
+                case 5: BT_LAUNCH_256(true, 2); break;   // timing ablation: no ds_reads   (wrong results)
+                case 6: BT_LAUNCH_256(true, 4); break;   // ds_reads before the DMA issue
+                case 7: BT_LAUNCH_256(true, 8); break;   // DMA issued inside the MFMA cluster
+                case 8: BT_LAUNCH_256(true, 3); break;   // timing ablation: MFMA + barriers only (wrong results)
+                case 9:
+                    hipLaunchKernelGGL((gemm_bf16_mfma256p2_kernel<true>), dim3(tiles_m * tiles_n), dim3(512), 0, s,
+                                       (const bf16*)A, lda, (const bf16*)W, K, (const bf16*)bias, (const bf16*)residual,
+                                       ldr, (bf16*)out, ldo, (int)M, (int)N, (int)K, act, tiles_m, tiles_n);
+                    break;
+                case 10:
+                    hipLaunchKernelGGL((gemm_bf16_mfma256p2_kernel<false>), dim3(tiles_m * tiles_n), dim3(512), 0, s,
+                                       (const bf16*)A, lda, (const bf16*)W, K, (const bf16*)bias, (const bf16*)residual,
+                                       ldr, (bf16*)out, ldo, (int)M, (int)N, (int)K, act, tiles_m, tiles_n);
+                    break;
+                case 3: BT_LAUNCH_256(true, 0); break;
+                default:  // production: two 32-MFMA phases per K-tile, staggered wave groups
+                    hipLaunchKernelGGL((gemm_bf16_mfma256p2_kernel<true>), dim3(tiles_m * tiles_n), dim3(512), 0, s,
+                                       (const bf16*)A, lda, (const bf16*)W, K, (const bf16*)bias, (const bf16*)residual,
+                                       ldr, (bf16*)out, ldo, (int)M, (int)N, (int)K, act, tiles_m, tiles_n);
+                    break;
+            }
+#undef BT_LAUNCH_256
         } else if (mfma_ok) {
             ProfScope ps(BT_PROF_LINEAR_MFMA, s);
             // pick the largest tile that still gives every CU a workgroup (256 CUs): 128x128 -> 128x64 -> 64x64

@@ -73,7 +73,7 @@ def test_linear_mfma_equals_generic_bf16():
 
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 520, 128), (512, 768, 2048), (1000, 260, 448), (64, 1024, 192)])
 @pytest.mark.parametrize("variant", ["plain", "bias_gelu", "bias_res"])
-@pytest.mark.parametrize("kernel", [2, 3])
+@pytest.mark.parametrize("kernel", [2, 3, 9, 10])
 def test_linear_256_tile_kernel(M, N, K, variant, kernel):
     """The deep-pipelined 256x256 kernel (forced) against fp64, incl. M/N tails and every pipeline length nk = K/64
     (nk = 1..7 exercise the prologue/epilogue wait counts of the half-tile ring)."""
@@ -88,7 +88,8 @@ def test_linear_256_tile_kernel(M, N, K, variant, kernel):
         ref = F.gelu(ref)
     if r is not None:
         ref = ref + r.double()
-    lib().bt_debug_gemm_variant(kernel)   # 2 = half-tile ring, 3 = ring + staggered wave groups
+    # 2 = half-tile ring, 3 = ring + staggered wave groups, 9 / 10 = two 32-MFMA phases per K-tile (staggered / not)
+    lib().bt_debug_gemm_variant(kernel)
     try:
         out = ops.linear(x.to(DEV), w.to(DEV), None if b is None else b.to(DEV), None if r is None else r.to(DEV),
                          act="gelu" if variant == "bias_gelu" else "none").cpu()
@@ -104,7 +105,7 @@ def test_linear_256_tile_kernel_repeatable():
     lib().bt_debug_gemm_variant(1)
     base = ops.linear(x, w)
     try:
-        for kernel in (2, 3):
+        for kernel in (2, 3, 9, 10):
             lib().bt_debug_gemm_variant(kernel)
             outs = [ops.linear(x, w) for _ in range(20)]
             torch.cuda.synchronize()

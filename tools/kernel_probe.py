@@ -97,7 +97,7 @@ def probe_copy(nbytes, iters):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["gemm", "attn", "flash", "suite", "copy", "ab"])
+    ap.add_argument("what", choices=["gemm", "attn", "flash", "suite", "copy", "ab", "abl"])
     ap.add_argument("--m", type=int, default=32768)
     ap.add_argument("--n", type=int, default=6144)
     ap.add_argument("--k", type=int, default=2048)
@@ -130,6 +130,14 @@ def main():
             for v in (1, 2, 3, 1, 2, 3):
                 lib().bt_debug_gemm_variant(v)
                 r = probe_gemm(M, N, K, 10 if M > 8000 else 20)
+                r["variant"] = v
+                res.append(r)
+        lib().bt_debug_gemm_variant(0)
+    elif args.what == "abl":
+        for (M, N, K) in ((32768, 6144, 2048), (32768, 2048, 8192)):
+            for v in (3, 9, 10, 6, 3, 9, 10, 6):
+                lib().bt_debug_gemm_variant(v)
+                r = probe_gemm(M, N, K, 10)
                 r["variant"] = v
                 res.append(r)
         lib().bt_debug_gemm_variant(0)
