@@ -52,6 +52,9 @@ _SIGS = {
                               c_void_p, c_int32, c_void_p]),
     "bt_rope_kv_append": (c_int, [c_int, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p,
                                   c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bt_qkv_rope_append": (c_int, [c_int, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_void_p,
+                                   c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p,
+                                   c_void_p, c_void_p]),
     "bt_attention": (c_int, [c_int, c_int, c_int64, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_void_p,
                              c_int64, c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p,
                              c_int64, c_void_p]),
@@ -75,6 +78,7 @@ _SIGS = {
     "bt_prof_collect": (c_int, [POINTER(ctypes.c_double), POINTER(c_int64), c_int]),
     "bt_debug_force_generic_gemm": (None, [c_int]),
     "bt_debug_gemm_variant": (None, [c_int]),
+    "bt_debug_no_qkv_fusion": (None, [c_int]),
     "bt_debug_flash_variant": (None, [c_int]),
     "bt_debug_tr_probe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }

@@ -2,9 +2,9 @@
 // kernel launches on one stream — the unit the Python host captures into a hipGraph per block step.
 //
 // Per layer (parallel residual, HF GPTNeoXLayer):
-//   LN1|LN2(x) -> qkv = LN1 Wqkv^T + b -> RoPE + KV append -> attention -> x += att Wd^T + bd (in place, fused epilogue)
+//   LN1|LN2(x) -> qkv = LN1 Wqkv^T + b with RoPE + KV append fused into the GEMM epilogue -> attention -> x += att Wd^T + bd (in place, fused epilogue)
 //   -> h = gelu(LN2 W1^T + b1) (fused epilogue) -> x += h W2^T + b2 (in place, fused epilogue)
-// 7 launches per layer instead of the reference's ~25 ATen kernels; no torch.cat cache copy.
+// 6 launches per layer (7 when the fused QKV epilogue does not apply) instead of the reference's ~25 ATen kernels; no torch.cat cache copy.
 //
 // Activation workspace for M rows (elements): [ln1|att: M*H][ln2: M*H][qkv: M*3H][h4: M*I].
 #include "bt_common.h"
@@ -66,10 +66,9 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
             BT_TRY(bt_layernorm(dtype, B, H, xl, (int64_t)q_len * H, lw.ln2_w, lw.ln2_b, ln2, H, nullptr, nullptr, nullptr,
                                 0, dims->ln_eps, stream));
         }
-        BT_TRY(bt_linear(dtype, M, 3 * H, H, ln1, H, lw.qkv_w, lw.qkv_b, nullptr, 0, qkv, 3 * H, BT_ACT_NONE, stream));
-        BT_TRY(bt_rope_kv_append(dtype, B, q_len, dims->heads, dims->head_dim, dims->rot, qkv, 3 * H, kc, vc,
-                                 attn->n_max, attn->pos0_dev, attn->pos0_host, attn->pos_table, attn->cos_tab,
-                                 attn->sin_tab, stream));
+        BT_TRY(bt_qkv_rope_append(dtype, B, q_len, dims->heads, dims->head_dim, dims->rot, ln1, H, lw.qkv_w, lw.qkv_b, qkv,
+                                  3 * H, kc, vc, attn->n_max, attn->pos0_dev, attn->pos0_host, attn->pos_table,
+                                  attn->cos_tab, attn->sin_tab, stream));
         if (!last) {
             BT_TRY(bt_attention(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc,
                                 attn->n_max, attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H,

@@ -23,6 +23,123 @@ typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 __device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
+// ---- shared epilogue ---------------------------------------------------------------------------------------------------
+// Optional fused "QKV mode" (bt_qkv_rope_append): the GEMM is the GPT-NeoX query_key_value projection; instead of
+// writing [M, 3H] and running a separate RoPE/append pass, the epilogue rotates q and k in registers (the rotate-half
+// partner of column e < 16 is column e + 16 = the NEXT 16-column fragment, same lane, same register index) and scatters
+// k (rotated) and v straight into the KV cache; only q goes to the qkv buffer.  Requires head_dim % 32 == 0, rot == 32.
+struct QkvEpi {
+    bf16* kc;
+    bf16* vc;
+    int64_t n_max;
+    const int32_t* pos0_dev;
+    const int32_t* pos_table;
+    const float* cos_tab;
+    const float* sin_tab;
+    int32_t pos0_host;
+    int32_t q_len;
+    int32_t heads;
+    int32_t head_dim;
+    int32_t enabled;
+};
+
+struct EpiArgs {
+    const bf16* bias;
+    const bf16* res;
+    int64_t ldr;
+    bf16* out;
+    int64_t ldo;
+    int M, N, act;
+    QkvEpi q;
+};
+
+__device__ inline void epi_store4(const EpiArgs& e, int m, int n, float (&v)[4], bool vec_ok) {
+    if (vec_ok) {
+        if (e.bias) {
+            const uint2 b2 = *reinterpret_cast<const uint2*>(e.bias + n);
+            v[0] += __uint_as_float(b2.x << 16); v[1] += __uint_as_float(b2.x & 0xffff0000u);
+            v[2] += __uint_as_float(b2.y << 16); v[3] += __uint_as_float(b2.y & 0xffff0000u);
+        }
+        if (e.act == BT_ACT_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+        }
+        if (e.res) {
+            const uint2 r2 = *reinterpret_cast<const uint2*>(e.res + (int64_t)m * e.ldr + n);
+            v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
+            v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
+        }
+        uint2 o2;
+        o2.x = pack_bf16x2(v[0], v[1]);
+        o2.y = pack_bf16x2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(e.out + (int64_t)m * e.ldo + n) = o2;
+    } else {
+        for (int r = 0; r < 4; ++r) {
+            if (n + r >= e.N) break;
+            float x = v[r];
+            if (e.bias) x += bf16_to_f32(e.bias[n + r].x);
+            if (e.act == BT_ACT_GELU) x = gelu_erf(x);
+            if (e.res) x += bf16_to_f32(e.res[(int64_t)m * e.ldr + n + r].x);
+            e.out[(int64_t)m * e.ldo + n + r].x = f32_to_bf16(x);
+        }
+    }
+}
+
+// one output row m, two adjacent 16-column fragments starting at the 32-aligned column n_lo - (lane >> 4) * 4
+__device__ inline void epilogue_pair(const EpiArgs& e, int m, int n_lo, const f32x4_t& a_lo, const f32x4_t& a_hi,
+                                     bool vec_ok) {
+    if (m >= e.M) return;
+    float lo[4] = {a_lo[0], a_lo[1], a_lo[2], a_lo[3]};
+    float hi[4] = {a_hi[0], a_hi[1], a_hi[2], a_hi[3]};
+    if (!e.q.enabled) {
+        if (n_lo < e.N) epi_store4(e, m, n_lo, lo, vec_ok);
+        if (n_lo + 16 < e.N) epi_store4(e, m, n_lo + 16, hi, vec_ok);
+        return;
+    }
+    // QKV mode (N = heads * 3 * D, D % 32 == 0, rot == 32; N % 4 == 0 holds)
+    const int D = e.q.head_dim;
+    const int head = n_lo / (3 * D);
+    const int within = n_lo - head * 3 * D;
+    const int part = within / D;              // 0 q, 1 k, 2 v
+    const int el = within - part * D;         // element of the lo fragment; the hi fragment holds el + 16
+    if (e.bias) {
+        const uint2 b2 = *reinterpret_cast<const uint2*>(e.bias + n_lo);
+        const uint2 b3 = *reinterpret_cast<const uint2*>(e.bias + n_lo + 16);
+        lo[0] += __uint_as_float(b2.x << 16); lo[1] += __uint_as_float(b2.x & 0xffff0000u);
+        lo[2] += __uint_as_float(b2.y << 16); lo[3] += __uint_as_float(b2.y & 0xffff0000u);
+        hi[0] += __uint_as_float(b3.x << 16); hi[1] += __uint_as_float(b3.x & 0xffff0000u);
+        hi[2] += __uint_as_float(b3.y << 16); hi[3] += __uint_as_float(b3.y & 0xffff0000u);
+    }
+    const int64_t b = m / e.q.q_len;
+    const int t = m - (int)b * e.q.q_len;
+    const int pos0 = e.q.pos0_dev ? *e.q.pos0_dev : e.q.pos0_host;
+    if (part < 2 && el < 16) {  // first 32 dims of q / k: rotate pairs (el + r, el + r + 16)
+        const int rpos = e.q.pos_table ? e.q.pos_table[pos0 + t] : pos0 + t;
+        const float4 c4 = *reinterpret_cast<const float4*>(e.q.cos_tab + (int64_t)rpos * 16 + el);
+        const float4 s4 = *reinterpret_cast<const float4*>(e.q.sin_tab + (int64_t)rpos * 16 + el);
+        const float c[4] = {c4.x, c4.y, c4.z, c4.w}, sn[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x1 = lo[r], x2 = hi[r];
+            lo[r] = x1 * c[r] - x2 * sn[r];
+            hi[r] = x2 * c[r] + x1 * sn[r];
+        }
+    }
+    uint2 o_lo, o_hi;
+    o_lo.x = pack_bf16x2(lo[0], lo[1]); o_lo.y = pack_bf16x2(lo[2], lo[3]);
+    o_hi.x = pack_bf16x2(hi[0], hi[1]); o_hi.y = pack_bf16x2(hi[2], hi[3]);
+    if (part == 0) {
+        bf16* o = e.out + (int64_t)m * e.ldo + n_lo;
+        *reinterpret_cast<uint2*>(o) = o_lo;
+        *reinterpret_cast<uint2*>(o + 16) = o_hi;
+    } else {
+        bf16* cache = part == 1 ? e.q.kc : e.q.vc;
+        bf16* o = cache + ((b * e.q.heads + head) * e.q.n_max + pos0 + t) * D + el;
+        *reinterpret_cast<uint2*>(o) = o_lo;
+        *reinterpret_cast<uint2*>(o + 16) = o_hi;
+    }
+}
+
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int GROUP_M = 8;
 
@@ -68,11 +185,9 @@ __device__ inline bf16x8_t read_frag(const char* lds_tile, int row_base, int kk,
 // TBM x TBN x 64 tile, 4 waves (2 x 2); 128x128 for full grids, 128x64 / 64x64 when the grid would not fill 256 CUs
 template <int TBM, int TBN>
 __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restrict__ A, int64_t lda,
-                                                            const bf16* __restrict__ W, int64_t ldw,
-                                                            const bf16* __restrict__ bias,
-                                                            const bf16* res, int64_t ldr,
-                                                            bf16* out, int64_t ldo, int M, int N, int K,
-                                                            int act, int tiles_m, int tiles_n) {
+                                                            const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
+                                                            int K, int tiles_m, int tiles_n) {
+    const int M = ep.M, N = ep.N;
     constexpr int A_BYTES = TBM * BK * 2, W_BYTES = TBN * BK * 2, STAGE = A_BYTES + W_BYTES;
     constexpr int FM = TBM / 32, FN = TBN / 32;  // 16x16 fragments per wave along m / n
     __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
@@ -125,41 +240,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restr
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
         const int m = m0 + wm * (TBM / 2) + j * 16 + (lane & 15);
-        if (m >= M) continue;
 #pragma unroll
-        for (int i = 0; i < FN; ++i) {
+        for (int i = 0; i < FN; i += 2) {
             const int n = n0 + wn * (TBN / 2) + i * 16 + (lane >> 4) * 4;
-            if (n >= N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (vec_ok) {
-                if (bias) {
-                    const uint2 b2 = *reinterpret_cast<const uint2*>(bias + n);
-                    v[0] += __uint_as_float(b2.x << 16); v[1] += __uint_as_float(b2.x & 0xffff0000u);
-                    v[2] += __uint_as_float(b2.y << 16); v[3] += __uint_as_float(b2.y & 0xffff0000u);
-                }
-                if (act == BT_ACT_GELU) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-                }
-                if (res) {
-                    const uint2 r2 = *reinterpret_cast<const uint2*>(res + (int64_t)m * ldr + n);
-                    v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
-                    v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
-                }
-                uint2 o2;
-                o2.x = pack_bf16x2(v[0], v[1]);
-                o2.y = pack_bf16x2(v[2], v[3]);
-                *reinterpret_cast<uint2*>(out + (int64_t)m * ldo + n) = o2;
-            } else {
-                for (int r = 0; r < 4; ++r) {
-                    if (n + r >= N) break;
-                    float x = v[r];
-                    if (bias) x += bf16_to_f32(bias[n + r].x);
-                    if (act == BT_ACT_GELU) x = gelu_erf(x);
-                    if (res) x += bf16_to_f32(res[(int64_t)m * ldr + n + r].x);
-                    out[(int64_t)m * ldo + n + r].x = f32_to_bf16(x);
-                }
-            }
+            epilogue_pair(ep, m, n, acc[i][j], acc[i + 1][j], vec_ok);
         }
     }
 }
@@ -247,10 +331,9 @@ __device__ inline void cbarrier() {
 // 4 = ds_reads before the DMA issue, 8 = DMA issued in the middle of the MFMA cluster
 template <bool STAGGER, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_mfma256_kernel(const bf16* __restrict__ A, int64_t lda,
-                                                               const bf16* __restrict__ W, int64_t ldw,
-                                                               const bf16* __restrict__ bias, const bf16* res,
-                                                               int64_t ldr, bf16* out, int64_t ldo, int M, int N, int K,
-                                                               int act, int tiles_m, int tiles_n) {
+                                                               const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
+                                                               int K, int tiles_m, int tiles_n) {
+    const int M = ep.M, N = ep.N;
     __shared__ __attribute__((aligned(16))) char smem[8 * HALF_BYTES];  // 128 KiB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -359,34 +442,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256_kernel(const bf16* __re
     }
     if (STAGGER && !grp1) cbarrier();
 
-    // epilogue: D[i = n][j = m]; lane holds column m = lane & 15 and rows n = (lane >> 4) * 4 + r  (N % 4 == 0 required)
 #pragma unroll
     for (int ai = 0; ai < 8; ++ai) {
         const int m = m0 + (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16 + (lane & 15);
-        if (m >= M) continue;
 #pragma unroll
-        for (int wj = 0; wj < 4; ++wj) {
-            const int n = n0 + (wj >> 1) * 128 + wn * 32 + (wj & 1) * 16 + (lane >> 4) * 4;
-            if (n >= N) continue;
-            float v[4] = {acc[ai][wj][0], acc[ai][wj][1], acc[ai][wj][2], acc[ai][wj][3]};
-            if (bias) {
-                const uint2 b2 = *reinterpret_cast<const uint2*>(bias + n);
-                v[0] += __uint_as_float(b2.x << 16); v[1] += __uint_as_float(b2.x & 0xffff0000u);
-                v[2] += __uint_as_float(b2.y << 16); v[3] += __uint_as_float(b2.y & 0xffff0000u);
-            }
-            if (act == BT_ACT_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-            }
-            if (res) {
-                const uint2 r2 = *reinterpret_cast<const uint2*>(res + (int64_t)m * ldr + n);
-                v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
-                v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
-            }
-            uint2 o2;
-            o2.x = pack_bf16x2(v[0], v[1]);
-            o2.y = pack_bf16x2(v[2], v[3]);
-            *reinterpret_cast<uint2*>(out + (int64_t)m * ldo + n) = o2;
+        for (int wh = 0; wh < 2; ++wh) {
+            const int n = n0 + wh * 128 + wn * 32 + (lane >> 4) * 4;
+            epilogue_pair(ep, m, n, acc[ai][wh * 2], acc[ai][wh * 2 + 1], true);
         }
     }
 }
@@ -415,12 +477,11 @@ __device__ inline void wait_for_phase2(int g, int total_loads) {
     else wait_vmcnt<0>();
 }
 
-template <bool STAGGER>
+template <bool STAGGER, bool NOSTORE = false>
 __global__ __launch_bounds__(512) void gemm_bf16_mfma256p2_kernel(const bf16* __restrict__ A, int64_t lda,
-                                                                 const bf16* __restrict__ W, int64_t ldw,
-                                                                 const bf16* __restrict__ bias, const bf16* res,
-                                                                 int64_t ldr, bf16* out, int64_t ldo, int M, int N, int K,
-                                                                 int act, int tiles_m, int tiles_n) {
+                                                                 const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
+                                                                 int K, int tiles_m, int tiles_n) {
+    const int M = ep.M, N = ep.N;
     __shared__ __attribute__((aligned(16))) char smem[8 * HALF_BYTES];  // 128 KiB
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
@@ -515,34 +576,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256p2_kernel(const bf16* __
     }
     (void)phases;
     if (STAGGER && !grp1) cbarrier();
+    if (NOSTORE) {  // timing ablation: keep the accumulators live, skip the epilogue
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
 
 #pragma unroll
     for (int ai = 0; ai < 8; ++ai) {
         const int m = m0 + (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16 + (lane & 15);
-        if (m >= M) continue;
 #pragma unroll
-        for (int wj = 0; wj < 4; ++wj) {
-            const int n = n0 + (wj >> 1) * 128 + wn * 32 + (wj & 1) * 16 + (lane >> 4) * 4;
-            if (n >= N) continue;
-            float v[4] = {acc[ai][wj][0], acc[ai][wj][1], acc[ai][wj][2], acc[ai][wj][3]};
-            if (bias) {
-                const uint2 b2 = *reinterpret_cast<const uint2*>(bias + n);
-                v[0] += __uint_as_float(b2.x << 16); v[1] += __uint_as_float(b2.x & 0xffff0000u);
-                v[2] += __uint_as_float(b2.y << 16); v[3] += __uint_as_float(b2.y & 0xffff0000u);
-            }
-            if (act == BT_ACT_GELU) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-            }
-            if (res) {
-                const uint2 r2 = *reinterpret_cast<const uint2*>(res + (int64_t)m * ldr + n);
-                v[0] += __uint_as_float(r2.x << 16); v[1] += __uint_as_float(r2.x & 0xffff0000u);
-                v[2] += __uint_as_float(r2.y << 16); v[3] += __uint_as_float(r2.y & 0xffff0000u);
-            }
-            uint2 o2;
-            o2.x = pack_bf16x2(v[0], v[1]);
-            o2.y = pack_bf16x2(v[2], v[3]);
-            *reinterpret_cast<uint2*>(out + (int64_t)m * ldo + n) = o2;
+        for (int wh = 0; wh < 2; ++wh) {
+            const int n = n0 + wh * 128 + wn * 32 + (lane >> 4) * 4;
+            epilogue_pair(ep, m, n, acc[ai][wh * 2], acc[ai][wh * 2 + 1], true);
         }
     }
 }
@@ -609,6 +657,7 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const T* __restrict__
 }
 
 static bool g_force_generic = false;
+static bool g_no_qkv_fusion = false;
 static int g_gemm_variant = 0;  // 0 auto; 1 force 128^2; 2/3 256^2 four-phase ring (plain/staggered); 4-8 timing ablations; 9/10 256^2 two-phase
 // ring (staggered/plain).  Tests and A/B probes only.
 
@@ -616,9 +665,9 @@ static int g_gemm_variant = 0;  // 0 auto; 1 force 128^2; 2/3 256^2 four-phase r
 
 using namespace bt;
 
-extern "C" int bt_linear(int dtype, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* W,
-                         const void* bias, const void* residual, int64_t ldr, void* out, int64_t ldo, int act,
-                         bt_stream stream) {
+static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* W,
+                       const void* bias, const void* residual, int64_t ldr, void* out, int64_t ldo, int act,
+                       const QkvEpi* qkv, bool* fused_out, bt_stream stream) {
     BT_CHECK_ARG(dtype == BT_F32 || dtype == BT_BF16, "bt_linear: bad dtype %d", dtype);
     BT_CHECK_ARG(M >= 0 && N > 0 && K > 0, "bt_linear: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N,
                  (long long)K);
@@ -626,6 +675,7 @@ extern "C" int bt_linear(int dtype, int64_t M, int64_t N, int64_t K, const void*
     BT_CHECK_ARG(lda >= K && ldo >= N && (!residual || ldr >= N), "bt_linear: row stride smaller than row");
     BT_CHECK_ARG(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), "bt_linear: dimension exceeds int32");
     BT_CHECK_ARG(act == BT_ACT_NONE || act == BT_ACT_GELU, "bt_linear: bad activation %d", act);
+    if (fused_out) *fused_out = false;
     if (M == 0) return BT_OK;
     hipStream_t s = (hipStream_t)stream;
     if (dtype == BT_BF16) {
@@ -633,6 +683,22 @@ extern "C" int bt_linear(int dtype, int64_t M, int64_t N, int64_t K, const void*
                              (ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 7u) == 0) &&
                              (!residual || ((ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(residual) & 7u) == 0)) &&
                              (!bias || (reinterpret_cast<uintptr_t>(bias) & 7u) == 0);
+        EpiArgs ep;
+        ep.bias = (const bf16*)bias;
+        ep.res = (const bf16*)residual;
+        ep.ldr = ldr;
+        ep.out = (bf16*)out;
+        ep.ldo = ldo;
+        ep.M = (int)M;
+        ep.N = (int)N;
+        ep.act = act;
+        ep.q = QkvEpi{};
+        // fused QKV epilogue: only on the MFMA kernels, rot == 32 (checked by the caller), 32-aligned head_dim
+        if (qkv && mfma_ok && !g_no_qkv_fusion) {
+            ep.q = *qkv;
+            ep.q.enabled = 1;
+            if (fused_out) *fused_out = true;
+        }
         const int64_t tiles256 = ceil_div(M, BM2) * ceil_div(N, BN2);
         // big-tile kernel: one 8-wave workgroup per CU -> needs >= ~1 full wave of 256 tiles and little tail quantisation
         const bool use256 = mfma_ok && g_gemm_variant != 1 && (N % 4 == 0) &&
@@ -641,33 +707,20 @@ extern "C" int bt_linear(int dtype, int64_t M, int64_t N, int64_t K, const void*
         if (use256) {
             ProfScope ps(BT_PROF_LINEAR_MFMA, s);
             const int tiles_m = (int)ceil_div(M, BM2), tiles_n = (int)ceil_div(N, BN2);
-#define BT_LAUNCH_256(ST_, ABL_)                                                                                          \
-    hipLaunchKernelGGL((gemm_bf16_mfma256_kernel<ST_, ABL_>), dim3(tiles_m * tiles_n), dim3(512), 0, s, (const bf16*)A, lda, \
-                       (const bf16*)W, K, (const bf16*)bias, (const bf16*)residual, ldr, (bf16*)out, ldo, (int)M, (int)N,  \
-                       (int)K, act, tiles_m, tiles_n)
+#define BT_LAUNCH_256(KERN_)                                                                                        \
+    hipLaunchKernelGGL((KERN_), dim3(tiles_m * tiles_n), dim3(512), 0, s, (const bf16*)A, lda, (const bf16*)W, K, ep, \
+                       (int)K, tiles_m, tiles_n)
             switch (g_gemm_variant) {
-                case 2: BT_LAUNCH_256(false, 0); break;
-                case 4: BT_LAUNCH_256(true, 1); break;   // timing ablation: no DMA        (wrong results)
-                case 5: BT_LAUNCH_256(true, 2); break;   // timing ablation: no ds_reads   (wrong results)
-                case 6: BT_LAUNCH_256(true, 4); break;   // ds_reads before the DMA issue
-                case 7: BT_LAUNCH_256(true, 8); break;   // DMA issued inside the MFMA cluster
-                case 8: BT_LAUNCH_256(true, 3); break;   // timing ablation: MFMA + barriers only (wrong results)
-                case 9:
-                    hipLaunchKernelGGL((gemm_bf16_mfma256p2_kernel<true>), dim3(tiles_m * tiles_n), dim3(512), 0, s,
-                                       (const bf16*)A, lda, (const bf16*)W, K, (const bf16*)bias, (const bf16*)residual,
-                                       ldr, (bf16*)out, ldo, (int)M, (int)N, (int)K, act, tiles_m, tiles_n);
-                    break;
-                case 10:
-                    hipLaunchKernelGGL((gemm_bf16_mfma256p2_kernel<false>), dim3(tiles_m * tiles_n), dim3(512), 0, s,
-                                       (const bf16*)A, lda, (const bf16*)W, K, (const bf16*)bias, (const bf16*)residual,
-                                       ldr, (bf16*)out, ldo, (int)M, (int)N, (int)K, act, tiles_m, tiles_n);
-                    break;
-                case 3: BT_LAUNCH_256(true, 0); break;
-                default:  // production: two 32-MFMA phases per K-tile, staggered wave groups
-                    hipLaunchKernelGGL((gemm_bf16_mfma256p2_kernel<true>), dim3(tiles_m * tiles_n), dim3(512), 0, s,
-                                       (const bf16*)A, lda, (const bf16*)W, K, (const bf16*)bias, (const bf16*)residual,
-                                       ldr, (bf16*)out, ldo, (int)M, (int)N, (int)K, act, tiles_m, tiles_n);
-                    break;
+                case 2: BT_LAUNCH_256((gemm_bf16_mfma256_kernel<false, 0>)); break;
+                case 3: BT_LAUNCH_256((gemm_bf16_mfma256_kernel<true, 0>)); break;
+                case 4: BT_LAUNCH_256((gemm_bf16_mfma256_kernel<true, 1>)); break;   // timing ablation: no DMA
+                case 5: BT_LAUNCH_256((gemm_bf16_mfma256_kernel<true, 2>)); break;   // timing ablation: no ds_reads
+                case 6: BT_LAUNCH_256((gemm_bf16_mfma256_kernel<true, 4>)); break;   // ds_reads before the DMA issue
+                case 7: BT_LAUNCH_256((gemm_bf16_mfma256_kernel<true, 8>)); break;   // DMA inside the MFMA cluster
+                case 8: BT_LAUNCH_256((gemm_bf16_mfma256_kernel<true, 3>)); break;   // timing ablation: MFMA+barriers
+                case 10: BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<false>)); break;
+                case 11: BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<true, true>)); break;  // timing ablation: no epilogue
+                default: BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<true>)); break;  // production (also variant 9)
             }
 #undef BT_LAUNCH_256
         } else if (mfma_ok) {
@@ -682,8 +735,7 @@ extern "C" int bt_linear(int dtype, int64_t M, int64_t N, int64_t K, const void*
             BT_CHECK_ARG((int64_t)tiles_m * tiles_n < (1ll << 31), "bt_linear: grid too large");
 #define BT_LAUNCH_GEMM(TM_, TN_)                                                                                        \
     hipLaunchKernelGGL((gemm_bf16_mfma_kernel<TM_, TN_>), dim3(tiles_m * tiles_n), dim3(256), 0, s, (const bf16*)A, lda, \
-                       (const bf16*)W, K, (const bf16*)bias, (const bf16*)residual, ldr, (bf16*)out, ldo, (int)M, (int)N, \
-                       (int)K, act, tiles_m, tiles_n)
+                       (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n)
             if (tbm == 128 && tbn == 128) BT_LAUNCH_GEMM(128, 128);
             else if (tbm == 128) BT_LAUNCH_GEMM(128, 64);
             else BT_LAUNCH_GEMM(64, 64);
@@ -708,6 +760,47 @@ extern "C" int bt_linear(int dtype, int64_t M, int64_t N, int64_t K, const void*
     return BT_OK;
 }
 
+extern "C" int bt_linear(int dtype, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* W,
+                         const void* bias, const void* residual, int64_t ldr, void* out, int64_t ldo, int act,
+                         bt_stream stream) {
+    return linear_impl(dtype, M, N, K, A, lda, W, bias, residual, ldr, out, ldo, act, nullptr, nullptr, stream);
+}
+
+extern "C" int bt_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim, int32_t rot,
+                                  const void* x, int64_t ldx, const void* qkv_w, const void* qkv_b, void* qkv,
+                                  int64_t ld_qkv, void* k_cache, void* v_cache, int64_t n_max, const int32_t* pos0_dev,
+                                  int32_t pos0_host, const int32_t* pos_table, const float* cos_tab, const float* sin_tab,
+                                  bt_stream stream) {
+    BT_CHECK_ARG(B >= 0 && q_len > 0 && heads > 0 && head_dim > 0, "bt_qkv_rope_append: bad shape");
+    BT_CHECK_ARG(x && qkv_w && qkv && k_cache && v_cache && cos_tab && sin_tab, "bt_qkv_rope_append: null pointer");
+    BT_CHECK_ARG(pos0_dev || (pos0_host >= 0 && pos0_host + q_len <= n_max), "bt_qkv_rope_append: cache overflow");
+    const int64_t H = (int64_t)heads * head_dim;
+    const int64_t M = B * q_len;
+    QkvEpi q{};
+    q.kc = (bf16*)k_cache;
+    q.vc = (bf16*)v_cache;
+    q.n_max = n_max;
+    q.pos0_dev = pos0_dev;
+    q.pos_table = pos_table;
+    q.cos_tab = cos_tab;
+    q.sin_tab = sin_tab;
+    q.pos0_host = pos0_host;
+    q.q_len = q_len;
+    q.heads = heads;
+    q.head_dim = head_dim;
+    const bool fusable = dtype == BT_BF16 && rot == 32 && head_dim % 32 == 0 && ld_qkv % 4 == 0 &&
+                         (reinterpret_cast<uintptr_t>(k_cache) & 7u) == 0 && (reinterpret_cast<uintptr_t>(v_cache) & 7u) == 0 &&
+                         (reinterpret_cast<uintptr_t>(cos_tab) & 15u) == 0 && (reinterpret_cast<uintptr_t>(sin_tab) & 15u) == 0;
+    bool fused = false;
+    BT_TRY(linear_impl(dtype, M, 3 * H, H, x, ldx, qkv_w, qkv_b, nullptr, 0, qkv, ld_qkv, BT_ACT_NONE,
+                       fusable ? &q : nullptr, &fused, stream));
+    if (!fused)
+        BT_TRY(bt_rope_kv_append(dtype, B, q_len, heads, head_dim, rot, qkv, ld_qkv, k_cache, v_cache, n_max, pos0_dev,
+                                 pos0_host, pos_table, cos_tab, sin_tab, stream));
+    return BT_OK;
+}
+
 // test hook: force the generic kernel for bf16 (A/B checks of the MFMA kernel against the simple one)
 extern "C" void bt_debug_force_generic_gemm(int on) { g_force_generic = on != 0; }
 extern "C" void bt_debug_gemm_variant(int v) { g_gemm_variant = v; }
+extern "C" void bt_debug_no_qkv_fusion(int on) { g_no_qkv_fusion = on != 0; }

@@ -117,6 +117,16 @@ int bt_rope_kv_append(int dtype, int64_t B, int32_t q_len, int32_t heads, int32_
                       int32_t pos0_host, const int32_t* pos_table, const float* cos_tab, const float* sin_tab,
                       bt_stream stream);
 
+/* Fused form of the two calls above for the GPT-NeoX query_key_value projection of a layer:
+ *   qkv = x[M, H] . Wqkv[3H, H]^T + b ; RoPE on q (written to qkv, k/v columns of qkv are NOT written) and k ;
+ *   (k_rot, v) appended to the cache rows pos0 + t  —  RoPE and the append run in the GEMM epilogue (bf16, rot == 32,
+ *   head_dim % 32 == 0); any other configuration runs bt_linear + bt_rope_kv_append (then all of qkv is written).
+ * Replaces HF GPTNeoXAttention.query_key_value + apply_rotary_pos_emb + torch.cat cache growth (C3, C4, C5). */
+int bt_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim, int32_t rot, const void* x,
+                       int64_t ldx, const void* qkv_w, const void* qkv_b, void* qkv, int64_t ld_qkv, void* k_cache,
+                       void* v_cache, int64_t n_max, const int32_t* pos0_dev, int32_t pos0_host,
+                       const int32_t* pos_table, const float* cos_tab, const float* sin_tab, bt_stream stream);
+
 /* Causal softmax attention of q_len (already rotated) query rows per sequence over the cache:
  *   query t sees keys j <= pos0 + t with mask[b, j] != 0 (mask may be NULL);  out[b*q_len+t, head*d + :]
  * mode: 0 = row-wise streaming kernel (decode: q_len = 1 global step, or the token decoder's <= E+L-1 window);

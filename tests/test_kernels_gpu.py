@@ -222,6 +222,47 @@ def test_rope_kv_append(dtype, d, rot, use_dev_pos, use_table):
     assert kcc[:, :, :pos0].abs().max() == 0 and kcc[:, :, pos0 + q:].abs().max() == 0
 
 
+@pytest.mark.parametrize("B,q,pos0,heads", [(3, 1, 5, 2), (2, 7, 0, 2), (40, 2, 3, 16), (1, 300, 0, 4)])
+@pytest.mark.parametrize("use_dev_pos,use_table", [(False, False), (True, False), (False, True)])
+@pytest.mark.parametrize("fused", [True, False])
+def test_qkv_rope_append_fused_epilogue(B, q, pos0, heads, use_dev_pos, use_table, fused):
+    """QKV projection with RoPE + KV-cache append in the GEMM epilogue (d = 128, rot = 32) == fp64 reference, and ==
+    the unfused sequence bt_linear + bt_rope_kv_append within bf16 rounding."""
+    d, rot = 128, 32
+    H = heads * d
+    n_max = pos0 + q + 2
+    x = rnd(B * q, H, seed=1).bfloat16()
+    w = rnd(3 * H, H, seed=2, scale=H ** -0.5).bfloat16()
+    bias = rnd(3 * H, seed=3, scale=0.1).bfloat16()
+    tab = ops.rope_tables(1024, rot, 10000.0, DEV)
+    table = (torch.arange(n_max, dtype=torch.int32) * 3 % 17).to(DEV) if use_table else None
+    pos_dev = torch.tensor([pos0], dtype=torch.int32, device=DEV) if use_dev_pos else None
+    qkv = torch.full((B * q, 3 * H), float("nan"), dtype=torch.bfloat16, device=DEV)
+    kc = torch.zeros(B, heads, n_max, d, dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    xd, wd, bd = x.to(DEV), w.to(DEV), bias.to(DEV)
+    lib().bt_debug_no_qkv_fusion(0 if fused else 1)
+    try:
+        check(lib().bt_qkv_rope_append(_lib.BT_BF16, B, q, heads, d, rot, ptr(xd), H, ptr(wd), ptr(bd), ptr(qkv), 3 * H,
+                                       ptr(kc), ptr(vc), n_max, ptr(pos_dev), 0 if use_dev_pos else pos0, ptr(table),
+                                       ptr(tab[0]), ptr(tab[1]), current_stream()))
+        torch.cuda.synchronize()
+    finally:
+        lib().bt_debug_no_qkv_fusion(0)
+    ref = (x.double() @ w.double().T + bias.double()).view(B, q, heads, 3, d)
+    rows = torch.arange(pos0, pos0 + q)
+    rp = table.cpu()[rows].long() if use_table else rows
+    pos = rp.view(1, q, 1).expand(B, q, heads)
+    q_ref, k_ref, v_ref = rope_ref(ref[..., 0, :], pos, rot), rope_ref(ref[..., 1, :], pos, rot), ref[..., 2, :]
+    got_q = qkv.cpu().double().view(B, q, heads, 3, d)[..., 0, :]
+    assert rel_err(got_q, q_ref) <= 1.5e-2
+    assert rel_err(kc.cpu().double()[:, :, pos0:pos0 + q].permute(0, 2, 1, 3), k_ref) <= 1.5e-2
+    assert rel_err(vc.cpu().double()[:, :, pos0:pos0 + q].permute(0, 2, 1, 3), v_ref) <= 1.5e-2
+    assert float(kc.cpu()[:, :, :pos0].abs().sum()) == 0 and float(kc.cpu()[:, :, pos0 + q:].abs().sum()) == 0
+    if fused:   # the k / v columns of the qkv buffer are not written in fused mode (bandwidth saved)
+        assert torch.isnan(qkv.view(B * q, heads, 3, d)[:, :, 1:].float()).all()
+
+
 # ---- bt_attention -------------------------------------------------------------------------------------------------------------
 def attn_ref(qkv, kc, vc, B, q, heads, d, pos0, mask):
     """fp64 reference: query t sees keys j <= pos0+t with mask[b, j]; fully-masked rows -> 0."""

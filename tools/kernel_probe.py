@@ -134,8 +134,8 @@ def main():
                 res.append(r)
         lib().bt_debug_gemm_variant(0)
     elif args.what == "abl":
-        for (M, N, K) in ((32768, 6144, 2048), (32768, 2048, 8192)):
-            for v in (3, 9, 10, 6, 3, 9, 10, 6):
+        for (M, N, K) in ((32768, 6144, 2048), (32768, 2048, 8192), (32768, 2048, 2048)):
+            for v in (9, 11, 9, 11, 9, 11):
                 lib().bt_debug_gemm_variant(v)
                 r = probe_gemm(M, N, K, 10)
                 r["variant"] = v
