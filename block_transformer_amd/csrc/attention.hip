@@ -663,6 +663,11 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_v2_kernel(const bf16* __
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
+    // epilogue: normalise, stage the 128 x D output tile through LDS (K/V buffers are free now) and store whole rows with
+    // coalesced 16-byte accesses (a lane owns single bf16 values of 4 rows: direct stores would be 2 bytes per lane)
+    constexpr int OP = ROWB + 16;  // padded LDS pitch of the output tile
+    static_assert(FQ_ROWS * OP <= 4 * TILE_B, "output tile must fit in the K/V staging LDS");
+    __syncthreads();
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
         float l = lrun[f];
@@ -672,13 +677,20 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_v2_kernel(const bf16* __
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float a = __shfl(inv, g * 4 + r, 64);
-            const int row = qbase + f * 16 + g * 4 + r;
-            if (row < q_len) {
-                bf16* op = out + (b * q_len + row) * ldo + (int64_t)head * D + l15;
+            const int rl = wave * (QF * 16) + f * 16 + g * 4 + r;  // row inside the block's tile
+            uint16_t* orow = reinterpret_cast<uint16_t*>(smem + rl * OP) + l15;
 #pragma unroll
-                for (int d = 0; d < DF; ++d) op[d * 16].x = f32_to_bf16(oacc[f][d][r] * a);
-            }
+            for (int d = 0; d < DF; ++d) orow[d * 16] = f32_to_bf16(oacc[f][d][r] * a);
         }
+    }
+    __syncthreads();
+    constexpr int CPR = ROWB / 16;
+    for (int idx = tid; idx < FQ_ROWS * CPR; idx += 256) {
+        const int rl = idx / CPR, c = idx - rl * CPR;
+        const int row = qb * FQ_ROWS + rl;
+        if (row < q_len)
+            *reinterpret_cast<uint4*>(out + (b * q_len + row) * ldo + (int64_t)head * D + c * 8) =
+                *reinterpret_cast<const uint4*>(smem + rl * OP + c * 16);
     }
 }
 

@@ -47,18 +47,18 @@ __host__ __device__ inline float bf16_to_f32(uint16_t h) {
     return c.f;
 }
 
-// round-to-nearest-even, NaN preserved (same as torch's float -> bfloat16)
+// round-to-nearest-even, NaN preserved (same as torch's float -> bfloat16); branch-free (a divergent NaN branch per value
+// showed up as ~100 exec-mask save/restore pairs in the flash / GEMM epilogues)
 __host__ __device__ inline uint16_t f32_to_bf16(float f) {
     union {
         uint32_t u;
         float f;
     } c;
     c.f = f;
-    uint32_t u = c.u;
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);
-    uint32_t lsb = (u >> 16) & 1u;
-    u += 0x7fffu + lsb;
-    return (uint16_t)(u >> 16);
+    const uint32_t u = c.u;
+    const uint32_t rounded = (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    const uint32_t nan = (u >> 16) | 0x0040u;
+    return (uint16_t)(((u & 0x7fffffffu) > 0x7f800000u) ? nan : rounded);
 }
 
 template <typename T>
@@ -98,8 +98,11 @@ template <>
 __device__ inline void store_vec<float>(float* p, const float (&v)[4]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
+// two fp32 -> packed bf16x2 (RNE) in ONE instruction: gfx950 v_cvt_pk_bf16_f32 (no clang builtin; operands are VGPRs)
 __device__ inline uint32_t pack_bf16x2(float lo, float hi) {
-    return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
 }
 template <>
 __device__ inline void store_vec<bf16>(bf16* p, const float (&v)[8]) {

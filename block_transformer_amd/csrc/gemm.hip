@@ -140,6 +140,115 @@ __device__ inline void epilogue_pair(const EpiArgs& e, int m, int n_lo, const f3
     }
 }
 
+// ---- LDS-staged epilogue (MFMA kernels) -----------------------------------------------------------------------------------
+// The accumulator layout gives a lane 4 consecutive columns of one row: storing from registers is 8 bytes per lane in
+// 32-byte row segments, which the memory system handles at < 2 TB/s (measured: 28 % of a K = 2048 GEMM).  Instead the
+// block's output tile goes through LDS (free after the K-loop): phase 1 writes bf16(acc + bias [GELU] [RoPE]) into a padded
+// row-major tile, phase 2 reads it back 16 bytes per lane along rows and issues fully coalesced 16-byte global stores
+// (adding the residual on the way; QKV mode scatters k / v chunks to the cache rows instead).
+template <int COLS>
+struct CTile {
+    static constexpr int PITCH = COLS * 2 + 16;  // bytes; +16 breaks the power-of-two row stride (ds_write_b64 conflicts)
+};
+
+template <int COLS>
+__device__ inline void epi_to_lds(const EpiArgs& e, char* ctile, int ml, int nl, int m, int n_lo, const f32x4_t& a_lo,
+                                  const f32x4_t& a_hi) {
+    float lo[4] = {a_lo[0], a_lo[1], a_lo[2], a_lo[3]};
+    float hi[4] = {a_hi[0], a_hi[1], a_hi[2], a_hi[3]};
+    if (e.bias) {
+        if (n_lo < e.N) {
+            const uint2 b2 = *reinterpret_cast<const uint2*>(e.bias + n_lo);
+            lo[0] += __uint_as_float(b2.x << 16); lo[1] += __uint_as_float(b2.x & 0xffff0000u);
+            lo[2] += __uint_as_float(b2.y << 16); lo[3] += __uint_as_float(b2.y & 0xffff0000u);
+        }
+        if (n_lo + 16 < e.N) {
+            const uint2 b3 = *reinterpret_cast<const uint2*>(e.bias + n_lo + 16);
+            hi[0] += __uint_as_float(b3.x << 16); hi[1] += __uint_as_float(b3.x & 0xffff0000u);
+            hi[2] += __uint_as_float(b3.y << 16); hi[3] += __uint_as_float(b3.y & 0xffff0000u);
+        }
+    }
+    if (e.act == BT_ACT_GELU) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            lo[r] = gelu_erf(lo[r]);
+            hi[r] = gelu_erf(hi[r]);
+        }
+    }
+    if (e.q.enabled && m < e.M) {
+        const int D = e.q.head_dim;
+        const int head = n_lo / (3 * D);
+        const int within = n_lo - head * 3 * D;
+        const int part = within / D;
+        const int el = within - part * D;
+        if (part < 2 && el < 16) {
+            const int64_t b = m / e.q.q_len;
+            const int t = m - (int)b * e.q.q_len;
+            const int pos0 = e.q.pos0_dev ? *e.q.pos0_dev : e.q.pos0_host;
+            const int rpos = e.q.pos_table ? e.q.pos_table[pos0 + t] : pos0 + t;
+            const float4 c4 = *reinterpret_cast<const float4*>(e.q.cos_tab + (int64_t)rpos * 16 + el);
+            const float4 s4 = *reinterpret_cast<const float4*>(e.q.sin_tab + (int64_t)rpos * 16 + el);
+            const float c[4] = {c4.x, c4.y, c4.z, c4.w}, sn[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x1 = lo[r], x2 = hi[r];
+                lo[r] = x1 * c[r] - x2 * sn[r];
+                hi[r] = x2 * c[r] + x1 * sn[r];
+            }
+        }
+    }
+    uint2 o_lo, o_hi;
+    o_lo.x = pack_bf16x2(lo[0], lo[1]); o_lo.y = pack_bf16x2(lo[2], lo[3]);
+    o_hi.x = pack_bf16x2(hi[0], hi[1]); o_hi.y = pack_bf16x2(hi[2], hi[3]);
+    char* p = ctile + ml * CTile<COLS>::PITCH + nl * 2;
+    *reinterpret_cast<uint2*>(p) = o_lo;
+    *reinterpret_cast<uint2*>(p + 32) = o_hi;
+}
+
+__device__ inline uint4 add_bf16x8(uint4 a, uint4 b) {
+    uint4 r;
+    r.x = pack_bf16x2(__uint_as_float(a.x << 16) + __uint_as_float(b.x << 16),
+                      __uint_as_float(a.x & 0xffff0000u) + __uint_as_float(b.x & 0xffff0000u));
+    r.y = pack_bf16x2(__uint_as_float(a.y << 16) + __uint_as_float(b.y << 16),
+                      __uint_as_float(a.y & 0xffff0000u) + __uint_as_float(b.y & 0xffff0000u));
+    r.z = pack_bf16x2(__uint_as_float(a.z << 16) + __uint_as_float(b.z << 16),
+                      __uint_as_float(a.z & 0xffff0000u) + __uint_as_float(b.z & 0xffff0000u));
+    r.w = pack_bf16x2(__uint_as_float(a.w << 16) + __uint_as_float(b.w << 16),
+                      __uint_as_float(a.w & 0xffff0000u) + __uint_as_float(b.w & 0xffff0000u));
+    return r;
+}
+
+// phase 2: ROWS x COLS tile (bf16, padded pitch) -> global, 16 bytes per lane along rows.  Requires N % 8 == 0.
+template <int ROWS, int COLS, int NT>
+__device__ inline void store_tile_from_lds(const EpiArgs& e, const char* ctile, int m0, int n0, int tid) {
+    constexpr int CPR = COLS / 8;
+    for (int idx = tid; idx < ROWS * CPR; idx += NT) {
+        const int r = idx / CPR, c = idx - r * CPR;
+        const int m = m0 + r, n = n0 + c * 8;
+        if (m >= e.M || n >= e.N) continue;
+        uint4 v = *reinterpret_cast<const uint4*>(ctile + r * CTile<COLS>::PITCH + c * 16);
+        if (!e.q.enabled) {
+            if (e.res) v = add_bf16x8(v, *reinterpret_cast<const uint4*>(e.res + (int64_t)m * e.ldr + n));
+            *reinterpret_cast<uint4*>(e.out + (int64_t)m * e.ldo + n) = v;
+        } else {
+            const int D = e.q.head_dim;
+            const int head = n / (3 * D);
+            const int within = n - head * 3 * D;
+            const int part = within / D;
+            const int el = within - part * D;
+            if (part == 0) {
+                *reinterpret_cast<uint4*>(e.out + (int64_t)m * e.ldo + n) = v;
+            } else {
+                const int64_t b = m / e.q.q_len;
+                const int t = m - (int)b * e.q.q_len;
+                const int pos0 = e.q.pos0_dev ? *e.q.pos0_dev : e.q.pos0_host;
+                bf16* cache = part == 1 ? e.q.kc : e.q.vc;
+                *reinterpret_cast<uint4*>(cache + ((b * e.q.heads + head) * e.q.n_max + pos0 + t) * D + el) = v;
+            }
+        }
+    }
+}
+
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int GROUP_M = 8;
 
@@ -236,6 +345,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restr
     }
 
     // epilogue: D[i = n][j = m]; lane holds column m = lane & 15 and rows n = (lane >> 4) * 4 + r
+    if ((N & 7) == 0) {
+        // the last K-step ended with vmcnt(0) + barrier: every DMA has landed and every ds_read is done -> LDS is free
+        static_assert(TBM * CTile<TBN>::PITCH <= 2 * STAGE, "output tile must fit in the staging LDS");
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int ml = wm * (TBM / 2) + j * 16 + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < FN; i += 2) {
+                const int nl = wn * (TBN / 2) + i * 16 + (lane >> 4) * 4;
+                epi_to_lds<TBN>(ep, smem, ml, nl, m0 + ml, n0 + nl, acc[i][j], acc[i + 1][j]);
+            }
+        }
+        __syncthreads();
+        store_tile_from_lds<TBM, TBN, 256>(ep, smem, m0, n0, tid);
+        return;
+    }
     const bool vec_ok = ((N & 3) == 0);
 #pragma unroll
     for (int j = 0; j < FM; ++j) {
@@ -334,7 +459,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256_kernel(const bf16* __re
                                                                const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
                                                                int K, int tiles_m, int tiles_n) {
     const int M = ep.M, N = ep.N;
-    __shared__ __attribute__((aligned(16))) char smem[8 * HALF_BYTES];  // 128 KiB
+    // 128 KiB ring; the epilogue reuses it as a padded 256 x 256 bf16 output tile (132 KiB)
+    __shared__ __attribute__((aligned(16))) char smem[BM2 * CTile<BN2>::PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const bool grp1 = STAGGER && (__builtin_amdgcn_readfirstlane(tid >> 8) != 0);
@@ -442,6 +568,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256_kernel(const bf16* __re
     }
     if (STAGGER && !grp1) cbarrier();
 
+    if ((N & 7) == 0) {
+        __syncthreads();  // all waves are past their last ds_reads; every DMA was waited for (vmcnt(0) in the tail phases)
+#pragma unroll
+        for (int ai = 0; ai < 8; ++ai) {
+            const int ml = (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16 + (lane & 15);
+#pragma unroll
+            for (int wh = 0; wh < 2; ++wh) {
+                const int nl = wh * 128 + wn * 32 + (lane >> 4) * 4;
+                epi_to_lds<BN2>(ep, smem, ml, nl, m0 + ml, n0 + nl, acc[ai][wh * 2], acc[ai][wh * 2 + 1]);
+            }
+        }
+        __syncthreads();
+        store_tile_from_lds<BM2, BN2, 512>(ep, smem, m0, n0, tid);
+        return;
+    }
 #pragma unroll
     for (int ai = 0; ai < 8; ++ai) {
         const int m = m0 + (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16 + (lane & 15);
@@ -482,7 +623,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256p2_kernel(const bf16* __
                                                                  const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
                                                                  int K, int tiles_m, int tiles_n) {
     const int M = ep.M, N = ep.N;
-    __shared__ __attribute__((aligned(16))) char smem[8 * HALF_BYTES];  // 128 KiB
+    // 128 KiB ring; the epilogue reuses it as a padded 256 x 256 bf16 output tile (132 KiB)
+    __shared__ __attribute__((aligned(16))) char smem[BM2 * CTile<BN2>::PITCH];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const bool grp1 = STAGGER && (__builtin_amdgcn_readfirstlane(tid >> 8) != 0);
@@ -584,6 +726,21 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256p2_kernel(const bf16* __
         return;
     }
 
+    if ((N & 7) == 0) {
+        __syncthreads();  // all waves are past their last ds_reads; every DMA was waited for (vmcnt(0) in the tail phases)
+#pragma unroll
+        for (int ai = 0; ai < 8; ++ai) {
+            const int ml = (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16 + (lane & 15);
+#pragma unroll
+            for (int wh = 0; wh < 2; ++wh) {
+                const int nl = wh * 128 + wn * 32 + (lane >> 4) * 4;
+                epi_to_lds<BN2>(ep, smem, ml, nl, m0 + ml, n0 + nl, acc[ai][wh * 2], acc[ai][wh * 2 + 1]);
+            }
+        }
+        __syncthreads();
+        store_tile_from_lds<BM2, BN2, 512>(ep, smem, m0, n0, tid);
+        return;
+    }
 #pragma unroll
     for (int ai = 0; ai < 8; ++ai) {
         const int m = m0 + (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16 + (lane & 15);

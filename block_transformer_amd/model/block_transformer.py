@@ -193,9 +193,63 @@ class BlockTransformer(nn.Module):
                                                          last_block_unfilled_length=block_length - next_token_count)
         return out
 
-    def forward(self, *args, **kwargs):
-        raise NotImplementedError("BlockTransformer.forward (training / scoring path, reference :50-225) is listed as "
-                                  "'next' in SURVEY.md section 8(f) rank 4 and is not part of the decode hot path yet")
+    @torch.inference_mode()
+    def forward(self, input_ids: torch.LongTensor, attention_mask: torch.LongTensor,
+                block_attention_mask: torch.LongTensor, labels=None, skip_padding_blocks: bool = True):
+        """Scoring path (reference :50-225, inference use: lm_eval wrappers and util/perplexity.py): teacher-forced logits
+        ``[B, n_blocks-1, L, V]`` where the context embedding of block i decodes block i+1.
+
+        input_ids / attention_mask ``[B, nb, L]``, block_attention_mask ``[B, nb]`` (see the reference docstring for the
+        padding conventions).  Losses (``labels``) are training-only and not implemented.  With
+        ``skip_padding_blocks`` the fully padded blocks are not computed and their logits are filled with
+        ``eos_token_id`` exactly like the reference (:200-205)."""
+        if labels is not None:
+            raise NotImplementedError("losses are training-only (out of the decode path); call forward(labels=None)")
+        input_ids = input_ids.view((-1,) + input_ids.shape[-2:])
+        attention_mask = attention_mask.view((-1,) + attention_mask.shape[-2:])
+        block_attention_mask = block_attention_mask.view(-1, block_attention_mask.shape[-1])
+        batch_size, n_blocks, block_length = input_ids.shape
+        if block_attention_mask.shape != (batch_size, n_blocks):
+            raise ValueError("block_attention_mask must have shape (batch_size, n_blocks)"
+                             f"expected: {(batch_size, n_blocks)}, got: {block_attention_mask.shape}")
+        if n_blocks < 2:
+            raise ValueError("forward() needs at least two blocks (block i's context decodes block i+1)")
+        td_cfg = self.token_decoder.config
+        # EMBEDDING + BLOCK DECODING (all positions)
+        input_embeds = self.embedder(input_ids=input_ids.reshape(-1, block_length),
+                                     attention_mask=attention_mask.reshape(-1, block_length))
+        input_embeds = input_embeds.view(batch_size, n_blocks * self.n_embedding_tokens, input_embeds.shape[-1])
+        hidden = self.block_decoder(inputs_embeds=input_embeds, block_attention_mask=block_attention_mask,
+                                    return_dict=True).hidden_states
+        # TOKEN DECODING: shift blocks left, drop the last block's context
+        tok = input_ids[:, 1:, :].reshape(-1, block_length)
+        tmask = attention_mask[:, 1:, :].reshape(-1, block_length)
+        bmask = block_attention_mask[:, 1:].reshape(-1)
+        block_embeddings = hidden[:, :-self.n_embedding_tokens, :].reshape(-1, self.n_embedding_tokens,
+                                                                          self.projection_hidden_size)
+        keep = None
+        if skip_padding_blocks:
+            keep = bmask.bool()
+            tok, tmask, block_embeddings = tok[keep], tmask[keep], block_embeddings[keep].contiguous()
+        local_bs = tok.shape[0]
+        vocab = td_cfg.vocab_size
+        logits_shape = (batch_size * (n_blocks - 1), block_length, vocab)
+        if local_bs > 0:
+            prefix = tok.new_full((local_bs, 1), td_cfg.bos_token_id)
+            td_ids = torch.cat([prefix, tok], dim=1)
+            td_mask = torch.cat([tmask.new_full((local_bs, 1), 1), tmask], dim=1)
+            td_logits = self.token_decoder(input_ids=td_ids, attention_mask=td_mask, block_embeddings=block_embeddings,
+                                           discard_redundant_tokens=True).logits
+        if keep is not None:
+            logits = hidden.new_full(logits_shape, fill_value=td_cfg.eos_token_id)
+            if local_bs > 0:
+                logits[keep] = td_logits
+        else:
+            logits = td_logits.view(logits_shape)
+        logits = logits.view(batch_size, n_blocks - 1, block_length, vocab)
+        self.loss = self.token_decoding_loss = self.block_decoding_loss = self.auto_encoding_loss = None
+        return {"logits": logits, "loss": None, "block_decoding_loss": None, "token_decoding_loss": None,
+                "auto_encoding_loss": None}
 
 
 class _BlockStreamer:

@@ -326,3 +326,70 @@ def test_fp32_logits_within_1e3_of_reference_real_head_dim(gpu_model):
     tin = torch.cat([torch.zeros(ctx.shape[0], 1, dtype=torch.long, device=DEV), toks], dim=1)
     lg = model.token_decoder(input_ids=tin, block_embeddings=ctx[:, None, :]).logits
     assert maxabs(lg, t(fx, "g5_logits")) <= TOL
+
+
+@pytest.mark.parametrize("name", GOLDEN_CONFIGS)
+def test_forward_scoring_path_g7(gpu_model, name):
+    """BlockTransformer.forward (teacher-forced logits [B, nb-1, L, V]) against the reference's own forward (G7):
+    pins the block-shift alignment 'context of block i decodes block i+1'."""
+    model, dims, sd, fx = gpu_model(name)
+    ids = t(fx, "g1_ids").to(DEV)
+    B, nb, L = ids.shape
+    out = model(input_ids=ids, attention_mask=torch.ones_like(ids),
+                block_attention_mask=torch.ones(B, nb, dtype=torch.long, device=DEV))
+    lg = out["logits"].cpu()
+    assert lg.shape == (B, nb - 1, L, dims.vocab) and out["loss"] is None
+    if "g7_logits" in fx:
+        assert maxabs(lg, t(fx, "g7_logits")) <= TOL
+        assert maxabs(lg, t(fx, "g7_logits")) <= TIGHT
+    else:
+        assert maxabs(lg[..., ::97], t(fx, "g7_logits_slice")) <= TOL
+        assert torch.equal(lg.argmax(-1), t(fx, "g7_logits_argmax"))
+
+
+def test_forward_scoring_path_padding_semantics(gpu_model):
+    """Right-padded batch (reference docstring, block_transformer.py:58-82): fully padded blocks are skipped and filled
+    with eos_token_id, logits after the last content token of a block are zero, content logits match the oracle."""
+    model, dims, sd, fx = gpu_model("micro")
+    ids = t(fx, "g1_ids").clone()
+    B, nb, L = ids.shape
+    am = torch.ones_like(ids)
+    am[1, 3, 2:] = 0      # block 3 of row 1 ends after 2 tokens (partial EOS block)
+    am[1, 4, :] = 0       # block 4 of row 1 is pure padding
+    ids[am == 0] = 0      # pad id == eos id == 0
+    bm = am.any(-1).long()
+    out = model(input_ids=ids.to(DEV), attention_mask=am.to(DEV), block_attention_mask=bm.to(DEV))["logits"].cpu()
+    o = oracle_from_dims(dims, sd)
+    ref = o.forward_logits(ids, am, bm)
+    assert out.shape == ref.shape
+    assert torch.all(out[1, 3] == model.token_decoder.config.eos_token_id)        # skipped padding block (index nb-2)
+    # block 3 of row 1 (decoded from context 2): inputs [BOS, a, b | pad pad] -> logits for a^, b^ (+ the position that
+    # predicts the token after b, which the reference keeps because attention_mask marks b as content) ; rest zero
+    assert maxabs(out[1, 2, :2], ref[1, 2, :2]) <= TIGHT
+    assert float(out[1, 2, 3].abs().max()) == 0.0
+    assert maxabs(out[0], ref[0]) <= TIGHT and maxabs(out[1, :2], ref[1, :2]) <= TIGHT
+    with pytest.raises(NotImplementedError):
+        model(input_ids=ids.to(DEV), attention_mask=am.to(DEV), block_attention_mask=bm.to(DEV), labels=ids.to(DEV))
+
+
+def test_checkpoint_roundtrip_safetensors(gpu_model, tmp_path):
+    """results/<name>/checkpoint-N/model.safetensors with the reference key names loads into the MI355X modules (the
+    newest checkpoint wins, the unused block_decoder embed_in may be absent) and reproduces the golden tokens."""
+    from safetensors.torch import save_file
+    from block_transformer_amd import inference_demo as demo
+    model, dims, sd, fx = gpu_model("micro")
+    root = tmp_path / "ckpts" / "micro"
+    for step, scale in ((100, 0.5), (2500, 1.0)):
+        d = root / f"checkpoint-{step}"
+        d.mkdir(parents=True)
+        save_file({k: (v * scale).contiguous() for k, v in sd.items() if k != "block_decoder.gpt_neox.embed_in.weight"},
+                  str(d / "model.safetensors"))
+    assert demo.get_checkpoint_path("micro", str(tmp_path / "ckpts")).endswith("checkpoint-2500/model.safetensors")
+    from safetensors.torch import load_file
+    fresh = load_block_transformer_from_dims(dims, "fp32").to(DEV)
+    missing, unexpected = fresh.load_state_dict(load_file(demo.get_checkpoint_path("micro", str(tmp_path / "ckpts")),
+                                                          device=DEV), strict=False)
+    assert missing == ["block_decoder.gpt_neox.embed_in.weight"] and not unexpected
+    fresh.token_decoder.generation_config.eos_token_id = None
+    out = fresh.generate(t(fx, "g6_1_prompt").to(DEV), max_length=16)
+    assert torch.equal(out.cpu(), t(fx, "g6_1_tokens"))
