@@ -46,6 +46,8 @@ _SIGS = {
     "bt_decoder_workspace_bytes": (c_int64, [POINTER(bt_decoder_dims), c_int, c_int64]),
     "bt_linear": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                           c_void_p, c_int64, c_int, c_void_p]),
+    "bt_linear_ws": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
+                             c_void_p, c_int64, c_int, c_void_p, c_int64, c_void_p]),
     "bt_layernorm": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int64,
                              c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p]),
     "bt_embed_rows": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_void_p, c_int64,
@@ -54,7 +56,7 @@ _SIGS = {
                                   c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
     "bt_qkv_rope_append": (c_int, [c_int, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_void_p,
                                    c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int32, c_void_p, c_void_p,
-                                   c_void_p, c_void_p]),
+                                   c_void_p, c_void_p, c_int64, c_void_p]),
     "bt_attention": (c_int, [c_int, c_int, c_int64, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_void_p,
                              c_int64, c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p,
                              c_int64, c_void_p]),

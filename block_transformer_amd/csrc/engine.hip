@@ -14,10 +14,14 @@ using namespace bt;
 static int64_t ws_elems(const bt_decoder_dims* d, int64_t M) {
     return M * ((int64_t)d->hidden * 5 + d->inter);
 }
+// split-K scratch for skinny GEMMs (M <= 256 rows): up to 16 fp32 partial slabs of [M, inter]
+static int64_t splitk_bytes(const bt_decoder_dims* d, int64_t M) {
+    return M <= 256 ? 16 * M * (int64_t)d->inter * 4 : 0;
+}
 
 extern "C" int64_t bt_decoder_workspace_bytes(const bt_decoder_dims* dims, int dtype, int64_t M) {
     if (!dims || M < 0) return -1;
-    return ws_elems(dims, M) * (int64_t)dtype_size(dtype) + 256;
+    return ws_elems(dims, M) * (int64_t)dtype_size(dtype) + splitk_bytes(dims, M) + 512;
 }
 
 extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const bt_decoder_weights* w, int64_t B,
@@ -34,7 +38,7 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
     // 256-byte align the workspace base
     uintptr_t base = (reinterpret_cast<uintptr_t>(ws) + 255u) & ~(uintptr_t)255u;
     const int64_t avail = ws_bytes - (int64_t)(base - reinterpret_cast<uintptr_t>(ws));
-    if (avail < ws_elems(dims, M) * (int64_t)es) {
+    if (avail < ws_elems(dims, M) * (int64_t)es + splitk_bytes(dims, M) + 256) {
         set_error("bt_decoder_forward: workspace too small: %lld bytes for M=%lld (need %lld)", (long long)ws_bytes,
                   (long long)M, (long long)bt_decoder_workspace_bytes(dims, dtype, M));
         return BT_ERR_WORKSPACE;
@@ -45,6 +49,9 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
     void* qkv = p + 2 * M * H * es;
     void* h4 = p + 5 * M * H * es;
     void* att = ln1;
+    char* sk = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p + ws_elems(dims, M) * es) + 255u) & ~(uintptr_t)255u);
+    const int64_t sk_bytes = splitk_bytes(dims, M);
+    void* scratch = sk_bytes ? sk : nullptr;
 
     // When the caller consumes only the LAST row of every sequence (prefill -> context embedding; token-decoder step 0),
     // the last layer's attention output / dense / MLP are needed for that row alone: the other rows of that layer only
@@ -68,14 +75,14 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
         }
         BT_TRY(bt_qkv_rope_append(dtype, B, q_len, dims->heads, dims->head_dim, dims->rot, ln1, H, lw.qkv_w, lw.qkv_b, qkv,
                                   3 * H, kc, vc, attn->n_max, attn->pos0_dev, attn->pos0_host, attn->pos_table,
-                                  attn->cos_tab, attn->sin_tab, stream));
+                                  attn->cos_tab, attn->sin_tab, scratch, sk_bytes, stream));
         if (!last) {
             BT_TRY(bt_attention(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc,
                                 attn->n_max, attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H,
                                 attn->n_split, attn->split_ws, attn->split_ws_bytes, stream));
-            BT_TRY(bt_linear(dtype, M, H, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, BT_ACT_NONE, stream));
-            BT_TRY(bt_linear(dtype, M, I, H, ln2, H, lw.h4_w, lw.h4_b, nullptr, 0, h4, I, BT_ACT_GELU, stream));
-            BT_TRY(bt_linear(dtype, M, H, I, h4, I, lw.h_w, lw.h_b, x, H, x, H, BT_ACT_NONE, stream));
+            BT_TRY(bt_linear_ws(dtype, M, H, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, BT_ACT_NONE, scratch, sk_bytes, stream));
+            BT_TRY(bt_linear_ws(dtype, M, I, H, ln2, H, lw.h4_w, lw.h4_b, nullptr, 0, h4, I, BT_ACT_GELU, scratch, sk_bytes, stream));
+            BT_TRY(bt_linear_ws(dtype, M, H, I, h4, I, lw.h_w, lw.h_b, x, H, x, H, BT_ACT_NONE, scratch, sk_bytes, stream));
         } else {
             // one query row per sequence: row (q_len - 1) at cache position pos0 + q_len - 1; row-wise kernel, q_len = 1
             const char* ql = reinterpret_cast<const char*>(qkv) + (int64_t)(q_len - 1) * 3 * H * es;
@@ -88,18 +95,18 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
                                     attn->n_max, attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H,
                                     attn->n_split, attn->split_ws, attn->split_ws_bytes, stream));
                 const char* al = reinterpret_cast<const char*>(att) + (int64_t)(q_len - 1) * H * es;
-                BT_TRY(bt_linear(dtype, B, H, H, al, (int64_t)q_len * H, lw.dense_w, lw.dense_b, xl, (int64_t)q_len * H,
-                                 xl, (int64_t)q_len * H, BT_ACT_NONE, stream));
+                BT_TRY(bt_linear_ws(dtype, B, H, H, al, (int64_t)q_len * H, lw.dense_w, lw.dense_b, xl, (int64_t)q_len * H,
+                                    xl, (int64_t)q_len * H, BT_ACT_NONE, scratch, sk_bytes, stream));
             } else {
                 BT_TRY(bt_attention(dtype, 0, B, 1, dims->heads, dims->head_dim, ql, (int64_t)q_len * 3 * H, kc, vc,
                                     attn->n_max, nullptr, attn->pos0_host + q_len - 1, attn->mask, attn->mask_ld, att, H,
                                     split, attn->split_ws, attn->split_ws_bytes, stream));
-                BT_TRY(bt_linear(dtype, B, H, H, att, H, lw.dense_w, lw.dense_b, xl, (int64_t)q_len * H, xl,
-                                 (int64_t)q_len * H, BT_ACT_NONE, stream));
+                BT_TRY(bt_linear_ws(dtype, B, H, H, att, H, lw.dense_w, lw.dense_b, xl, (int64_t)q_len * H, xl,
+                                    (int64_t)q_len * H, BT_ACT_NONE, scratch, sk_bytes, stream));
             }
-            BT_TRY(bt_linear(dtype, B, I, H, ln2, H, lw.h4_w, lw.h4_b, nullptr, 0, h4, I, BT_ACT_GELU, stream));
-            BT_TRY(bt_linear(dtype, B, H, I, h4, I, lw.h_w, lw.h_b, xl, (int64_t)q_len * H, xl, (int64_t)q_len * H,
-                             BT_ACT_NONE, stream));
+            BT_TRY(bt_linear_ws(dtype, B, I, H, ln2, H, lw.h4_w, lw.h4_b, nullptr, 0, h4, I, BT_ACT_GELU, scratch, sk_bytes, stream));
+            BT_TRY(bt_linear_ws(dtype, B, H, I, h4, I, lw.h_w, lw.h_b, xl, (int64_t)q_len * H, xl, (int64_t)q_len * H,
+                                BT_ACT_NONE, scratch, sk_bytes, stream));
         }
     }
     // final_layer_norm of the rows the caller consumes

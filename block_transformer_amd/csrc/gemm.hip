@@ -292,10 +292,14 @@ __device__ inline bf16x8_t read_frag(const char* lds_tile, int row_base, int kk,
 }
 
 // TBM x TBN x 64 tile, 4 waves (2 x 2); 128x128 for full grids, 128x64 / 64x64 when the grid would not fill 256 CUs
-template <int TBM, int TBN>
+// SPLITK: blockIdx.y selects a K slice; the fp32 partial tile goes to `partial[slice][M][N]` and splitk_reduce_kernel
+// applies the epilogue.  This is the weight-streaming ("skinny") regime: M <= ~256 rows, where one pass over W is the cost
+// and a tile-per-CU grid would leave most CUs idle (M=1, N=2048, K=8192: 32 tiles -> 256 workgroups with 8 slices).
+template <int TBM, int TBN, bool SPLITK = false>
 __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restrict__ A, int64_t lda,
                                                             const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
-                                                            int K, int tiles_m, int tiles_n) {
+                                                            int K, int tiles_m, int tiles_n,
+                                                            float* __restrict__ partial = nullptr) {
     const int M = ep.M, N = ep.N;
     constexpr int A_BYTES = TBM * BK * 2, W_BYTES = TBN * BK * 2, STAGE = A_BYTES + W_BYTES;
     constexpr int FM = TBM / 32, FN = TBN / 32;  // 16x16 fragments per wave along m / n
@@ -305,6 +309,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restr
     int tm, tn;
     tile_coords(tiles_m, tiles_n, tm, tn);
     const int m0 = tm * TBM, n0 = tn * TBN;
+    if (SPLITK) {  // this workgroup's K slice (K here is the slice length; the operands are advanced to the slice start)
+        A += (int64_t)blockIdx.y * K;
+        W += (int64_t)blockIdx.y * K;
+    }
 
     f32x4_t acc[FN][FM];
 #pragma unroll
@@ -344,6 +352,20 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restr
         __syncthreads();
     }
 
+    if (SPLITK) {  // fp32 partials: lane owns 4 consecutive columns of one row -> one 16-byte store per fragment
+        float* slab = partial + (int64_t)blockIdx.y * M * N;
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int m = m0 + wm * (TBM / 2) + j * 16 + (lane & 15);
+            if (m >= M) continue;
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                const int n = n0 + wn * (TBN / 2) + i * 16 + (lane >> 4) * 4;
+                if (n < N) *reinterpret_cast<f32x4_t*>(slab + (int64_t)m * N + n) = acc[i][j];
+            }
+        }
+        return;
+    }
     // epilogue: D[i = n][j = m]; lane holds column m = lane & 15 and rows n = (lane >> 4) * 4 + r
     if ((N & 7) == 0) {
         // the last K-step ended with vmcnt(0) + barrier: every DMA has landed and every ds_read is done -> LDS is free
@@ -371,6 +393,39 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restr
             epilogue_pair(ep, m, n, acc[i][j], acc[i + 1][j], vec_ok);
         }
     }
+}
+
+// sum the K-slice partials and apply the shared epilogue (bias, GELU, residual): 8 columns per thread, 16-byte accesses
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int slices, const EpiArgs ep) {
+    const int M = ep.M, N = ep.N;
+    const int cpr = N / 8;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)M * cpr) return;
+    const int m = (int)(idx / cpr), n = (int)(idx - (int64_t)m * cpr) * 8;
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < slices; ++s) {
+        const float* p = partial + ((int64_t)s * M + m) * N + n;
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+        v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+    if (ep.bias) {
+        float bv[8];
+        load_vec<bf16>(ep.bias + n, bv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += bv[i];
+    }
+    if (ep.act == BT_ACT_GELU) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = gelu_erf(v[i]);
+    }
+    if (ep.res) {
+        float rv[8];
+        load_vec<bf16>(ep.res + (int64_t)m * ep.ldr + n, rv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += rv[i];
+    }
+    store_vec<bf16>(ep.out + (int64_t)m * ep.ldo + n, v);
 }
 
 // ---- 256x256 deep-pipelined kernel ---------------------------------------------------------------------------------------
@@ -824,7 +879,8 @@ using namespace bt;
 
 static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* W,
                        const void* bias, const void* residual, int64_t ldr, void* out, int64_t ldo, int act,
-                       const QkvEpi* qkv, bool* fused_out, bt_stream stream) {
+                       const QkvEpi* qkv, bool* fused_out, bt_stream stream, void* scratch = nullptr,
+                       int64_t scratch_bytes = 0) {
     BT_CHECK_ARG(dtype == BT_F32 || dtype == BT_BF16, "bt_linear: bad dtype %d", dtype);
     BT_CHECK_ARG(M >= 0 && N > 0 && K > 0, "bt_linear: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N,
                  (long long)K);
@@ -880,6 +936,28 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                 default: BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<true>)); break;  // production (also variant 9)
             }
 #undef BT_LAUNCH_256
+        } else if (mfma_ok && scratch && !ep.q.enabled && g_gemm_variant != 1 && (N % 8 == 0) && (ldo % 8 == 0) &&
+                   aligned16(out) && (!residual || (ldr % 8 == 0 && aligned16(residual))) && (!bias || aligned16(bias)) &&
+                   aligned16(scratch) && ceil_div(M, 64) * ceil_div(N, 64) < 256) {
+            // skinny regime: even 64x64 tiles leave CUs idle -> split K until >= ~256 workgroups stream W concurrently
+            ProfScope ps(BT_PROF_LINEAR_MFMA, s);
+            const int tiles_m = (int)ceil_div(M, 64), tiles_n = (int)ceil_div(N, 64);
+            const int nk = (int)(K / BK);
+            int slices = 1;
+            while (slices < 16 && tiles_m * tiles_n * slices < 256 && nk % (slices * 2) == 0 && nk / (slices * 2) >= 2 &&
+                   (int64_t)(slices * 2) * M * N * 4 <= scratch_bytes)
+                slices *= 2;
+            if (slices > 1) {
+                hipLaunchKernelGGL((gemm_bf16_mfma_kernel<64, 64, true>), dim3(tiles_m * tiles_n, slices), dim3(256), 0, s,
+                                   (const bf16*)A, lda, (const bf16*)W, K, ep, (int)(K / slices), tiles_m, tiles_n,
+                                   (float*)scratch);
+                BT_LAUNCH_CHECK("bt_linear split-K launch");
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div(M * (N / 8), 256)), dim3(256), 0, s,
+                                   (const float*)scratch, slices, ep);
+            } else {
+                hipLaunchKernelGGL((gemm_bf16_mfma_kernel<64, 64, false>), dim3(tiles_m * tiles_n), dim3(256), 0, s,
+                                   (const bf16*)A, lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n, nullptr);
+            }
         } else if (mfma_ok) {
             ProfScope ps(BT_PROF_LINEAR_MFMA, s);
             // pick the largest tile that still gives every CU a workgroup (256 CUs): 128x128 -> 128x64 -> 64x64
@@ -891,8 +969,8 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
             const int tiles_m = (int)ceil_div(M, tbm), tiles_n = (int)ceil_div(N, tbn);
             BT_CHECK_ARG((int64_t)tiles_m * tiles_n < (1ll << 31), "bt_linear: grid too large");
 #define BT_LAUNCH_GEMM(TM_, TN_)                                                                                        \
-    hipLaunchKernelGGL((gemm_bf16_mfma_kernel<TM_, TN_>), dim3(tiles_m * tiles_n), dim3(256), 0, s, (const bf16*)A, lda, \
-                       (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n)
+    hipLaunchKernelGGL((gemm_bf16_mfma_kernel<TM_, TN_, false>), dim3(tiles_m * tiles_n), dim3(256), 0, s, (const bf16*)A, \
+                       lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n, nullptr)
             if (tbm == 128 && tbn == 128) BT_LAUNCH_GEMM(128, 128);
             else if (tbm == 128) BT_LAUNCH_GEMM(128, 64);
             else BT_LAUNCH_GEMM(64, 64);
@@ -923,11 +1001,18 @@ extern "C" int bt_linear(int dtype, int64_t M, int64_t N, int64_t K, const void*
     return linear_impl(dtype, M, N, K, A, lda, W, bias, residual, ldr, out, ldo, act, nullptr, nullptr, stream);
 }
 
+extern "C" int bt_linear_ws(int dtype, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* W,
+                            const void* bias, const void* residual, int64_t ldr, void* out, int64_t ldo, int act,
+                            void* scratch, int64_t scratch_bytes, bt_stream stream) {
+    return linear_impl(dtype, M, N, K, A, lda, W, bias, residual, ldr, out, ldo, act, nullptr, nullptr, stream, scratch,
+                       scratch_bytes);
+}
+
 extern "C" int bt_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim, int32_t rot,
                                   const void* x, int64_t ldx, const void* qkv_w, const void* qkv_b, void* qkv,
                                   int64_t ld_qkv, void* k_cache, void* v_cache, int64_t n_max, const int32_t* pos0_dev,
                                   int32_t pos0_host, const int32_t* pos_table, const float* cos_tab, const float* sin_tab,
-                                  bt_stream stream) {
+                                  void* scratch, int64_t scratch_bytes, bt_stream stream) {
     BT_CHECK_ARG(B >= 0 && q_len > 0 && heads > 0 && head_dim > 0, "bt_qkv_rope_append: bad shape");
     BT_CHECK_ARG(x && qkv_w && qkv && k_cache && v_cache && cos_tab && sin_tab, "bt_qkv_rope_append: null pointer");
     BT_CHECK_ARG(pos0_dev || (pos0_host >= 0 && pos0_host + q_len <= n_max), "bt_qkv_rope_append: cache overflow");
@@ -949,8 +1034,10 @@ extern "C" int bt_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_t h
                          (reinterpret_cast<uintptr_t>(k_cache) & 7u) == 0 && (reinterpret_cast<uintptr_t>(v_cache) & 7u) == 0 &&
                          (reinterpret_cast<uintptr_t>(cos_tab) & 15u) == 0 && (reinterpret_cast<uintptr_t>(sin_tab) & 15u) == 0;
     bool fused = false;
+    // skinny problems stream W faster with split-K (an unfused RoPE pass over a few rows costs nothing)
+    const bool skinny = scratch != nullptr && ceil_div(M, 64) * ceil_div(3 * H, 64) < 256;
     BT_TRY(linear_impl(dtype, M, 3 * H, H, x, ldx, qkv_w, qkv_b, nullptr, 0, qkv, ld_qkv, BT_ACT_NONE,
-                       fusable ? &q : nullptr, &fused, stream));
+                       (fusable && !skinny) ? &q : nullptr, &fused, stream, scratch, scratch_bytes));
     if (!fused)
         BT_TRY(bt_rope_kv_append(dtype, B, q_len, heads, head_dim, rot, qkv, ld_qkv, k_cache, v_cache, n_max, pos0_dev,
                                  pos0_host, pos_table, cos_tab, sin_tab, stream));

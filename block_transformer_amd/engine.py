@@ -67,6 +67,9 @@ class TokenBlockState:
                                     float(getattr(cfg, "rotary_emb_base", 10000.0)), device)
         self.ws = torch.empty(self.rt.workspace_bytes(batch * self.E), dtype=torch.uint8, device=device)
         self.sample_step = torch.zeros(1, dtype=torch.int32, device=device)
+        # split-K scratch for the skinny expansion GEMM (small batches stream the weights with every CU)
+        self.scratch = (torch.empty(16 * batch * self.E * self.H, dtype=torch.float32, device=device)
+                        if batch <= 256 else None)
 
     def _pick(self, t: int, gen):
         if gen is not None and gen.do_sample:
@@ -80,7 +83,8 @@ class TokenBlockState:
         """ctx [B, H_bd] -> raw[:, :count] token ids.  Pure launch sequence (capturable when on_token is None)."""
         td, rt = self.td, self.rt
         # expansion_layer: Conv1d(k=1) == Linear; [B, H_bd] -> [B, E*H] == E prefix rows per sequence
-        ops.linear(ctx, td.expansion_layer.weight, td.expansion_layer.bias, out=self.x_pre.view(self.B, self.E * self.H))
+        ops.linear(ctx, td.expansion_layer.weight, td.expansion_layer.bias, out=self.x_pre.view(self.B, self.E * self.H),
+                   scratch=self.scratch)
         rt.forward(self.x_pre, self.E, self.local, pos0=0, pos_table=self.pos_table, first_out_row=self.E - 1,
                    out=self.hid, ws=self.ws, rope=self.rope)
         for t in range(count):

@@ -21,8 +21,10 @@ def _rows(t: torch.Tensor):
 
 
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-           residual: Optional[torch.Tensor] = None, act: str = "none", out: Optional[torch.Tensor] = None):
-    """out = act(x @ weight.T + bias) + residual   (weight in nn.Linear layout [out_features, in_features])."""
+           residual: Optional[torch.Tensor] = None, act: str = "none", out: Optional[torch.Tensor] = None,
+           scratch: Optional[torch.Tensor] = None):
+    """out = act(x @ weight.T + bias) + residual   (weight in nn.Linear layout [out_features, in_features]).
+    ``scratch`` (any dtype, >= 2*M*N*4 bytes) lets skinny problems use the split-K weight-streaming path."""
     x2, lda = _rows(x)
     M, K = x2.shape
     if weight.dim() == 3:  # Conv1d(kernel_size=1) weight [out, in, 1]
@@ -36,9 +38,14 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     ldr = 0
     if residual is not None:
         r2, ldr = _rows(residual)
-    check(lib().bt_linear(dtype_code(x.dtype), M, N, K, ptr(x2), lda, ptr(weight), ptr(bias),
-                          ptr(residual), ldr, ptr(o2), ldo, _lib.BT_ACT_GELU if act == "gelu" else _lib.BT_ACT_NONE,
-                          current_stream()), "bt_linear")
+    a = _lib.BT_ACT_GELU if act == "gelu" else _lib.BT_ACT_NONE
+    if scratch is None:
+        check(lib().bt_linear(dtype_code(x.dtype), M, N, K, ptr(x2), lda, ptr(weight), ptr(bias), ptr(residual), ldr,
+                              ptr(o2), ldo, a, current_stream()), "bt_linear")
+    else:
+        check(lib().bt_linear_ws(dtype_code(x.dtype), M, N, K, ptr(x2), lda, ptr(weight), ptr(bias), ptr(residual), ldr,
+                                 ptr(o2), ldo, a, ptr(scratch), scratch.numel() * scratch.element_size(),
+                                 current_stream()), "bt_linear_ws")
     return out
 
 

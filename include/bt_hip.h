@@ -92,6 +92,13 @@ int bt_linear(int dtype, int64_t M, int64_t N, int64_t K, const void* A, int64_t
               const void* bias, const void* residual, int64_t ldr, void* out, int64_t ldo, int act,
               bt_stream stream);
 
+/* bt_linear with caller-provided scratch (fp32, >= 2*M*N*4 bytes to be useful): lets skinny problems (M <~ 256 rows, the
+ * weight-streaming regime of small-batch decode) split K across workgroups so that all 256 CUs stream W; the partials are
+ * reduced by a second kernel that applies the same epilogue.  Identical results contract as bt_linear. */
+int bt_linear_ws(int dtype, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* W, const void* bias,
+                 const void* residual, int64_t ldr, void* out, int64_t ldo, int act, void* scratch,
+                 int64_t scratch_bytes, bt_stream stream);
+
 /* LayerNorm of the same row with one or two affine sets (parallel residual reads LN1(x) and LN2(x)):  (C2)
  * out1 = LN(x)*w1+b1, out2 = LN(x)*w2+b2 (out2/w2/b2 may be NULL).  HF GPTNeoXLayer.input_layernorm /
  * post_attention_layernorm / GPTNeoXModel.final_layer_norm. */
@@ -125,7 +132,8 @@ int bt_rope_kv_append(int dtype, int64_t B, int32_t q_len, int32_t heads, int32_
 int bt_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim, int32_t rot, const void* x,
                        int64_t ldx, const void* qkv_w, const void* qkv_b, void* qkv, int64_t ld_qkv, void* k_cache,
                        void* v_cache, int64_t n_max, const int32_t* pos0_dev, int32_t pos0_host,
-                       const int32_t* pos_table, const float* cos_tab, const float* sin_tab, bt_stream stream);
+                       const int32_t* pos_table, const float* cos_tab, const float* sin_tab, void* scratch,
+                       int64_t scratch_bytes, bt_stream stream);   /* scratch: optional split-K scratch, see bt_linear_ws */
 
 /* Causal softmax attention of q_len (already rotated) query rows per sequence over the cache:
  *   query t sees keys j <= pos0 + t with mask[b, j] != 0 (mask may be NULL);  out[b*q_len+t, head*d + :]

@@ -116,6 +116,31 @@ def test_linear_256_tile_kernel_repeatable():
         lib().bt_debug_gemm_variant(0)
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 2048, 8192), (3, 256, 2048), (64, 2048, 2048), (200, 512, 1024), (17, 4096, 2048),
+                                   (1, 64, 128)])
+@pytest.mark.parametrize("variant", ["plain", "bias_gelu", "bias_res"])
+def test_linear_splitk_skinny(M, N, K, variant):
+    """bt_linear_ws: split-K weight-streaming path for small M == fp64 reference == bt_linear within bf16 rounding."""
+    x = rnd(M, K, seed=1).bfloat16()
+    w = rnd(N, K, seed=2, scale=K ** -0.5).bfloat16()
+    b = rnd(N, seed=3).bfloat16() if variant != "plain" else None
+    r = rnd(M, N, seed=4).bfloat16() if variant == "bias_res" else None
+    ref = x.double() @ w.double().T
+    if b is not None:
+        ref = ref + b.double()
+    if variant == "bias_gelu":
+        ref = F.gelu(ref)
+    if r is not None:
+        ref = ref + r.double()
+    scratch = torch.empty(16 * M * N, dtype=torch.float32, device=DEV)
+    args = (x.to(DEV), w.to(DEV), None if b is None else b.to(DEV), None if r is None else r.to(DEV))
+    act = "gelu" if variant == "bias_gelu" else "none"
+    out = ops.linear(*args, act=act, scratch=scratch).cpu()
+    base = ops.linear(*args, act=act).cpu()
+    assert rel_err(out, ref) <= 1.2e-2, rel_err(out, ref)
+    assert rel_err(out, base.double()) <= 1.2e-2
+
+
 def test_linear_strided_inplace_residual():
     """Row strides + in-place residual (x += att @ Wd^T + b), the way bt_decoder_forward calls it."""
     for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 1.2e-2)):
@@ -245,7 +270,7 @@ def test_qkv_rope_append_fused_epilogue(B, q, pos0, heads, use_dev_pos, use_tabl
     try:
         check(lib().bt_qkv_rope_append(_lib.BT_BF16, B, q, heads, d, rot, ptr(xd), H, ptr(wd), ptr(bd), ptr(qkv), 3 * H,
                                        ptr(kc), ptr(vc), n_max, ptr(pos_dev), 0 if use_dev_pos else pos0, ptr(table),
-                                       ptr(tab[0]), ptr(tab[1]), current_stream()))
+                                       ptr(tab[0]), ptr(tab[1]), None, 0, current_stream()))
         torch.cuda.synchronize()
     finally:
         lib().bt_debug_no_qkv_fusion(0)

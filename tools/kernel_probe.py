@@ -37,16 +37,18 @@ def timed(fn, iters, warmup=3):
     return a.elapsed_time(b) / iters  # ms
 
 
-def probe_gemm(M, N, K, iters, act="none", bias=True, res=False):
+def probe_gemm(M, N, K, iters, act="none", bias=True, res=False, scratch=False):
     x = (torch.randn(M, K, device=DEV) * 1.0).bfloat16()
     w = (torch.randn(N, K, device=DEV) * K ** -0.5).bfloat16()
     b = torch.randn(N, device=DEV).bfloat16() if bias else None
     r = torch.randn(M, N, device=DEV).bfloat16() if res else None
     out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
-    ms = timed(lambda: ops.linear(x, w, b, r, act=act, out=out), iters)
+    sc = torch.empty(16 * M * N, dtype=torch.float32, device=DEV) if scratch else None
+    ms = timed(lambda: ops.linear(x, w, b, r, act=act, out=out, scratch=sc), iters)
     tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
     return {"op": "gemm", "M": M, "N": N, "K": K, "act": act, "ms": round(ms, 4), "TFLOPs": round(tf, 1),
-            "frac_mfma_peak": round(tf / 2500.0, 3)}
+            "frac_mfma_peak": round(tf / 2500.0, 3), "splitk_scratch": scratch,
+            "weight_GBps": round(N * K * 2 / (ms * 1e-3) / 1e9, 1)}
 
 
 def probe_attn(B, n, iters, heads=16, d=128, n_split=1, dtype=torch.bfloat16):
@@ -97,7 +99,7 @@ def probe_copy(nbytes, iters):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["gemm", "attn", "flash", "suite", "copy", "ab", "abl"])
+    ap.add_argument("what", choices=["gemm", "attn", "flash", "suite", "copy", "ab", "abl", "skinny"])
     ap.add_argument("--m", type=int, default=32768)
     ap.add_argument("--n", type=int, default=6144)
     ap.add_argument("--k", type=int, default=2048)
@@ -133,6 +135,11 @@ def main():
                 r["variant"] = v
                 res.append(r)
         lib().bt_debug_gemm_variant(0)
+    elif args.what == "skinny":
+        for M in (1, 8, 64, 128, 256):
+            for (N, K) in ((6144, 2048), (2048, 2048), (8192, 2048), (2048, 8192), (4096, 2048)):
+                for sc in (False, True):
+                    res.append(probe_gemm(M, N, K, 30, scratch=sc))
     elif args.what == "abl":
         for (M, N, K) in ((32768, 6144, 2048), (32768, 2048, 8192), (32768, 2048, 2048)):
             for v in (9, 11, 9, 11, 9, 11):
