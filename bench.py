@@ -216,30 +216,42 @@ def main():
         if os.path.exists(pmc_path):
             pmc = json.load(open(pmc_path))
 
+        def traffic(name):
+            """HBM bytes per launch from the committed rocprofv3 PMC pass (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
+            of tools/kernel_probe.py at the shape recorded next to it; None when no PMC pass is on file."""
+            rec = pmc.get(name)
+            return None if not rec else rec["hbm_bytes_corrected"]
+
+        def traffic_note(name):
+            rec = pmc.get(name)
+            return None if not rec else (f"PMC pass on {rec['shape']}: {rec['hbm_bytes_corrected'] / 1e6:.1f} MB HBM traffic "
+                                         f"per launch vs {rec['algorithmic_bytes'] / 1e6:.1f} MB algorithmic")
+
         def roof(name):
             ms, n = fam[name]
             if name in ("linear_mfma", "linear_generic"):
                 ach = counts["linear_flops"] / (ms / 1e3) / 1e12
                 return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
-                        "traffic": pmc.get(name), "launches": int(n), "avg_launch_us": ms / n * 1e3,
+                        "traffic": traffic(name), "launches": int(n), "avg_launch_us": ms / n * 1e3,
                         "algorithmic_per_launch": counts["linear_flops"] / n}
             if name == "attn_flash":
                 ach = counts["attn_flash_flops"] / (ms / 1e3) / 1e12
                 return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": pmc.get(name),
+                        "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS, "traffic": traffic(name),
                         "launches": int(n), "avg_launch_us": ms / n * 1e3,
                         "algorithmic_per_launch": counts["attn_flash_flops"] / n}
             if name == "attn_rows":
                 ach = counts["attn_rows_bytes"] / (ms / 1e3) / 1e9
                 return {"kernel": name, "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": pmc.get(name), "launches": int(n),
+                        "frac": ach / HBM_PEAK_GBS, "traffic": traffic(name), "launches": int(n),
                         "avg_launch_us": ms / n * 1e3, "algorithmic_per_launch": counts["attn_rows_bytes"] / n}
             return {"kernel": name, "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": None, "traffic": None, "launches": int(n), "avg_launch_us": ms / n * 1e3}
 
         log(f"kernel families (ms): {fam_ms}")
         result["roofline"] = roof(dominant)
+        result["roofline"]["traffic_note"] = traffic_note(dominant)
         if "attn_rows" in fam_ms and dominant != "attn_rows":
             result["roofline_global_attention"] = roof("attn_rows")   # the north-star HBM-bound global path
         if "linear_mfma" in fam_ms and dominant != "linear_mfma":
