@@ -16,12 +16,52 @@
 // Roofline: MFMA-bound for M >~ 300 rows (2*M*N*K flop vs 2*(M*K + N*K + M*N) bytes); HBM-bound on W below that.
 #include "bt_common.h"
 
+#include <algorithm>
+
 namespace bt {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 __device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// GELU for the bf16 MFMA epilogues.  erff costs ~45 VALU instructions per value (measured: a K = 2048 GEMM with GELU ran
+// 33 % slower than without), so the bf16 path evaluates  gelu(x) = x * Phi(x)  through the scaled normal tail
+//     Phi(-a) = exp(-a^2 / 2) * R(a),   a = |x|,   R = degree-12 polynomial in u = a/3 - 1 (relative minimax fit on [0, 6])
+//     gelu(x) = x * Phi(-a)          (x < 0)        = x * (1 - Phi(-a))   (x >= 0)
+// which keeps RELATIVE accuracy in the negative tail (no 1 + erf cancellation).  In fp32 arithmetic the result is within
+// 5.5e-6 relative of the exact erf GELU for x > -6 (|gelu| < 6e-9 beyond, absolute error < 3e-9): 1/700 of a bf16
+// half-ulp.  The fp32 parity path (gemm_generic_kernel) keeps erff.  Two values per call so the polynomial runs on the
+// packed-fp32 pipe (v_pk_fma_f32): ~15 instruction slots per value.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ inline v2f gelu_tail2(v2f x) {
+    const v2f ax = {__builtin_fabsf(x.x), __builtin_fabsf(x.y)};
+    const v2f a = {__builtin_fminf(ax.x, 6.0f), __builtin_fminf(ax.y, 6.0f)};
+    const v2f u = a * (1.0f / 3.0f) - 1.0f;
+    v2f r = u * 2.359363747e-03f + -4.802452166e-03f;
+    r = r * u + 1.242561118e-03f;
+    r = r * u + -5.446036305e-04f;
+    r = r * u + 9.139311313e-03f;
+    r = r * u + -1.622305936e-02f;
+    r = r * u + 2.069297082e-02f;
+    r = r * u + -3.035567151e-02f;
+    r = r * u + 4.502980965e-02f;
+    r = r * u + -6.248621239e-02f;
+    r = r * u + 8.241136925e-02f;
+    r = r * u + -1.031977833e-01f;
+    r = r * u + 1.215138655e-01f;
+    const v2f t = ax * ax * -0.72134752044448170368f;   // -a^2 / 2 * log2(e)
+    const v2f e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    const v2f q = e * r;                                 // Phi(-|x|)
+    const v2f s = {x.x < 0.0f ? q.x : 1.0f - q.x, x.y < 0.0f ? q.y : 1.0f - q.y};
+    return x * s;
+}
+
+__device__ inline void gelu4(float (&v)[4]) {
+    const v2f lo = gelu_tail2(v2f{v[0], v[1]}), hi = gelu_tail2(v2f{v[2], v[3]});
+    v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
+}
 
 // ---- shared epilogue ---------------------------------------------------------------------------------------------------
 // Optional fused "QKV mode" (bt_qkv_rope_append): the GEMM is the GPT-NeoX query_key_value projection; instead of
@@ -61,8 +101,7 @@ __device__ inline void epi_store4(const EpiArgs& e, int m, int n, float (&v)[4],
             v[2] += __uint_as_float(b2.y << 16); v[3] += __uint_as_float(b2.y & 0xffff0000u);
         }
         if (e.act == BT_ACT_GELU) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+            gelu4(v);
         }
         if (e.res) {
             const uint2 r2 = *reinterpret_cast<const uint2*>(e.res + (int64_t)m * e.ldr + n);
@@ -78,7 +117,7 @@ __device__ inline void epi_store4(const EpiArgs& e, int m, int n, float (&v)[4],
             if (n + r >= e.N) break;
             float x = v[r];
             if (e.bias) x += bf16_to_f32(e.bias[n + r].x);
-            if (e.act == BT_ACT_GELU) x = gelu_erf(x);
+            if (e.act == BT_ACT_GELU) x = gelu_tail2(v2f{x, x}).x;
             if (e.res) x += bf16_to_f32(e.res[(int64_t)m * e.ldr + n + r].x);
             e.out[(int64_t)m * e.ldo + n + r].x = f32_to_bf16(x);
         }
@@ -151,12 +190,12 @@ struct CTile {
     static constexpr int PITCH = COLS * 2 + 16;  // bytes; +16 breaks the power-of-two row stride (ds_write_b64 conflicts)
 };
 
-template <int COLS>
+template <int COLS, bool BIAS = true>
 __device__ inline void epi_to_lds(const EpiArgs& e, char* ctile, int ml, int nl, int m, int n_lo, const f32x4_t& a_lo,
                                   const f32x4_t& a_hi) {
     float lo[4] = {a_lo[0], a_lo[1], a_lo[2], a_lo[3]};
     float hi[4] = {a_hi[0], a_hi[1], a_hi[2], a_hi[3]};
-    if (e.bias) {
+    if (BIAS && e.bias) {
         if (n_lo < e.N) {
             const uint2 b2 = *reinterpret_cast<const uint2*>(e.bias + n_lo);
             lo[0] += __uint_as_float(b2.x << 16); lo[1] += __uint_as_float(b2.x & 0xffff0000u);
@@ -169,11 +208,8 @@ __device__ inline void epi_to_lds(const EpiArgs& e, char* ctile, int ml, int nl,
         }
     }
     if (e.act == BT_ACT_GELU) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            lo[r] = gelu_erf(lo[r]);
-            hi[r] = gelu_erf(hi[r]);
-        }
+        gelu4(lo);
+        gelu4(hi);
     }
     if (e.q.enabled && m < e.M) {
         const int D = e.q.head_dim;
@@ -417,7 +453,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
     if (ep.act == BT_ACT_GELU) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = gelu_erf(v[i]);
+        for (int i = 0; i < 8; i += 2) {
+            const v2f g2 = gelu_tail2(v2f{v[i], v[i + 1]});
+            v[i] = g2.x;
+            v[i + 1] = g2.y;
+        }
     }
     if (ep.res) {
         float rv[8];
@@ -807,6 +847,433 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256p2_kernel(const bf16* __
     }
 }
 
+// ---- persistent 256x256 kernel (production path for chip-filling grids) ----------------------------------------------------
+// The two-phase ring above, made persistent: min(tiles, #CU) workgroups each walk tiles id = round * G + remap(block), and
+// the half-tile load stream simply continues across tile boundaries (the load cursor moves to the next tile's A / W panels
+// two K-tiles before the MFMAs get there).  What this removes is the per-tile bubble of the one-tile-per-workgroup kernels:
+// prologue latency + a 32 MiB chip-wide store burst that had to drain before the next workgroup could start (measured:
+// 18 % of a K = 2048 GEMM).  Here the epilogue is per WAVE and needs no block barrier:
+//   * a wave owns 128 rows x 64 CONTIGUOUS columns (wn selects the W half and the 64-row slab inside it), so its output
+//     rows are full 128-byte lines;
+//   * per 16-row fragment: registers -> a private 16 x 64 bf16 LDS patch (2.25 KiB per wave, next to the ring) -> two
+//     16-byte-per-lane coalesced global stores per fragment = 16 store instructions per tile, fire and forget;
+//   * the bias is folded into the accumulator init (DMA'd to a 1 KiB LDS row by wave 0 together with the tile's first
+//     loads), so the epilogue issues no loads unless there is a residual / RoPE table to read.
+// vmcnt accounting: loads and stores retire in order on gfx9-family vmcnt, so the stores sit in the same queue as the
+// ring DMAs.  For the two phases after an epilogue the needed DMAs are OLDER than the 16 stores, and the counted waits add
+// 16 (only when the previous tile was a full tile: every wave then issued >= 16 stores; on edge tiles the smaller count is
+// used, which is merely conservative).  From the third phase on the needed DMAs are younger than the stores and the
+// stores must have been acknowledged by L2 -- they get ~2 phases (~1 us) to do so, which holds once the CUs have drifted
+// out of lockstep.  Any other VMEM op a wave issues (bias DMA, residual / RoPE loads) only makes its waits stricter.
+constexpr int EPI_PITCH = CTile<64>::PITCH;                  // 144 B: 16 rows x (128 B + 16 pad)
+constexpr int PP_EPI_OFF = 8 * HALF_BYTES;                   // after the 128 KiB ring
+constexpr int PP_EPI_WAVE = 16 * EPI_PITCH;
+constexpr int PP_BIAS_OFF = PP_EPI_OFF + 8 * PP_EPI_WAVE;
+constexpr int PP_SMEM = PP_BIAS_OFF + 2 * 1024;
+constexpr int PP_STORES = 16;                                // store instructions per wave per full tile
+static_assert(PP_SMEM <= 160 * 1024, "persistent GEMM LDS budget");
+
+template <int N>
+__device__ inline void wait_vmcnt_pp() {
+    if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if constexpr (N == 22) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+    else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else wait_vmcnt<N>();
+}
+
+// as wait_for_phase2, over the workgroup's whole load stream; stores_younger: a full tile's epilogue (PP_STORES store
+// instructions) was issued after the youngest load this phase needs
+__device__ inline void wait_for_phase_pp(int g, int total_loads, bool stores_younger) {
+    const int t = g >> 1;
+    if (4 * t >= total_loads) return;
+    const int need = 4 * t + ((g & 1) ? 3 : 2);
+    const int issued = min(2 * (g - 1) + 1 + PD2, total_loads - 1);
+    const int allow = issued - need;
+    if (stores_younger) {
+        static_assert(PP_STORES == 16, "vmcnt immediates below assume 16 stores");
+        if (allow >= 4) wait_vmcnt_pp<24>();
+        else if (allow == 3) wait_vmcnt_pp<22>();
+        else if (allow == 2) wait_vmcnt_pp<20>();
+        else if (allow == 1) wait_vmcnt_pp<18>();
+        else wait_vmcnt_pp<16>();
+    } else {
+        if (allow >= 4) wait_vmcnt<8>();
+        else if (allow == 3) wait_vmcnt<6>();
+        else if (allow == 2) wait_vmcnt<4>();
+        else if (allow == 1) wait_vmcnt<2>();
+        else wait_vmcnt<0>();
+    }
+}
+
+// tile of (round, this workgroup): XCD remap inside the round (each XCD's L2 sees a contiguous id range), then GROUP_M2
+__device__ inline bool pp_tile(int round, int tiles_m, int tiles_n, int& m0, int& n0) {
+    const int G = gridDim.x;
+    const int nwg = tiles_m * tiles_n;
+    const int base = round * G;
+    const int S = min(G, nwg - base);
+    if (S <= 0) return false;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, local = bid >> 3, q = S >> 3, r = S & 7;
+    if (local >= q + (xcd < r ? 1 : 0)) return false;
+    const int id = base + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+    const int group_sz = GROUP_M2 * tiles_n;
+    const int g = id / group_sz;
+    const int first_m = g * GROUP_M2;
+    const int gm = min(tiles_m - first_m, GROUP_M2);
+    const int in_g = id - g * group_sz;
+    m0 = (first_m + in_g % gm) * BM2;
+    n0 = (in_g / gm) * BN2;
+    return true;
+}
+
+__device__ inline uint32_t lds_addr(const char* p) {
+    return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+}
+
+// 16-byte-per-lane LDS-DMA, global address = SGPR base + 32-bit VGPR offset, LDS address = lds_base (M0) + lane * 16
+__device__ inline void glds16_sbase(const char* base_uniform, uint32_t voff, uint32_t lds_base_uniform) {
+    asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(voff), "s"(base_uniform), "s"(lds_base_uniform)
+                 : "memory");
+}
+
+// same with a per-lane 64-bit global address (edge tiles, bias row).  The persistent kernel issues every LDS-DMA through
+// these two helpers so the compiler never emits its own M0 writes in that kernel (it does not know the asm changes M0).
+__device__ inline void glds16_vaddr(const void* gptr, uint32_t lds_base_uniform) {
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gptr), "s"(lds_base_uniform) : "memory");
+}
+
+// one half-tile (kind in consumption order A0, W0, W1, A1) of the K-tile at k0 into ring buffer `parity`.
+// Addressing is (wave-uniform 64-bit base) + (32-bit lane offset): the lane part -- row (lane >> 3) of an 8-row group and
+// the swizzled 16-byte slot -- is the same for every half-tile of an operand, so the whole load stream costs two VGPRs
+// (voff_a / voff_w) instead of a 64-bit pointer per DMA.  Tiles cut by the matrix edge clamp rows per lane (rare path).
+__device__ inline void stage_half_at(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ W, int64_t ldw,
+                                     int m0, int n0, int M, int N, int k0, int parity, int kind, char* smem, int wave,
+                                     int lane, uint32_t voff_a, uint32_t voff_w) {
+    const bool is_a = (kind == 0) || (kind == 3);
+    const int half = (kind == 2 || kind == 3) ? 1 : 0;
+    const char* src = reinterpret_cast<const char*>(is_a ? A : W);
+    const int64_t ld = is_a ? lda : ldw;
+    const int row0 = (is_a ? m0 : n0) + half * 128 + wave * 16;
+    const int row_max = is_a ? M : N;
+    const uint32_t voff = is_a ? voff_a : voff_w;
+    char* slot = smem + parity * 4 * HALF_BYTES + ((is_a ? 0 : 2) + half) * HALF_BYTES + wave * 16 * 128;
+    if (row0 + 16 <= row_max) {
+        const char* base = src + ((int64_t)row0 * ld + k0) * 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16_sbase(base + i * 8 * ld * 2, voff, lds_addr(slot + i * 8 * 128));
+    } else {
+        int l = lane;
+        asm volatile("" : "+v"(l));   // opaque: keep this path's lane-derived address parts out of registers until needed
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int grow = row0 + i * 8 + (l >> 3);
+            grow = grow < row_max ? grow : row_max - 1;
+            const int gslot = (l & 7) ^ ((l >> 3) & 7);
+            glds16_vaddr(src + ((int64_t)grow * ld + k0 + gslot * 8) * 2, lds_addr(slot + i * 8 * 128));
+        }
+    }
+}
+
+
+// Per-wave epilogue of the persistent kernel: the wave's 128 rows x 64 columns (8 fragments of 16 rows), bias already in
+// the accumulators.  Sweep A issues EVERY load the epilogue needs (RoPE table rows / residual chunks) before sweep B
+// issues the first store: with in-order vmcnt retirement a load waited for after a store would wait for that store too.
+enum { PP_PLAIN = 0, PP_GELU = 1, PP_RES = 2, PP_QKV = 3 };   // epilogue flavour (bias is orthogonal: accumulator init)
+
+template <int MODE>
+__device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x4_t (&acc)[8][4], int cm0, int n_wave, int wm,
+                                   int lane) {
+    const int M = e.M, N = e.N;
+    constexpr bool qkv = MODE == PP_QKV;
+    // ---- sweep A ----  (two batches of 4 fragments: 32 transient registers, two exposed load latencies)
+    if (qkv) {
+        const int D = e.q.head_dim;
+        bool rot[2];
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            const int n_grp = n_wave + pr * 32;           // 32-aligned column group (wave-uniform)
+            const int head = n_grp / (3 * D);
+            const int within = n_grp - head * 3 * D;
+            const int part = within / D;                  // 0 q, 1 k, 2 v
+            rot[pr] = part < 2 && within == part * D && n_grp < N;   // the group holds dims 0..31 of a q / k head
+        }
+        if (rot[0] || rot[1]) {
+            // table rows of the lane's 8 output rows (independent loads first, then the dependent cos / sin rows)
+            int rpos[8];
+#pragma unroll
+            for (int ai = 0; ai < 8; ++ai) {
+                int m = cm0 + (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16 + (lane & 15);
+                m = m < M ? m : M - 1;
+                rpos[ai] = pos0 + m % e.q.q_len;
+            }
+            if (e.q.pos_table) {
+#pragma unroll
+                for (int ai = 0; ai < 8; ++ai) rpos[ai] = e.q.pos_table[rpos[ai]];
+            }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                if (!rot[pr]) continue;
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    float4 c[4], sn[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int64_t off = (int64_t)rpos[hb * 4 + i] * 16 + (lane >> 4) * 4;
+                        c[i] = *reinterpret_cast<const float4*>(e.q.cos_tab + off);
+                        sn[i] = *reinterpret_cast<const float4*>(e.q.sin_tab + off);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float cc[4] = {c[i].x, c[i].y, c[i].z, c[i].w};
+                        const float ss[4] = {sn[i].x, sn[i].y, sn[i].z, sn[i].w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float x1 = acc[hb * 4 + i][pr * 2][r], x2 = acc[hb * 4 + i][pr * 2 + 1][r];
+                            acc[hb * 4 + i][pr * 2][r] = x1 * cc[r] - x2 * ss[r];
+                            acc[hb * 4 + i][pr * 2 + 1][r] = x2 * cc[r] + x1 * ss[r];
+                        }
+                    }
+                }
+            }
+        }
+    } else if (MODE == PP_RES) {   // residual joins the fp32 accumulators (accumulator layout: 4 consecutive columns of one row)
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            uint2 rv[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = cm0 + hb * 128 + wm * 64 + i * 16 + (lane & 15);
+#pragma unroll
+                for (int jf = 0; jf < 4; ++jf) {
+                    const int n = n_wave + jf * 16 + (lane >> 4) * 4;
+                    rv[i][jf] = (m < M && n < N) ? *reinterpret_cast<const uint2*>(e.res + (int64_t)m * e.ldr + n)
+                                                 : uint2{0, 0};
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int jf = 0; jf < 4; ++jf) {
+                    acc[hb * 4 + i][jf][0] += __uint_as_float(rv[i][jf].x << 16);
+                    acc[hb * 4 + i][jf][1] += __uint_as_float(rv[i][jf].x & 0xffff0000u);
+                    acc[hb * 4 + i][jf][2] += __uint_as_float(rv[i][jf].y << 16);
+                    acc[hb * 4 + i][jf][3] += __uint_as_float(rv[i][jf].y & 0xffff0000u);
+                }
+        }
+    }
+    asm volatile("" ::: "memory");
+    // ---- sweep B ----
+    const uint32_t patch_w = lds_addr(stage) + (lane & 15) * EPI_PITCH + (lane >> 4) * 8;
+    const uint32_t patch_r = lds_addr(stage) + (lane >> 3) * EPI_PITCH + (lane & 7) * 16;
+#pragma unroll
+    for (int ai = 0; ai < 8; ++ai) {
+        const int row_l = (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16;
+        uint2 o[4];
+#pragma unroll
+        for (int jf = 0; jf < 4; ++jf) {
+            float v[4] = {acc[ai][jf][0], acc[ai][jf][1], acc[ai][jf][2], acc[ai][jf][3]};
+            if (MODE == PP_GELU) gelu4(v);
+            o[jf].x = pack_bf16x2(v[0], v[1]);
+            o[jf].y = pack_bf16x2(v[2], v[3]);
+        }
+        // registers -> wave-private patch -> registers, transposed to 16 B per lane along rows (inline asm: the compiler
+        // must not see LDS traffic here, it would fence it against the in-flight LDS-DMA with vmcnt(0))
+        uint4 v0, v1;
+        asm volatile("ds_write_b64 %2, %4\n\tds_write_b64 %2, %5 offset:32\n\t"
+                     "ds_write_b64 %2, %6 offset:64\n\tds_write_b64 %2, %7 offset:96\n\t"
+                     "s_waitcnt lgkmcnt(0)\n\t"
+                     "ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:%8\n\t"
+                     "s_waitcnt lgkmcnt(0)"
+                     : "=&v"(v0), "=&v"(v1)
+                     : "v"(patch_w), "v"(patch_r), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "n"(8 * EPI_PITCH)
+                     : "memory");
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint4 v = h ? v1 : v0;
+            const int m = cm0 + row_l + h * 8 + (lane >> 3);
+            const int n = n_wave + (lane & 7) * 8;
+            if (m < M && n < N) {
+                bf16* dst;
+                if (!qkv) {
+                    dst = e.out + (int64_t)m * e.ldo + n;
+                } else {
+                    const int D = e.q.head_dim;
+                    const int head = n / (3 * D);
+                    const int within = n - head * 3 * D;
+                    const int part = within / D;
+                    const int el = within - part * D;
+                    const int64_t b = m / e.q.q_len;
+                    const int t = m - (int)b * e.q.q_len;
+                    bf16* cache = part == 1 ? e.q.kc : e.q.vc;
+                    dst = part == 0 ? e.out + (int64_t)m * e.ldo + n
+                                    : cache + ((b * e.q.heads + head) * e.q.n_max + pos0 + t) * D + el;
+                }
+                *reinterpret_cast<uint4*>(dst) = v;
+            }
+        }
+    }
+}
+
+struct LoadCursor {   // wave-uniform: the K-tile whose half-tiles are being issued
+    int m0, n0, t, j, x;
+    bool valid;
+};
+
+template <int MODE>
+__global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __restrict__ A, int64_t lda,
+                                                                 const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
+                                                                 int K, int tiles_m, int tiles_n) {
+    const int M = ep.M, N = ep.N;
+    __shared__ __attribute__((aligned(16))) char smem[PP_SMEM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int wh = wn >> 1;                      // W half this wave multiplies
+    const int wrow = (wn & 1) * 64;              // its 64-row slab inside the half == 64 contiguous output columns
+    const int wcol = wh * 128 + wrow;            // column offset of the wave's output inside the tile
+    const bool grp1 = wave >= 4;
+    char* stage = smem + PP_EPI_OFF + wave * PP_EPI_WAVE;
+    const uint32_t lane_slot = (uint32_t)(((lane & 7) ^ ((lane >> 3) & 7)) * 16);
+    const uint32_t voff_a = (uint32_t)(lane >> 3) * (uint32_t)(lda * 2) + lane_slot;
+    const uint32_t voff_w = (uint32_t)(lane >> 3) * (uint32_t)(ldw * 2) + lane_slot;
+
+    const int nk = K / BK;
+    // tiles of this workgroup: rounds 0 .. nt-1 (all workgroups have the full rounds; the last round may be partial)
+    const int nwg = tiles_m * tiles_n;
+    const int G = gridDim.x;
+    int nt = nwg / G;
+    {
+        int mm, nn;
+        if (nwg % G != 0 && pp_tile(nt, tiles_m, tiles_n, mm, nn)) ++nt;
+    }
+    const int total = 4 * nk * nt;
+
+    LoadCursor lc;
+    lc.t = 0; lc.j = 0; lc.x = 0;
+    lc.valid = pp_tile(0, tiles_m, tiles_n, lc.m0, lc.n0);
+    auto issue = [&](int kind) {
+        if (lc.valid)
+            stage_half_at(A, lda, W, ldw, lc.m0, lc.n0, M, N, lc.t * BK, lc.x & 1, kind, smem, wave, lane, voff_a, voff_w);
+    };
+    auto issue_bias = [&]() {   // wave 0: bias[n0 .. n0+255] of the cursor's tile -> LDS row (j & 1), before that tile's loads
+        if (wave == 0 && ep.bias && lc.valid) {
+            int col = lc.n0 + (lane & 31) * 8;
+            col = col <= N - 8 ? col : N - 8;
+            glds16_vaddr(ep.bias + col, lds_addr(smem + PP_BIAS_OFF + (lc.j & 1) * 1024));
+        }
+    };
+    auto advance = [&]() {
+        ++lc.x;
+        if (++lc.t == nk) {
+            lc.t = 0;
+            ++lc.j;
+            lc.valid = lc.j < nt && pp_tile(lc.j, tiles_m, tiles_n, lc.m0, lc.n0);
+        }
+    };
+    // prologue: K-tile 0 (4 half-tiles) + K-tile 1 (A0, W0) = PD2 loads
+    issue_bias();
+    issue(0); issue(1); issue(2); issue(3);
+    advance();
+    if (lc.t == 0) issue_bias();
+    issue(0); issue(1);
+
+    f32x4_t acc[8][4];       // [A half * 4 + m-frag][n-frag]
+    bf16x8_t af[4][2];
+    bf16x8_t wf[4][2];
+    // fused-QKV mode: the cache write position is constant for the launch -> one scalar, read before the pipeline starts
+    int pos0 = 0;
+    if (MODE == PP_QKV) pos0 = __builtin_amdgcn_readfirstlane(ep.q.pos0_dev ? *ep.q.pos0_dev : ep.q.pos0_host);
+    const uint32_t bias_lds = lds_addr(smem + PP_BIAS_OFF + (wcol + (lane >> 4) * 4) * 2);
+
+    if (grp1) {
+        wait_for_phase_pp(0, total, false);
+        cbarrier();
+    }
+    int g = 0;
+    int cm0 = 0, cn0 = 0;
+    bool prev_full = false;
+    for (int j = 0; j < nt; ++j) {
+        pp_tile(j, tiles_m, tiles_n, cm0, cn0);
+        for (int t = 0; t < nk; ++t) {
+            const char* buf = smem + (g & 2) * 2 * HALF_BYTES;   // ring buffer of K-tile g >> 1
+#pragma unroll
+            for (int p = 0; p < 2; ++p, ++g) {
+                if (!grp1) wait_for_phase_pp(g, total, prev_full && t == 0);
+                cbarrier();
+                if (p == 0) {
+                    if (t == 0) {   // new tile: accumulators start at the bias (LDS row j & 1, landed before this barrier)
+                        if (ep.bias) {
+                            // inline asm: a compiler-visible LDS read of a DMA-written region would get a vmcnt(0) in front
+                            uint64_t b[4];
+                            const uint32_t ba = bias_lds + (j & 1) * 1024;
+                            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:32\n\t"
+                                         "ds_read_b64 %2, %4 offset:64\n\tds_read_b64 %3, %4 offset:96\n\t"
+                                         "s_waitcnt lgkmcnt(0)"
+                                         : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
+                                         : "v"(ba)
+                                         : "memory");
+#pragma unroll
+                            for (int jf = 0; jf < 4; ++jf) {
+                                const uint32_t lo = (uint32_t)b[jf], hi = (uint32_t)(b[jf] >> 32);
+                                const f32x4_t bv = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u),
+                                                    __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+#pragma unroll
+                                for (int i = 0; i < 8; ++i) acc[i][jf] = bv;
+                            }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                                for (int jf = 0; jf < 4; ++jf) acc[i][jf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                        }
+                    }
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                        for (int jf = 0; jf < 4; ++jf)
+                            wf[jf][kk] = read_frag(buf + (2 + wh) * HALF_BYTES, wrow + jf * 16, kk, lane);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) af[i][kk] = read_frag(buf, wm * 64 + i * 16, kk, lane);
+                    }
+                    issue(2); issue(3);
+                    advance();
+                } else {
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) af[i][kk] = read_frag(buf + HALF_BYTES, wm * 64 + i * 16, kk, lane);
+                    if (lc.t == 0) issue_bias();
+                    issue(0); issue(1);
+                }
+                if (grp1) wait_for_phase_pp(g + 1, total, prev_full && t == 0 && p == 0);
+                cbarrier();
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int jf = 0; jf < 4; ++jf)
+                            acc[p * 4 + i][jf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jf][kk], af[i][kk],
+                                                                                         acc[p * 4 + i][jf], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+            }
+        }
+        // the epilogue's lane-derived addresses must not be hoisted out of the tile loop (they would sit in VGPRs through
+        // the K-loop, which has none to spare): hand it an opaque copy of the lane id
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        pp_epilogue<MODE>(ep, pos0, stage, acc, cm0, cn0 + wcol, wm, lane_e);
+        prev_full = (cm0 + BM2 <= M) && (cn0 + BN2 <= N);
+    }
+    if (!grp1) cbarrier();
+}
+
 // ---- generic tiled kernel (fp32 parity path; any M, N, K, strides) --------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_generic_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ W,
@@ -868,10 +1335,24 @@ __global__ __launch_bounds__(256) void gemm_generic_kernel(const T* __restrict__
     }
 }
 
+static int num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;
+    }
+    return n;
+}
+
 static bool g_force_generic = false;
+static int g_max_wg = 0;   // test hook: cap the persistent kernel's grid so small problems walk several tiles per workgroup
 static bool g_no_qkv_fusion = false;
 static int g_gemm_variant = 0;  // 0 auto; 1 force 128^2; 2/3 256^2 four-phase ring (plain/staggered); 4-8 timing ablations; 9/10 256^2 two-phase
-// ring (staggered/plain).  Tests and A/B probes only.
+// ring, one tile per workgroup (staggered/plain); default: persistent two-phase ring.  Tests and A/B probes only.
 
 }  // namespace bt
 
@@ -933,7 +1414,27 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                 case 8: BT_LAUNCH_256((gemm_bf16_mfma256_kernel<true, 3>)); break;   // timing ablation: MFMA+barriers
                 case 10: BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<false>)); break;
                 case 11: BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<true, true>)); break;  // timing ablation: no epilogue
-                default: BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<true>)); break;  // production (also variant 9)
+                case 9: BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<true>)); break;    // one tile per workgroup
+                default: {
+                    const bool pp_ok = (N % 8 == 0) && (ldo % 8 == 0) && aligned16(out) && K / BK >= 4 &&
+                                       (!residual || (ldr % 8 == 0 && aligned16(residual))) && (!bias || aligned16(bias));
+                    if (pp_ok) {   // production: persistent, per-wave epilogue
+                        const int n_wg = (int)std::min<int64_t>((int64_t)tiles_m * tiles_n, g_max_wg > 0 ? g_max_wg : num_cus());
+#define BT_LAUNCH_PP(MODE_)                                                                                          \
+    hipLaunchKernelGGL(gemm_bf16_mfma256pp_kernel<MODE_>, dim3(n_wg), dim3(512), 0, s, (const bf16*)A, lda, (const bf16*)W, \
+                       K, ep, (int)K, tiles_m, tiles_n)
+                        // (the engine never combines these: QKV has no activation / residual, GELU has no residual)
+                        if (ep.q.enabled) BT_LAUNCH_PP(PP_QKV);
+                        else if (act == BT_ACT_GELU && !residual) BT_LAUNCH_PP(PP_GELU);
+                        else if (act == BT_ACT_NONE && residual) BT_LAUNCH_PP(PP_RES);
+                        else if (act == BT_ACT_NONE) BT_LAUNCH_PP(PP_PLAIN);
+                        else BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<true>));   // GELU + residual: one-tile kernel
+#undef BT_LAUNCH_PP
+                    } else {
+                        BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<true>));
+                    }
+                    break;
+                }
             }
 #undef BT_LAUNCH_256
         } else if (mfma_ok && scratch && !ep.q.enabled && g_gemm_variant != 1 && (N % 8 == 0) && (ldo % 8 == 0) &&
@@ -1047,4 +1548,5 @@ extern "C" int bt_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_t h
 // test hook: force the generic kernel for bf16 (A/B checks of the MFMA kernel against the simple one)
 extern "C" void bt_debug_force_generic_gemm(int on) { g_force_generic = on != 0; }
 extern "C" void bt_debug_gemm_variant(int v) { g_gemm_variant = v; }
+extern "C" void bt_debug_gemm_max_wg(int n) { g_max_wg = n; }
 extern "C" void bt_debug_no_qkv_fusion(int on) { g_no_qkv_fusion = on != 0; }

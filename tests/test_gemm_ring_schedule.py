@@ -82,3 +82,136 @@ def test_model_detects_a_too_deep_prefetch():
         model(8, 4, 9)
     with pytest.raises(AssertionError, match="WAR"):
         model(8, 2, 8)
+
+
+# ---- persistent kernel (gemm_bf16_mfma256pp_kernel) -----------------------------------------------------------------------
+# Literal program-order model: every wave's VMEM queue retires IN ORDER (gfx9 vmcnt); `s_waitcnt vmcnt(N)` completes all but
+# the N youngest ops.  The kernel's counted waits add PP_STORES after a FULL tile's epilogue and nothing after an edge tile.
+PP_STORES = int(re.search(r"constexpr int PP_STORES = (\d+);", SRC).group(1))
+
+
+def _pp_wait_imm(g, total, stores_younger, pd):
+    """transliteration of wait_for_phase_pp: the vmcnt immediate, or None when no wait is issued"""
+    t = g >> 1
+    if 4 * t >= total:
+        return None
+    need = 4 * t + (3 if g & 1 else 2)
+    issued = min(2 * (g - 1) + 1 + pd, total - 1)
+    allow = issued - need
+    assert allow >= 0
+    return 2 * min(allow, 4) + (PP_STORES if stores_younger else 0)
+
+
+def _pp_stream(grp, wave0, nk, nt, full, stores, pd, has_bias):
+    """program-order event list of one wave: ('vm', tag) VMEM op, ('wait', N), ('bar',), ('read', tag)"""
+    total = 4 * nk * nt
+    ev = []
+
+    def dma(s):
+        if s < total:
+            if has_bias and wave0 and s % (4 * nk) == 0:
+                ev.append(("vm", ("bias", s // (4 * nk))))   # issue_bias() right before the new tile's first half-tile
+            ev.append(("vm", ("ld", s)))
+            ev.append(("vm", ("ld", s)))                     # two DMA instructions per half-tile
+
+    for s in range(pd):
+        dma(s)
+    if grp == 1:
+        n = _pp_wait_imm(0, total, False, pd)
+        if n is not None:
+            ev.append(("wait", n))
+        ev.append(("bar",))
+    g = 0
+    prev_full = False
+    for j in range(nt):
+        for t in range(nk):
+            for p in (0, 1):
+                if grp == 0:
+                    n = _pp_wait_imm(g, total, prev_full and t == 0, pd)
+                    if n is not None:
+                        ev.append(("wait", n))
+                ev.append(("bar",))
+                if p == 0 and t == 0 and has_bias:
+                    ev.append(("read", ("bias", j)))
+                x = g >> 1
+                for s in ([4 * x, 4 * x + 1, 4 * x + 2] if p == 0 else [4 * x + 3]):
+                    ev.append(("read", ("ld", s)))
+                dma(2 * g + pd)
+                dma(2 * g + 1 + pd)
+                if grp == 1:
+                    n = _pp_wait_imm(g + 1, total, prev_full and t == 0 and p == 0, pd)
+                    if n is not None:
+                        ev.append(("wait", n))
+                ev.append(("bar",))
+                g += 1
+        for _ in range(stores[j]):
+            ev.append(("vm", ("st", j)))
+        prev_full = full[j]
+    if grp == 0:
+        ev.append(("bar",))
+    return ev
+
+
+def _pp_analyse(ev):
+    """-> (issue_bar[tag], done_bar[tag], reads[(tag, bar)]) with bar = barriers executed before the event"""
+    bars, queue, done_upto = 0, [], 0
+    issue_bar, done_bar, reads = {}, {}, []
+    for e in ev:
+        if e[0] == "bar":
+            bars += 1
+        elif e[0] == "vm":
+            queue.append(e[1])
+            issue_bar.setdefault(e[1], bars)
+            issue_bar[("last", e[1])] = bars
+        elif e[0] == "wait":
+            upto = max(done_upto, len(queue) - e[1])
+            for tag in queue[done_upto:upto]:
+                done_bar[tag] = bars            # (a half-tile counts as landed when its SECOND instruction retired)
+            done_upto = upto
+        else:
+            reads.append((e[1], bars))
+    return issue_bar, done_bar, reads, bars
+
+
+def pp_model(nk, nt, full, stores, pd=None, has_bias=True):
+    pd = PD2 if pd is None else pd
+    waves = {(0, True): None, (0, False): None, (1, False): None}   # wave 0 (issues the bias DMA), other group-0 waves, group 1
+    for (grp, w0) in waves:
+        waves[(grp, w0)] = _pp_analyse(_pp_stream(grp, w0, nk, nt, full, stores, pd, has_bias))
+    nbars = {v[3] for v in waves.values()}
+    assert len(nbars) == 1, "barrier counts differ between wave groups"
+    last_read = {}
+    for key, (issue, done, reads, _) in waves.items():
+        for tag, b in reads:
+            last_read[tag] = max(last_read.get(tag, -1), b)
+            for okey, (oissue, odone, _, _) in waves.items():
+                if tag[0] == "bias" and not okey[1]:
+                    continue                     # only wave 0 issued (and must have waited for) the bias DMA
+                assert tag in odone and odone[tag] <= b - 1, f"RAW nk={nk} nt={nt}: {tag} read by {key} not waited by {okey}"
+    for key, (issue, done, reads, _) in waves.items():
+        for tag, b in list(issue.items()):
+            if tag[0] == "ld" and tag[1] >= 8:
+                prev = ("ld", tag[1] - 8)
+            elif tag[0] == "bias" and tag[1] >= 2:
+                prev = ("bias", tag[1] - 2)
+            else:
+                continue
+            assert b >= last_read[prev] + 1, f"WAR nk={nk} nt={nt}: {tag} issued by {key} before the last read of {prev}"
+
+
+@pytest.mark.parametrize("nk", [4, 5, 8, 32])
+@pytest.mark.parametrize("nt", [1, 2, 3, 5])
+def test_persistent_gemm_schedule(nk, nt):
+    pp_model(nk, nt, [True] * nt, [PP_STORES] * nt)                 # interior tiles
+    pp_model(nk, nt, [True] * nt, [2 * PP_STORES] * nt)             # head_dim 32 QKV scatter: more stores than assumed
+    pp_model(nk, nt, [False] * nt, [0] * nt)                        # edge tiles whose rows are all out of range for a wave
+    pp_model(nk, nt, [False] * nt, [PP_STORES] * nt)                # edge tile, but this wave's rows are all valid
+    pp_model(nk, nt, [j % 2 == 0 for j in range(nt)], [PP_STORES if j % 2 == 0 else 3 for j in range(nt)], has_bias=False)
+
+
+def test_persistent_model_detects_miscounted_stores():
+    # claiming PP_STORES younger stores when the wave issued fewer must be caught (this is the one unsafe direction)
+    with pytest.raises(AssertionError, match="RAW"):
+        pp_model(8, 3, [True] * 3, [PP_STORES - 8] * 3)
+    with pytest.raises(AssertionError, match="WAR"):
+        pp_model(8, 3, [True] * 3, [PP_STORES] * 3, pd=8)

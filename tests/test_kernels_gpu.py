@@ -98,6 +98,87 @@ def test_linear_256_tile_kernel(M, N, K, variant, kernel):
     assert rel_err(out, ref) <= 1.2e-2, rel_err(out, ref)
 
 
+@pytest.mark.parametrize("kernel", [0, 9, 12])
+def test_gelu_epilogue_accuracy(kernel):
+    """The bf16 epilogues' GELU (scaled-normal-tail polynomial, not erff) through an identity GEMM: within one bf16 ulp of
+    the exact erf GELU everywhere -- including the negative tail, where 1 + erf cancels -- and bit-equal to the correctly
+    rounded value for almost every input."""
+    K = 256
+    g = torch.linspace(-9.0, 9.0, 256 * K, dtype=torch.float64)
+    g = torch.cat([g, torch.tensor([0.0, -0.0, 1e-30, -1e-30, 20.0, -20.0, 3e4, -3e4], dtype=torch.float64)])
+    g = torch.cat([g, torch.zeros((-g.numel()) % K, dtype=torch.float64)])
+    x = g.view(-1, K).bfloat16()
+    w = torch.eye(K).bfloat16()
+    lib().bt_debug_gemm_variant(kernel)
+    try:
+        y = ops.linear(x.to(DEV), w.to(DEV), act="gelu").cpu().double()
+    finally:
+        lib().bt_debug_gemm_variant(0)
+    xd = x.double()
+    exact = xd * 0.5 * torch.erfc(-xd / math.sqrt(2.0))
+    rounded = exact.bfloat16().double()
+    main = xd > -6.0
+    assert float(((y - exact).abs() - 0.012 * exact.abs())[main].max()) <= 1e-38      # 1.5 bf16 ulp
+    assert float((y - exact).abs()[~main].max()) <= 1e-8           # |gelu(x)| < 6e-9 there
+    assert float((y == rounded)[main].double().mean()) > 0.995
+    assert not torch.isnan(y).any()
+
+
+@pytest.mark.parametrize("M,N,K", [(512, 768, 2048), (1000, 776, 448), (300, 520, 256), (2048, 1024, 512), (256, 2304, 320)])
+@pytest.mark.parametrize("variant", ["plain", "bias", "bias_gelu", "bias_res", "res"])
+@pytest.mark.parametrize("max_wg", [0, 1, 4, 5])
+def test_linear_persistent_kernel(M, N, K, variant, max_wg):
+    """The persistent 256x256 kernel (forced; grid capped so workgroups walk 1..many tiles incl. a partial last round)
+    against fp64: bias folded into the accumulator init, per-wave LDS-patch epilogue, residual joined in fp32, M/N edge
+    tiles (which take the conservative store-count waits)."""
+    x = rnd(M, K, seed=1).bfloat16()
+    w = rnd(N, K, seed=2, scale=K ** -0.5).bfloat16()
+    b = rnd(N, seed=3).bfloat16() if variant.startswith("bias") else None
+    r = rnd(M, N, seed=4).bfloat16() if variant.endswith("res") else None
+    ref = x.double() @ w.double().T
+    if b is not None:
+        ref = ref + b.double()
+    if variant == "bias_gelu":
+        ref = F.gelu(ref)
+    if r is not None:
+        ref = ref + r.double()
+    lib().bt_debug_gemm_variant(12)
+    lib().bt_debug_gemm_max_wg(max_wg)
+    try:
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.linear(x.to(DEV), w.to(DEV), None if b is None else b.to(DEV), None if r is None else r.to(DEV),
+                   act="gelu" if variant == "bias_gelu" else "none", out=out)
+        out = out.cpu()
+    finally:
+        lib().bt_debug_gemm_variant(0)
+        lib().bt_debug_gemm_max_wg(0)
+    assert rel_err(out, ref) <= 1.2e-2, rel_err(out, ref)
+    # element-wise: every output within bf16 rounding of the exact value (catches a single misplaced / stale tile)
+    err = (out.double() - ref).abs()
+    assert float((err - 1.6e-2 * ref.abs() - 2e-2).max()) <= 0, float(err.max())
+
+
+def test_linear_persistent_inplace_residual_and_strides():
+    """hidden += x @ W^T through the persistent kernel, in place (res == out), row strides > row length."""
+    M, N, K = 1024, 512, 256
+    x = rnd(M, K + 64, seed=1).bfloat16().to(DEV)[:, :K]
+    w = rnd(N, K, seed=2, scale=K ** -0.5).bfloat16().to(DEV)
+    hid = rnd(M, N + 128, seed=3).bfloat16().to(DEV)
+    view = hid[:, :N]
+    ref = view.double().cpu() + x.double().cpu() @ w.double().cpu().T
+    pad_before = hid[:, N:].clone()
+    lib().bt_debug_gemm_variant(12)
+    lib().bt_debug_gemm_max_wg(3)
+    try:
+        ops.linear(x, w, None, view, out=view)
+        torch.cuda.synchronize()
+    finally:
+        lib().bt_debug_gemm_variant(0)
+        lib().bt_debug_gemm_max_wg(0)
+    assert rel_err(view.cpu(), ref) <= 1.2e-2
+    assert torch.equal(hid[:, N:], pad_before), "columns beyond N must not be written"
+
+
 def test_linear_256_tile_kernel_repeatable():
     """Race screen: the ring schedule must give bit-identical results run to run (and equal to the 128x128 kernel)."""
     x = rnd(1024, 1024, seed=5).bfloat16().to(DEV)
@@ -105,8 +186,9 @@ def test_linear_256_tile_kernel_repeatable():
     lib().bt_debug_gemm_variant(1)
     base = ops.linear(x, w)
     try:
-        for kernel in (2, 3, 9, 10):
+        for kernel in (2, 3, 9, 10, 12):   # 12 = persistent
             lib().bt_debug_gemm_variant(kernel)
+            lib().bt_debug_gemm_max_wg(5 if kernel == 12 else 0)
             outs = [ops.linear(x, w) for _ in range(20)]
             torch.cuda.synchronize()
             for o in outs:
@@ -114,6 +196,7 @@ def test_linear_256_tile_kernel_repeatable():
             assert torch.equal(outs[0], base), "same fp32 accumulation order per output element -> identical bits"
     finally:
         lib().bt_debug_gemm_variant(0)
+        lib().bt_debug_gemm_max_wg(0)
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 2048, 8192), (3, 256, 2048), (64, 2048, 2048), (200, 512, 1024), (17, 4096, 2048),
@@ -249,11 +332,23 @@ def test_rope_kv_append(dtype, d, rot, use_dev_pos, use_table):
 
 @pytest.mark.parametrize("B,q,pos0,heads", [(3, 1, 5, 2), (2, 7, 0, 2), (40, 2, 3, 16), (1, 300, 0, 4)])
 @pytest.mark.parametrize("use_dev_pos,use_table", [(False, False), (True, False), (False, True)])
-@pytest.mark.parametrize("fused", [True, False])
-def test_qkv_rope_append_fused_epilogue(B, q, pos0, heads, use_dev_pos, use_table, fused):
+@pytest.mark.parametrize("fused,kernel,max_wg", [(True, 0, 0), (False, 0, 0), (True, 9, 0), (True, 12, 0), (True, 12, 2)])
+def test_qkv_rope_append_fused_epilogue(B, q, pos0, heads, use_dev_pos, use_table, fused, kernel, max_wg):
     """QKV projection with RoPE + KV-cache append in the GEMM epilogue (d = 128, rot = 32) == fp64 reference, and ==
     the unfused sequence bt_linear + bt_rope_kv_append within bf16 rounding."""
-    d, rot = 128, 32
+    run_qkv_fused(B, q, pos0, heads, 128, use_dev_pos, use_table, fused, kernel, max_wg)
+
+
+@pytest.mark.parametrize("d,heads", [(32, 8), (64, 4), (96, 4)])
+@pytest.mark.parametrize("kernel,max_wg", [(0, 0), (9, 0), (12, 0), (12, 1)])
+def test_qkv_rope_append_fused_head_dims(d, heads, kernel, max_wg):
+    """Other head sizes through every MFMA kernel's fused epilogue (d = 32: two rotated column groups per 64-column wave
+    slab and a divergent q / cache scatter; d = 96: heads straddle the waves' 64-column slabs)."""
+    run_qkv_fused(5, 61, 2, heads, d, True, True, True, kernel, max_wg)
+
+
+def run_qkv_fused(B, q, pos0, heads, d, use_dev_pos, use_table, fused, kernel, max_wg):
+    rot = 32
     H = heads * d
     n_max = pos0 + q + 2
     x = rnd(B * q, H, seed=1).bfloat16()
@@ -267,6 +362,8 @@ def test_qkv_rope_append_fused_epilogue(B, q, pos0, heads, use_dev_pos, use_tabl
     vc = torch.zeros_like(kc)
     xd, wd, bd = x.to(DEV), w.to(DEV), bias.to(DEV)
     lib().bt_debug_no_qkv_fusion(0 if fused else 1)
+    lib().bt_debug_gemm_variant(kernel)     # 0 heuristic (128^2 tiles at these sizes), 9 one-tile 256^2, 12 persistent 256^2
+    lib().bt_debug_gemm_max_wg(max_wg)
     try:
         check(lib().bt_qkv_rope_append(_lib.BT_BF16, B, q, heads, d, rot, ptr(xd), H, ptr(wd), ptr(bd), ptr(qkv), 3 * H,
                                        ptr(kc), ptr(vc), n_max, ptr(pos_dev), 0 if use_dev_pos else pos0, ptr(table),
@@ -274,6 +371,8 @@ def test_qkv_rope_append_fused_epilogue(B, q, pos0, heads, use_dev_pos, use_tabl
         torch.cuda.synchronize()
     finally:
         lib().bt_debug_no_qkv_fusion(0)
+        lib().bt_debug_gemm_variant(0)
+        lib().bt_debug_gemm_max_wg(0)
     ref = (x.double() @ w.double().T + bias.double()).view(B, q, heads, 3, d)
     rows = torch.arange(pos0, pos0 + q)
     rp = table.cpu()[rows].long() if use_table else rows

@@ -127,13 +127,14 @@ def main():
     elif args.what == "ab":
         # interleaved A/B of the two MFMA kernels on the prefill / large-batch decode shapes
         for (M, N, K) in ((32768, 6144, 2048), (32768, 2048, 2048), (32768, 8192, 2048), (32768, 2048, 8192),
-                          (4096, 6144, 2048), (4096, 8192, 2048), (4096, 2048, 8192), (4096, 50304, 2048),
-                          (8192, 2048, 2048)):
-            for v in (1, 2, 3, 1, 2, 3):
+                          (4096, 8192, 2048), (16384, 2048, 2048), (8192, 8192, 2048)):
+            for v in (9, 0, 9, 0):   # 9 = one tile per workgroup (two-phase ring), 0 = production (persistent)
                 lib().bt_debug_gemm_variant(v)
-                r = probe_gemm(M, N, K, 10 if M > 8000 else 20)
-                r["variant"] = v
-                res.append(r)
+                for kw in ({}, {"act": "gelu"}, {"res": True}):
+                    r = probe_gemm(M, N, K, 10 if M > 8000 else 20, **kw)
+                    r["variant"] = v
+                    r["res"] = bool(kw.get("res"))
+                    res.append(r)
         lib().bt_debug_gemm_variant(0)
     elif args.what == "skinny":
         for M in (1, 8, 64, 128, 256):
