@@ -868,7 +868,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256p2_kernel(const bf16* __
 constexpr int EPI_PITCH = CTile<64>::PITCH;                  // 144 B: 16 rows x (128 B + 16 pad)
 constexpr int PP_EPI_OFF = 8 * HALF_BYTES;                   // after the 128 KiB ring
 constexpr int PP_EPI_WAVE = 16 * EPI_PITCH;
-constexpr int PP_BIAS_OFF = PP_EPI_OFF + 8 * PP_EPI_WAVE;
+constexpr int PP_BIAS_OFF = PP_EPI_OFF + 8 * 2560;   // 8 wave patches (16x16 MFMA: 2304 B, 32x32: 2560 B)
 constexpr int PP_SMEM = PP_BIAS_OFF + 2 * 1024;
 constexpr int PP_STORES = 16;                                // store instructions per wave per full tile
 static_assert(PP_SMEM <= 160 * 1024, "persistent GEMM LDS budget");
@@ -1118,12 +1118,280 @@ __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x
     }
 }
 
+// ---- MFMA shape policies of the persistent kernel -----------------------------------------------------------------------
+// Mma16: v_mfma_f32_16x16x32_bf16, wave tile = 8 x 4 fragments (production).  Mma32: v_mfma_f32_32x32x16_bf16, wave tile =
+// 4 x 2 blocks, four K = 16 steps per K-tile; same LDS image and bytes read per K-tile (a 32-row fragment read is the
+// 16-row one with row = lane & 31 and 16-byte slot = 2 * kstep + (lane >> 5)).  The 32x32 form has the higher
+// micro-benchmark floor (guide: 2382 vs 2075 TF) but measured 5-8 % SLOWER in this two-waves-per-SIMD ping-pong schedule
+// (profiles/r1_gemm_ab_mma32_vs_mma16.jsonl), so it stays a test / A-B variant (bt_debug_gemm_variant(14)).
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+
+__device__ inline bf16x8_t read_frag32(const char* lds_tile, int row_base, int ks, int lane) {
+    const int row = row_base + (lane & 31);
+    const int slot = (ks * 2 + (lane >> 5)) ^ (row & 7);
+    return *reinterpret_cast<const bf16x8_t*>(lds_tile + row * 128 + slot * 16);
+}
+
+__device__ inline f32x4_t bf16x4_to_f32(uint64_t b) {
+    const uint32_t lo = (uint32_t)b, hi = (uint32_t)(b >> 32);
+    return f32x4_t{__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16),
+                   __uint_as_float(hi & 0xffff0000u)};
+}
+
+struct Mma16 {
+    typedef f32x4_t Acc;
+    static constexpr int MI = 4, NB = 4, KS = 2;
+    static constexpr int PATCH_BYTES = PP_EPI_WAVE;
+    __device__ static inline bf16x8_t read_a(const char* half, int wm, int i, int ks, int lane) {
+        return read_frag(half, wm * 64 + i * 16, ks, lane);
+    }
+    __device__ static inline bf16x8_t read_w(const char* half, int wrow, int nb, int ks, int lane) {
+        return read_frag(half, wrow + nb * 16, ks, lane);
+    }
+    __device__ static inline Acc mma(const bf16x8_t& w, const bf16x8_t& a, const Acc& c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, c, 0, 0, 0);
+    }
+    // accumulators <- bias row in LDS (bias_row = LDS byte address of the tile's 256-column bf16 row), or zero
+    __device__ static inline void init(Acc (&acc)[8][4], bool has_bias, uint32_t bias_row, int wcol, int lane) {
+        if (has_bias) {
+            // inline asm: a compiler-visible LDS read of a DMA-written region would get a vmcnt(0) in front
+            uint64_t b[4];
+            const uint32_t ba = bias_row + (wcol + (lane >> 4) * 4) * 2;
+            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:32\n\t"
+                         "ds_read_b64 %2, %4 offset:64\n\tds_read_b64 %3, %4 offset:96\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
+                         : "v"(ba)
+                         : "memory");
+#pragma unroll
+            for (int jf = 0; jf < 4; ++jf) {
+                const f32x4_t bv = bf16x4_to_f32(b[jf]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i][jf] = bv;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int jf = 0; jf < 4; ++jf) acc[i][jf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    template <int MODE>
+    __device__ static inline void epilogue(const EpiArgs& e, int pos0, char* stage, Acc (&acc)[8][4], int cm0, int n_wave,
+                                           int wm, int lane) {
+        pp_epilogue<MODE>(e, pos0, stage, acc, cm0, n_wave, wm, lane);
+    }
+};
+
+// 32x32 blocks: lane holds row m = lane & 31 of the block and, per q = 0..3, the 4 consecutive columns 8q + 4(lane >> 5) + r
+constexpr int EPI32_PITCH = 80;                  // 32 columns x 2 B + 16 pad
+constexpr int PP_EPI32_WAVE = 32 * EPI32_PITCH;  // 2.5 KiB per wave
+static_assert(PP_EPI_OFF + 8 * PP_EPI32_WAVE <= PP_BIAS_OFF && PP_EPI_OFF + 8 * PP_EPI_WAVE <= PP_BIAS_OFF, "wave patches overlap the bias rows");
+
+template <int MODE>
+__device__ inline void pp32_epilogue(const EpiArgs& e, int pos0, char* stage, f32x16_t (&acc)[4][2], int cm0, int n_wave, int wm,
+                                     int lane) {
+    const int M = e.M, N = e.N;
+    constexpr bool qkv = MODE == PP_QKV;
+    const int lrow = lane & 31, lcol = (lane >> 5) * 4;
+    // ---- sweep A: every load of the epilogue, before its first store ----
+    if (qkv) {
+        const int D = e.q.head_dim;
+        bool rot[2];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int n_grp = n_wave + nb * 32;
+            const int head = n_grp / (3 * D);
+            const int within = n_grp - head * 3 * D;
+            const int part = within / D;
+            rot[nb] = part < 2 && within == part * D && n_grp < N;   // dims 0..31 of a q / k head
+        }
+        if (rot[0] || rot[1]) {
+            int rpos[4];
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb) {
+                int m = cm0 + (mb >> 1) * 128 + wm * 64 + (mb & 1) * 32 + lrow;
+                m = m < M ? m : M - 1;
+                rpos[mb] = pos0 + m % e.q.q_len;
+            }
+            if (e.q.pos_table) {
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) rpos[mb] = e.q.pos_table[rpos[mb]];
+            }
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                if (!rot[nb]) continue;
+#pragma unroll
+                for (int hb = 0; hb < 2; ++hb) {
+                    float4 c[2][2], sn[2][2];   // [m-block][q]: table columns 8q + lcol .. + 3
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int64_t off = (int64_t)rpos[hb * 2 + i] * 16 + q * 8 + lcol;
+                            c[i][q] = *reinterpret_cast<const float4*>(e.q.cos_tab + off);
+                            sn[i][q] = *reinterpret_cast<const float4*>(e.q.sin_tab + off);
+                        }
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const float cc[4] = {c[i][q].x, c[i][q].y, c[i][q].z, c[i][q].w};
+                            const float ss[4] = {sn[i][q].x, sn[i][q].y, sn[i][q].z, sn[i][q].w};
+                            f32x16_t& a = acc[hb * 2 + i][nb];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {   // column 8q + lcol + r pairs with the same + 16 = register q + 2
+                                const float x1 = a[q * 4 + r], x2 = a[(q + 2) * 4 + r];
+                                a[q * 4 + r] = x1 * cc[r] - x2 * ss[r];
+                                a[(q + 2) * 4 + r] = x2 * cc[r] + x1 * ss[r];
+                            }
+                        }
+                }
+            }
+        }
+    } else if (MODE == PP_RES) {   // residual joins the fp32 accumulators
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {
+            uint2 rv[2][2][4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int m = cm0 + hb * 128 + wm * 64 + i * 32 + lrow;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = n_wave + nb * 32 + q * 8 + lcol;
+                        rv[i][nb][q] = (m < M && n < N) ? *reinterpret_cast<const uint2*>(e.res + (int64_t)m * e.ldr + n)
+                                                       : uint2{0, 0};
+                    }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x16_t& a = acc[hb * 2 + i][nb];
+                        a[q * 4 + 0] += __uint_as_float(rv[i][nb][q].x << 16);
+                        a[q * 4 + 1] += __uint_as_float(rv[i][nb][q].x & 0xffff0000u);
+                        a[q * 4 + 2] += __uint_as_float(rv[i][nb][q].y << 16);
+                        a[q * 4 + 3] += __uint_as_float(rv[i][nb][q].y & 0xffff0000u);
+                    }
+        }
+    }
+    asm volatile("" ::: "memory");
+    // ---- sweep B: per 32 x 32 block: registers -> wave-private LDS patch -> 16 B per lane along rows -> 2 stores ----
+    const uint32_t patch_w = lds_addr(stage) + lrow * EPI32_PITCH + lcol * 2;
+    const uint32_t patch_r = lds_addr(stage) + (lane >> 2) * EPI32_PITCH + (lane & 3) * 16;
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int row_l = (mb >> 1) * 128 + wm * 64 + (mb & 1) * 32;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            uint2 o[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v[4] = {acc[mb][nb][q * 4], acc[mb][nb][q * 4 + 1], acc[mb][nb][q * 4 + 2], acc[mb][nb][q * 4 + 3]};
+                if (MODE == PP_GELU) gelu4(v);
+                o[q].x = pack_bf16x2(v[0], v[1]);
+                o[q].y = pack_bf16x2(v[2], v[3]);
+            }
+            uint4 v0, v1;
+            asm volatile("ds_write_b64 %2, %4\n\tds_write_b64 %2, %5 offset:16\n\t"
+                         "ds_write_b64 %2, %6 offset:32\n\tds_write_b64 %2, %7 offset:48\n\t"
+                         "s_waitcnt lgkmcnt(0)\n\t"
+                         "ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:%8\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(v0), "=&v"(v1)
+                         : "v"(patch_w), "v"(patch_r), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "n"(16 * EPI32_PITCH)
+                         : "memory");
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint4 v = h ? v1 : v0;
+                const int m = cm0 + row_l + h * 16 + (lane >> 2);
+                const int n = n_wave + nb * 32 + (lane & 3) * 8;
+                if (m < M && n < N) {
+                    bf16* dst;
+                    if (!qkv) {
+                        dst = e.out + (int64_t)m * e.ldo + n;
+                    } else {
+                        const int D = e.q.head_dim;
+                        const int head = n / (3 * D);
+                        const int within = n - head * 3 * D;
+                        const int part = within / D;
+                        const int el = within - part * D;
+                        const int64_t b = m / e.q.q_len;
+                        const int t = m - (int)b * e.q.q_len;
+                        bf16* cache = part == 1 ? e.q.kc : e.q.vc;
+                        dst = part == 0 ? e.out + (int64_t)m * e.ldo + n
+                                        : cache + ((b * e.q.heads + head) * e.q.n_max + pos0 + t) * D + el;
+                    }
+                    *reinterpret_cast<uint4*>(dst) = v;
+                }
+            }
+        }
+    }
+}
+
+struct Mma32 {
+    typedef f32x16_t Acc;
+    static constexpr int MI = 2, NB = 2, KS = 4;
+    static constexpr int PATCH_BYTES = PP_EPI32_WAVE;
+    __device__ static inline bf16x8_t read_a(const char* half, int wm, int i, int ks, int lane) {
+        return read_frag32(half, wm * 64 + i * 32, ks, lane);
+    }
+    __device__ static inline bf16x8_t read_w(const char* half, int wrow, int nb, int ks, int lane) {
+        return read_frag32(half, wrow + nb * 32, ks, lane);
+    }
+    __device__ static inline Acc mma(const bf16x8_t& w, const bf16x8_t& a, const Acc& c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, c, 0, 0, 0);
+    }
+    __device__ static inline void init(Acc (&acc)[4][2], bool has_bias, uint32_t bias_row, int wcol, int lane) {
+        if (has_bias) {
+            uint64_t b[8];   // [nb][q]: columns nb * 32 + 8q + 4 (lane >> 5) .. + 3
+            const uint32_t ba = bias_row + (wcol + (lane >> 5) * 4) * 2;
+            asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:16\n\t"
+                         "ds_read_b64 %2, %8 offset:32\n\tds_read_b64 %3, %8 offset:48\n\t"
+                         "ds_read_b64 %4, %8 offset:64\n\tds_read_b64 %5, %8 offset:80\n\t"
+                         "ds_read_b64 %6, %8 offset:96\n\tds_read_b64 %7, %8 offset:112\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6]),
+                           "=&v"(b[7])
+                         : "v"(ba)
+                         : "memory");
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                f32x16_t bv;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4_t x = bf16x4_to_f32(b[nb * 4 + q]);
+                    bv[q * 4] = x[0]; bv[q * 4 + 1] = x[1]; bv[q * 4 + 2] = x[2]; bv[q * 4 + 3] = x[3];
+                }
+#pragma unroll
+                for (int mb = 0; mb < 4; ++mb) acc[mb][nb] = bv;
+            }
+        } else {
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mb][nb][r] = 0.f;
+        }
+    }
+    template <int MODE>
+    __device__ static inline void epilogue(const EpiArgs& e, int pos0, char* stage, Acc (&acc)[4][2], int cm0, int n_wave,
+                                           int wm, int lane) {
+        pp32_epilogue<MODE>(e, pos0, stage, acc, cm0, n_wave, wm, lane);
+    }
+};
+
 struct LoadCursor {   // wave-uniform: the K-tile whose half-tiles are being issued
     int m0, n0, t, j, x;
     bool valid;
 };
 
-template <int MODE>
+template <int MODE, typename P>
 __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __restrict__ A, int64_t lda,
                                                                  const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
                                                                  int K, int tiles_m, int tiles_n) {
@@ -1136,7 +1404,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
     const int wrow = (wn & 1) * 64;              // its 64-row slab inside the half == 64 contiguous output columns
     const int wcol = wh * 128 + wrow;            // column offset of the wave's output inside the tile
     const bool grp1 = wave >= 4;
-    char* stage = smem + PP_EPI_OFF + wave * PP_EPI_WAVE;
+    char* stage = smem + PP_EPI_OFF + wave * P::PATCH_BYTES;
     const uint32_t lane_slot = (uint32_t)(((lane & 7) ^ ((lane >> 3) & 7)) * 16);
     const uint32_t voff_a = (uint32_t)(lane >> 3) * (uint32_t)(lda * 2) + lane_slot;
     const uint32_t voff_w = (uint32_t)(lane >> 3) * (uint32_t)(ldw * 2) + lane_slot;
@@ -1181,13 +1449,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
     if (lc.t == 0) issue_bias();
     issue(0); issue(1);
 
-    f32x4_t acc[8][4];       // [A half * 4 + m-frag][n-frag]
-    bf16x8_t af[4][2];
-    bf16x8_t wf[4][2];
+    typename P::Acc acc[2 * P::MI][P::NB];   // [A half * MI + m-fragment][n-fragment]
+    bf16x8_t af[P::MI][P::KS];
+    bf16x8_t wf[P::NB][P::KS];
     // fused-QKV mode: the cache write position is constant for the launch -> one scalar, read before the pipeline starts
     int pos0 = 0;
     if (MODE == PP_QKV) pos0 = __builtin_amdgcn_readfirstlane(ep.q.pos0_dev ? *ep.q.pos0_dev : ep.q.pos0_host);
-    const uint32_t bias_lds = lds_addr(smem + PP_BIAS_OFF + (wcol + (lane >> 4) * 4) * 2);
 
     if (grp1) {
         wait_for_phase_pp(0, total, false);
@@ -1205,47 +1472,23 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
                 if (!grp1) wait_for_phase_pp(g, total, prev_full && t == 0);
                 cbarrier();
                 if (p == 0) {
-                    if (t == 0) {   // new tile: accumulators start at the bias (LDS row j & 1, landed before this barrier)
-                        if (ep.bias) {
-                            // inline asm: a compiler-visible LDS read of a DMA-written region would get a vmcnt(0) in front
-                            uint64_t b[4];
-                            const uint32_t ba = bias_lds + (j & 1) * 1024;
-                            asm volatile("ds_read_b64 %0, %4\n\tds_read_b64 %1, %4 offset:32\n\t"
-                                         "ds_read_b64 %2, %4 offset:64\n\tds_read_b64 %3, %4 offset:96\n\t"
-                                         "s_waitcnt lgkmcnt(0)"
-                                         : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
-                                         : "v"(ba)
-                                         : "memory");
+                    // new tile: accumulators start at the bias (LDS row j & 1, landed before this barrier)
+                    if (t == 0) P::init(acc, ep.bias != nullptr, lds_addr(smem + PP_BIAS_OFF + (j & 1) * 1024), wcol, lane);
 #pragma unroll
-                            for (int jf = 0; jf < 4; ++jf) {
-                                const uint32_t lo = (uint32_t)b[jf], hi = (uint32_t)(b[jf] >> 32);
-                                const f32x4_t bv = {__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u),
-                                                    __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+                    for (int ks = 0; ks < P::KS; ++ks) {
 #pragma unroll
-                                for (int i = 0; i < 8; ++i) acc[i][jf] = bv;
-                            }
-                        } else {
+                        for (int nb = 0; nb < P::NB; ++nb)
+                            wf[nb][ks] = P::read_w(buf + (2 + wh) * HALF_BYTES, wrow, nb, ks, lane);
 #pragma unroll
-                            for (int i = 0; i < 8; ++i)
-#pragma unroll
-                                for (int jf = 0; jf < 4; ++jf) acc[i][jf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                        }
-                    }
-#pragma unroll
-                    for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-                        for (int jf = 0; jf < 4; ++jf)
-                            wf[jf][kk] = read_frag(buf + (2 + wh) * HALF_BYTES, wrow + jf * 16, kk, lane);
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) af[i][kk] = read_frag(buf, wm * 64 + i * 16, kk, lane);
+                        for (int i = 0; i < P::MI; ++i) af[i][ks] = P::read_a(buf, wm, i, ks, lane);
                     }
                     issue(2); issue(3);
                     advance();
                 } else {
 #pragma unroll
-                    for (int kk = 0; kk < 2; ++kk)
+                    for (int ks = 0; ks < P::KS; ++ks)
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) af[i][kk] = read_frag(buf + HALF_BYTES, wm * 64 + i * 16, kk, lane);
+                        for (int i = 0; i < P::MI; ++i) af[i][ks] = P::read_a(buf + HALF_BYTES, wm, i, ks, lane);
                     if (lc.t == 0) issue_bias();
                     issue(0); issue(1);
                 }
@@ -1254,13 +1497,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk)
+                for (int ks = 0; ks < P::KS; ++ks)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < P::MI; ++i)
 #pragma unroll
-                        for (int jf = 0; jf < 4; ++jf)
-                            acc[p * 4 + i][jf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[jf][kk], af[i][kk],
-                                                                                         acc[p * 4 + i][jf], 0, 0, 0);
+                        for (int nb = 0; nb < P::NB; ++nb)
+                            acc[p * P::MI + i][nb] = P::mma(wf[nb][ks], af[i][ks], acc[p * P::MI + i][nb]);
                 __builtin_amdgcn_s_setprio(0);
             }
         }
@@ -1268,7 +1510,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
         // the K-loop, which has none to spare): hand it an opaque copy of the lane id
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
-        pp_epilogue<MODE>(ep, pos0, stage, acc, cm0, cn0 + wcol, wm, lane_e);
+        P::template epilogue<MODE>(ep, pos0, stage, acc, cm0, cn0 + wcol, wm, lane_e);
         prev_full = (cm0 + BM2 <= M) && (cn0 + BN2 <= N);
     }
     if (!grp1) cbarrier();
@@ -1420,9 +1662,15 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                                        (!residual || (ldr % 8 == 0 && aligned16(residual))) && (!bias || aligned16(bias));
                     if (pp_ok) {   // production: persistent, per-wave epilogue
                         const int n_wg = (int)std::min<int64_t>((int64_t)tiles_m * tiles_n, g_max_wg > 0 ? g_max_wg : num_cus());
-#define BT_LAUNCH_PP(MODE_)                                                                                          \
-    hipLaunchKernelGGL(gemm_bf16_mfma256pp_kernel<MODE_>, dim3(n_wg), dim3(512), 0, s, (const bf16*)A, lda, (const bf16*)W, \
-                       K, ep, (int)K, tiles_m, tiles_n)
+#define BT_LAUNCH_PP(MODE_)                                                                                           \
+    do {                                                                                                              \
+        if (g_gemm_variant == 14)   /* A/B: 32x32x16 MFMA blocks (measured 5-8 % slower in this schedule) */        \
+            hipLaunchKernelGGL((gemm_bf16_mfma256pp_kernel<MODE_, Mma32>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A, \
+                               lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                 \
+        else                                                                                                          \
+            hipLaunchKernelGGL((gemm_bf16_mfma256pp_kernel<MODE_, Mma16>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A, \
+                               lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                 \
+    } while (0)
                         // (the engine never combines these: QKV has no activation / residual, GELU has no residual)
                         if (ep.q.enabled) BT_LAUNCH_PP(PP_QKV);
                         else if (act == BT_ACT_GELU && !residual) BT_LAUNCH_PP(PP_GELU);

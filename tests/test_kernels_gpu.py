@@ -98,7 +98,7 @@ def test_linear_256_tile_kernel(M, N, K, variant, kernel):
     assert rel_err(out, ref) <= 1.2e-2, rel_err(out, ref)
 
 
-@pytest.mark.parametrize("kernel", [0, 9, 12])
+@pytest.mark.parametrize("kernel", [0, 9, 12, 14])
 def test_gelu_epilogue_accuracy(kernel):
     """The bf16 epilogues' GELU (scaled-normal-tail polynomial, not erff) through an identity GEMM: within one bf16 ulp of
     the exact erf GELU everywhere -- including the negative tail, where 1 + erf cancels -- and bit-equal to the correctly
@@ -127,10 +127,11 @@ def test_gelu_epilogue_accuracy(kernel):
 @pytest.mark.parametrize("M,N,K", [(512, 768, 2048), (1000, 776, 448), (300, 520, 256), (2048, 1024, 512), (256, 2304, 320)])
 @pytest.mark.parametrize("variant", ["plain", "bias", "bias_gelu", "bias_res", "res"])
 @pytest.mark.parametrize("max_wg", [0, 1, 4, 5])
-def test_linear_persistent_kernel(M, N, K, variant, max_wg):
+@pytest.mark.parametrize("kernel", [12, 14])
+def test_linear_persistent_kernel(M, N, K, variant, max_wg, kernel):
     """The persistent 256x256 kernel (forced; grid capped so workgroups walk 1..many tiles incl. a partial last round)
     against fp64: bias folded into the accumulator init, per-wave LDS-patch epilogue, residual joined in fp32, M/N edge
-    tiles (which take the conservative store-count waits)."""
+    tiles (which take the conservative store-count waits).  kernel 12 = production (16x16x32 MFMA fragments), 14 = 32x32x16 blocks."""
     x = rnd(M, K, seed=1).bfloat16()
     w = rnd(N, K, seed=2, scale=K ** -0.5).bfloat16()
     b = rnd(N, seed=3).bfloat16() if variant.startswith("bias") else None
@@ -142,7 +143,7 @@ def test_linear_persistent_kernel(M, N, K, variant, max_wg):
         ref = F.gelu(ref)
     if r is not None:
         ref = ref + r.double()
-    lib().bt_debug_gemm_variant(12)
+    lib().bt_debug_gemm_variant(kernel)
     lib().bt_debug_gemm_max_wg(max_wg)
     try:
         out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
@@ -186,14 +187,18 @@ def test_linear_256_tile_kernel_repeatable():
     lib().bt_debug_gemm_variant(1)
     base = ops.linear(x, w)
     try:
-        for kernel in (2, 3, 9, 10, 12):   # 12 = persistent
+        for kernel in (2, 3, 9, 10, 12, 14):   # 12 / 14 = persistent (16x16x32 / 32x32x16 MFMA)
             lib().bt_debug_gemm_variant(kernel)
-            lib().bt_debug_gemm_max_wg(5 if kernel == 12 else 0)
+            lib().bt_debug_gemm_max_wg(5 if kernel >= 12 else 0)
             outs = [ops.linear(x, w) for _ in range(20)]
             torch.cuda.synchronize()
             for o in outs:
                 assert torch.equal(o, outs[0]), kernel
-            assert torch.equal(outs[0], base), "same fp32 accumulation order per output element -> identical bits"
+            if kernel == 14:   # 32x32x16 MFMA sums K in 16-wide steps: same values up to fp32 summation order
+                diff = (outs[0].float() - base.float()).abs()
+                assert float((diff > 0).float().mean()) < 2e-2 and float((diff - 0.008 * base.float().abs()).max()) <= 1e-6
+            else:
+                assert torch.equal(outs[0], base), "same fp32 accumulation order per output element -> identical bits"
     finally:
         lib().bt_debug_gemm_variant(0)
         lib().bt_debug_gemm_max_wg(0)
@@ -332,7 +337,8 @@ def test_rope_kv_append(dtype, d, rot, use_dev_pos, use_table):
 
 @pytest.mark.parametrize("B,q,pos0,heads", [(3, 1, 5, 2), (2, 7, 0, 2), (40, 2, 3, 16), (1, 300, 0, 4)])
 @pytest.mark.parametrize("use_dev_pos,use_table", [(False, False), (True, False), (False, True)])
-@pytest.mark.parametrize("fused,kernel,max_wg", [(True, 0, 0), (False, 0, 0), (True, 9, 0), (True, 12, 0), (True, 12, 2)])
+@pytest.mark.parametrize("fused,kernel,max_wg", [(True, 0, 0), (False, 0, 0), (True, 9, 0), (True, 12, 0), (True, 12, 2),
+                                                 (True, 14, 2)])
 def test_qkv_rope_append_fused_epilogue(B, q, pos0, heads, use_dev_pos, use_table, fused, kernel, max_wg):
     """QKV projection with RoPE + KV-cache append in the GEMM epilogue (d = 128, rot = 32) == fp64 reference, and ==
     the unfused sequence bt_linear + bt_rope_kv_append within bf16 rounding."""
@@ -340,7 +346,7 @@ def test_qkv_rope_append_fused_epilogue(B, q, pos0, heads, use_dev_pos, use_tabl
 
 
 @pytest.mark.parametrize("d,heads", [(32, 8), (64, 4), (96, 4)])
-@pytest.mark.parametrize("kernel,max_wg", [(0, 0), (9, 0), (12, 0), (12, 1)])
+@pytest.mark.parametrize("kernel,max_wg", [(0, 0), (9, 0), (12, 0), (12, 1), (14, 1)])
 def test_qkv_rope_append_fused_head_dims(d, heads, kernel, max_wg):
     """Other head sizes through every MFMA kernel's fused epilogue (d = 32: two rotated column groups per 64-column wave
     slab and a divergent q / cache scatter; d = 96: heads straddle the waves' 64-column slabs)."""

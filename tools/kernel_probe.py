@@ -107,6 +107,7 @@ def main():
     ap.add_argument("--keys", type=int, default=528)
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--split", type=int, default=1)
+    ap.add_argument("--ab-other", type=int, default=9, help="GEMM variant compared with production in `ab`")
     ap.add_argument("--variant", type=int, default=0, help="bt_debug_gemm_variant: 0 auto, 1 128^2 kernel, 2 256^2 kernel")
     args = ap.parse_args()
     res = []
@@ -128,7 +129,7 @@ def main():
         # interleaved A/B of the two MFMA kernels on the prefill / large-batch decode shapes
         for (M, N, K) in ((32768, 6144, 2048), (32768, 2048, 2048), (32768, 8192, 2048), (32768, 2048, 8192),
                           (4096, 8192, 2048), (16384, 2048, 2048), (8192, 8192, 2048)):
-            for v in (9, 0, 9, 0):   # 9 = one tile per workgroup (two-phase ring), 0 = production (persistent)
+            for v in (args.ab_other, 0, args.ab_other, 0):   # e.g. 9 = one tile per workgroup, 14 = 32x32x16 MFMA; 0 = production
                 lib().bt_debug_gemm_variant(v)
                 for kw in ({}, {"act": "gelu"}, {"res": True}):
                     r = probe_gemm(M, N, K, 10 if M > 8000 else 20, **kw)
