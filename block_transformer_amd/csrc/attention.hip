@@ -123,7 +123,7 @@ __device__ inline float block_sum(float v, float* red, int wave, int lane) {
     return r;
 }
 
-template <typename T, int D, int NW>
+template <typename T, int D, int NW, bool NT = false>
 __global__ __launch_bounds__(NW * 64) void attend_rows_kernel(const T* __restrict__ qkv, int64_t ld_qkv,
                                                              const T* __restrict__ kc, const T* __restrict__ vc,
                                                              int64_t n_max, const int32_t* __restrict__ pos0_dev,
@@ -169,7 +169,8 @@ __global__ __launch_bounds__(NW * 64) void attend_rows_kernel(const T* __restric
         for (int u = 0; u < U; ++u) {
             int r = rb + u * NW * RPW + sub;
             r = r < k1 ? r : k1 - 1;
-            load_vec<T>(kbase + (int64_t)r * D, kv[u]);
+            if (NT) load_vec_nt<T>(kbase + (int64_t)r * D, kv[u]);
+            else load_vec<T>(kbase + (int64_t)r * D, kv[u]);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -206,7 +207,8 @@ __global__ __launch_bounds__(NW * 64) void attend_rows_kernel(const T* __restric
             int r = rb + u * NW * RPW + sub;
             const bool ok = r < k1;
             r = ok ? r : k1 - 1;
-            load_vec<T>(vbase + (int64_t)r * D, vv[u]);
+            if (NT) load_vec_nt<T>(vbase + (int64_t)r * D, vv[u]);
+            else load_vec<T>(vbase + (int64_t)r * D, vv[u]);
             p[u] = ok ? sc[r - k0] : 0.f;
         }
 #pragma unroll
@@ -695,6 +697,8 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_v2_kernel(const bf16* __
 }
 
 // ---- host dispatch ------------------------------------------------------------------------------------------------------
+static int g_attn_nt = 0;   // A/B hook: non-temporal K/V loads in the global (NW = 4) streaming kernel
+
 template <typename T, int D>
 static int launch_attend(int64_t B, int q_len, int heads, const void* qkv, int64_t ld_qkv, const void* kc, const void* vc,
                          int64_t n_max, const int32_t* pos0_dev, int pos0_host, const uint8_t* mask, int64_t mask_ld,
@@ -714,9 +718,14 @@ static int launch_attend(int64_t B, int q_len, int heads, const void* qkv, int64
             set_error("bt_attention: %lld keys per split need %zu B of LDS; raise n_split", (long long)cap, shm);
             return BT_ERR_ARG;
         }
-        hipLaunchKernelGGL((attend_rows_kernel<T, D, 4>), grid, dim3(256), shm, s, (const T*)qkv, ld_qkv, (const T*)kc,
-                           (const T*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (T*)out, ldo, ws, q_len, heads,
-                           n_split, scale);
+        if (g_attn_nt)
+            hipLaunchKernelGGL((attend_rows_kernel<T, D, 4, true>), grid, dim3(256), shm, s, (const T*)qkv, ld_qkv,
+                               (const T*)kc, (const T*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (T*)out, ldo, ws, q_len,
+                               heads, n_split, scale);
+        else
+            hipLaunchKernelGGL((attend_rows_kernel<T, D, 4>), grid, dim3(256), shm, s, (const T*)qkv, ld_qkv, (const T*)kc,
+                               (const T*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (T*)out, ldo, ws, q_len, heads,
+                               n_split, scale);
     }
     BT_LAUNCH_CHECK("bt_attention(rows) launch");
     if (n_split > 1) {
@@ -839,3 +848,4 @@ extern "C" int bt_attention(int dtype, int mode, int64_t B, int32_t q_len, int32
 }
 
 extern "C" void bt_debug_flash_variant(int v) { bt::g_flash_variant = v; }
+extern "C" void bt_debug_attn_nt(int v) { bt::g_attn_nt = v; }

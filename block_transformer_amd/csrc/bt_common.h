@@ -92,6 +92,23 @@ __device__ inline void load_vec<bf16>(const bf16* p, float (&v)[8]) {
     v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
     v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
 }
+// streaming (non-temporal) variants: read-once K/V streams should not displace reusable lines in L2 / MALL
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ inline void load_vec_nt(const T* p, float (&v)[Elem<T>::VEC]);
+template <>
+__device__ inline void load_vec_nt<float>(const float* p, float (&v)[4]) {
+    const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    v[0] = __uint_as_float(t.x); v[1] = __uint_as_float(t.y); v[2] = __uint_as_float(t.z); v[3] = __uint_as_float(t.w);
+}
+template <>
+__device__ inline void load_vec_nt<bf16>(const bf16* p, float (&v)[8]) {
+    const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+    v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
+    v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+}
 template <typename T>
 __device__ inline void store_vec(T* p, const float (&v)[Elem<T>::VEC]);
 template <>

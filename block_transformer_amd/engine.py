@@ -18,6 +18,8 @@ from __future__ import annotations
 import math
 from typing import Optional
 
+import os
+
 import torch
 
 from . import _lib, ops
@@ -102,7 +104,7 @@ class TokenBlockState:
 class DecodeEngine:
     """Everything ``BlockTransformer.generate`` needs for one (batch, max_blocks) problem size."""
 
-    def __init__(self, model, batch: int, max_blocks: int, rope_policy: str = "train", prefill_rows: int = 32768):
+    def __init__(self, model, batch: int, max_blocks: int, rope_policy: str = "train", prefill_rows: Optional[int] = None):
         self.model = model
         bd, td, emb = model.block_decoder, model.token_decoder, model.embedder
         self.bd_rt: DecoderRuntime = bd._rt
@@ -127,7 +129,7 @@ class DecodeEngine:
         self.stream = torch.cuda.Stream(device=dev)                       # graphs cannot be captured on the null stream
         self.n_cur = torch.zeros(1, dtype=torch.int32, device=dev)       # cached block positions == index of next block
         # prefill is chunked over sequences so the activation workspace stays bounded
-        self.prefill_rows = prefill_rows
+        self.prefill_rows = int(prefill_rows or os.environ.get("BT_PREFILL_ROWS", 32768))
         self.ws_step = torch.empty(self.bd_rt.workspace_bytes(batch), dtype=torch.uint8, device=dev)
         self.ws_prefill: Optional[torch.Tensor] = None
         # split-N ("flash-decoding") for the global step when B*heads is too small to fill 256 CUs

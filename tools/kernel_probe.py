@@ -99,7 +99,7 @@ def probe_copy(nbytes, iters):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["gemm", "attn", "flash", "suite", "copy", "ab", "abl", "skinny"])
+    ap.add_argument("what", choices=["gemm", "attn", "flash", "suite", "copy", "ab", "abl", "skinny", "decode", "vendor"])
     ap.add_argument("--m", type=int, default=32768)
     ap.add_argument("--n", type=int, default=6144)
     ap.add_argument("--k", type=int, default=2048)
@@ -115,7 +115,12 @@ def main():
     if args.what == "gemm":
         res.append(probe_gemm(args.m, args.n, args.k, args.iters))
     elif args.what == "attn":
-        res.append(probe_attn(args.batch, args.keys, args.iters, n_split=args.split))
+        for nt in (0, 1, 0, 1):
+            lib().bt_debug_attn_nt(nt)
+            r = probe_attn(args.batch, args.keys, args.iters, n_split=args.split)
+            r["nontemporal"] = nt
+            res.append(r)
+        lib().bt_debug_attn_nt(0)
     elif args.what == "flash":
         for v in (0, 1, 0, 1):
             lib().bt_debug_flash_variant(v)
@@ -137,16 +142,46 @@ def main():
                     r["res"] = bool(kw.get("res"))
                     res.append(r)
         lib().bt_debug_gemm_variant(0)
+    elif args.what == "decode":
+        # decode-regime GEMMs (M = batch): dispatch heuristic (0) vs forced persistent 256^2 (12) vs forced 128^2 (1)
+        for (M, N, K) in ((4096, 6144, 2048), (4096, 2048, 2048), (4096, 8192, 2048), (4096, 2048, 8192),
+                          (4096, 50304, 2048), (2048, 6144, 2048), (2048, 8192, 2048), (1024, 8192, 2048)):
+            for v in (0, 12, 1, 0, 12, 1):
+                lib().bt_debug_gemm_variant(v)
+                r = probe_gemm(M, N, K, 20, bias=(N != 50304))
+                r["variant"] = v
+                res.append(r)
+        lib().bt_debug_gemm_variant(0)
+    elif args.what == "vendor":
+        # calibration: this library's bt_linear vs torch's bf16 F.linear (hipBLASLt / rocBLAS under PyTorch-ROCm), same box,
+        # same inputs, interleaved.  Not part of the product path -- a yardstick for the MFMA roofline fraction.
+        import torch.nn.functional as F
+        for (M, N, K) in ((32768, 6144, 2048), (32768, 2048, 2048), (32768, 8192, 2048), (32768, 2048, 8192),
+                          (4096, 6144, 2048), (4096, 2048, 2048), (4096, 8192, 2048), (4096, 2048, 8192), (4096, 50304, 2048)):
+            x = torch.randn(M, K, device=DEV).bfloat16()
+            w = (torch.randn(N, K, device=DEV) * K ** -0.5).bfloat16()
+            b = torch.randn(N, device=DEV).bfloat16()
+            out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+            it = 10 if M > 8000 else 20
+            for rep in range(2):
+                ms_bt = timed(lambda: ops.linear(x, w, b, out=out), it)
+                ms_v = timed(lambda: F.linear(x, w, b), it)
+                fl = 2.0 * M * N * K
+                res.append({"op": "gemm_vs_vendor", "M": M, "N": N, "K": K, "bt_linear_TFLOPs": round(fl / ms_bt / 1e9, 1),
+                            "torch_F_linear_TFLOPs": round(fl / ms_v / 1e9, 1), "ratio": round(ms_v / ms_bt, 3)})
+            ref = F.linear(x, w, b).float()
+            err = float((out.float() - ref).abs().max() / ref.abs().max())
+            res[-1]["max_rel_diff_vs_vendor"] = err
     elif args.what == "skinny":
         for M in (1, 8, 64, 128, 256):
             for (N, K) in ((6144, 2048), (2048, 2048), (8192, 2048), (2048, 8192), (4096, 2048)):
                 for sc in (False, True):
                     res.append(probe_gemm(M, N, K, 30, scratch=sc))
     elif args.what == "abl":
-        for (M, N, K) in ((32768, 6144, 2048), (32768, 2048, 8192), (32768, 2048, 2048)):
-            for v in (9, 11, 9, 11, 9, 11):
+        for (M, N, K) in ((32768, 6144, 2048), (32768, 2048, 8192)):
+            for v in (0, 16, 17, 18, 12, 0, 16, 17, 18, 12):   # w4: full / no DMA / no ds_read / neither; 12 = 8-wave kernel
                 lib().bt_debug_gemm_variant(v)
-                r = probe_gemm(M, N, K, 10)
+                r = probe_gemm(M, N, K, 10, bias=False)
                 r["variant"] = v
                 res.append(r)
         lib().bt_debug_gemm_variant(0)
