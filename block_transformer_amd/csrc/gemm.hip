@@ -17,7 +17,6 @@
 #include "bt_common.h"
 
 #include <algorithm>
-#include <type_traits>
 
 namespace bt {
 
@@ -1517,506 +1516,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
     if (!grp1) cbarrier();
 }
 
-// ---- 256x256 persistent kernel, ONE wave per SIMD (production) ---------------------------------------------------------
-// 4 waves x (128 x 128 output, 256 fp32 accumulators, up to 512 registers per lane).  Compared with the 8-wave ping-pong
-// kernel above: 128 KiB instead of 192 KiB of LDS fragment reads per K = 64 (a wave's 128 x 128 tile reuses every fragment
-// 8 times), one barrier per 64 MFMAs among 4 waves instead of two among 8, and no phase hand-over between two waves of a
-// SIMD -- the wave itself issues next-step ds_reads and LDS-DMAs in the shadow of its MFMAs.
-//   step g (K = 32):   wait own share of K-tile g+1 ; barrier ; ds_read fragments F(g+1) <- ring[(g+1)&3] ;
-//                      LDS-DMA K-tile g+4 -> ring[g&3] ; 64 MFMAs on F(g) (registers, read during step g-1)
-// Ring = 4 x 32 KiB buffers [A rows 0..255 | W rows 0..255] x 64 B (K = 32).  A row's four 16-byte k-slots are XOR-ed with
-// (row >> 2) & 3 (on the DMA source address and on the ds_read address), which makes the 16 rows x 16 B of a ds_read_b128
-// lane group cover all 64 banks once.  RAW: every wave waits for its own DMA share of K-tile g+1 (counted vmcnt: two
-// younger K-tiles = 16 instructions stay in flight, so a load has 3 steps ~ 1.6 us to land) before barrier g.  WAR:
-// ring[g&3] was last read for F(g) during step g-1; each wave drains lgkmcnt before barrier g and refills after it.
-// The load stream, bias row, per-wave epilogue patch and in-order store accounting work as in the 8-wave kernel
-// (W4_STORES = 32 store instructions per wave and full tile: 8 fragments rows x 4).
-constexpr int W4_KT = 32;
-constexpr int W4_BUF = 512 * W4_KT * 2;                   // 32 KiB
-constexpr int W4_PITCH = 256 + 16;                        // patch row: 128 bf16 + 16 B pad
-constexpr int W4_PATCH = 16 * W4_PITCH;
-constexpr int W4_EPI_OFF = 4 * W4_BUF;
-constexpr int W4_BIAS_OFF = W4_EPI_OFF + 4 * W4_PATCH;
-constexpr int W4_SMEM = W4_BIAS_OFF + 2 * 1024;
-constexpr int W4_STORES = 32;
-static_assert(W4_SMEM <= 160 * 1024, "one-wave-per-SIMD GEMM LDS budget");
-
-template <int N>
-__device__ inline void wait_vmcnt_w4() {
-    if constexpr (N == 48) asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-    else if constexpr (N == 40) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-    else if constexpr (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-}
-
-// before barrier g: this wave's 8 DMA instructions of K-tile g+1 have landed; K-tiles g+2, g+3 (8 instructions each) and,
-// for the first three steps after a full tile's epilogue, its W4_STORES stores may stay in flight
-__device__ inline void w4_wait(int g, int total, bool stores_younger) {
-    if (g + 1 >= total) return;
-    // K-tiles g+2 and g+3 have always been issued (past the end of the work the cursor re-issues the last tile)
-    static_assert(W4_STORES == 32, "vmcnt immediates here and in w4_step_rl assume 32 stores");
-    if (stores_younger) wait_vmcnt_w4<48>();
-    else wait_vmcnt_w4<16>();
-}
-
-template <int MODE>
-__device__ inline void w4_epilogue(const EpiArgs& e, int pos0, char* stage, f32x4_t (&acc)[8][8], int m_wave, int n_wave,
-                                   int lane, uint32_t bias_row /* LDS address of the wave's 128 bias columns (bf16) */) {
-    constexpr bool qkv = MODE == PP_QKV;
-    const int lrow = lane & 15, lcol = (lane >> 4) * 4;
-    // bias of the lane's 8 x 4 columns (fp32), added on the way out (the accumulators start at 0)
-    f32x4_t bv[8];
-    if (e.bias) {
-        uint64_t b[8];
-        const uint32_t ba = bias_row + lcol * 2;
-        asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:32\n\t"
-                     "ds_read_b64 %2, %8 offset:64\n\tds_read_b64 %3, %8 offset:96\n\t"
-                     "ds_read_b64 %4, %8 offset:128\n\tds_read_b64 %5, %8 offset:160\n\t"
-                     "ds_read_b64 %6, %8 offset:192\n\tds_read_b64 %7, %8 offset:224\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3]), "=&v"(b[4]), "=&v"(b[5]), "=&v"(b[6]), "=&v"(b[7])
-                     : "v"(ba)
-                     : "memory");
-#pragma unroll
-        for (int ni = 0; ni < 8; ++ni) bv[ni] = bf16x4_to_f32(b[ni]);
-    } else {
-#pragma unroll
-        for (int ni = 0; ni < 8; ++ni) bv[ni] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-    }
-    // ---- sweep A: every load of the epilogue, before its first store ----
-    if (qkv) {
-        const int D = e.q.head_dim;
-        bool rot[4];
-        bool any = false;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int n_grp = n_wave + p * 32;
-            const int head = n_grp / (3 * D);
-            const int within = n_grp - head * 3 * D;
-            const int part = within / D;
-            rot[p] = part < 2 && within == part * D;   // dims 0..31 of a q / k head
-            any = any || rot[p];
-        }
-        if (any) {
-            int rpos[8];
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi) {
-                const int m = m_wave + mi * 16 + lrow;
-                rpos[mi] = pos0 + m % e.q.q_len;
-            }
-            if (e.q.pos_table) {
-#pragma unroll
-                for (int mi = 0; mi < 8; ++mi) rpos[mi] = e.q.pos_table[rpos[mi]];
-            }
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                if (!rot[p]) continue;
-                float4 c[8], sn[8];
-#pragma unroll
-                for (int mi = 0; mi < 8; ++mi) {
-                    const int64_t off = (int64_t)rpos[mi] * 16 + lcol;
-                    c[mi] = *reinterpret_cast<const float4*>(e.q.cos_tab + off);
-                    sn[mi] = *reinterpret_cast<const float4*>(e.q.sin_tab + off);
-                }
-#pragma unroll
-                for (int mi = 0; mi < 8; ++mi) {
-                    const float cc[4] = {c[mi].x, c[mi].y, c[mi].z, c[mi].w};
-                    const float ss[4] = {sn[mi].x, sn[mi].y, sn[mi].z, sn[mi].w};
-                    asm volatile("" : "+a"(acc[mi][2 * p]), "+a"(acc[mi][2 * p + 1]));   // bound the AGPR -> VGPR copies
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {   // column e pairs with e + 16 = the next 16-column fragment, same register
-                        const float x1 = acc[mi][2 * p][r] + bv[2 * p][r], x2 = acc[mi][2 * p + 1][r] + bv[2 * p + 1][r];
-                        acc[mi][2 * p][r] = x1 * cc[r] - x2 * ss[r];
-                        acc[mi][2 * p + 1][r] = x2 * cc[r] + x1 * ss[r];
-                    }
-                    asm volatile("" : "+a"(acc[mi][2 * p]), "+a"(acc[mi][2 * p + 1]));
-                }
-            }
-        }
-    } else if (MODE == PP_RES) {   // residual joins the fp32 accumulators
-#pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
-            uint2 rv[4][8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m_wave + (hb * 4 + i) * 16 + lrow;
-#pragma unroll
-                for (int ni = 0; ni < 8; ++ni) {
-                    const int n = n_wave + ni * 16 + lcol;
-                    rv[i][ni] = *reinterpret_cast<const uint2*>(e.res + (int64_t)m * e.ldr + n);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                f32x4_t(&row)[8] = acc[hb * 4 + i];
-                asm volatile("" : "+a"(row[0]), "+a"(row[1]), "+a"(row[2]), "+a"(row[3]), "+a"(row[4]), "+a"(row[5]), "+a"(row[6]),
-                                  "+a"(row[7]));   // bound the AGPR -> VGPR copies to one fragment row
-#pragma unroll
-                for (int ni = 0; ni < 8; ++ni) {
-                    row[ni][0] += __uint_as_float(rv[i][ni].x << 16);
-                    row[ni][1] += __uint_as_float(rv[i][ni].x & 0xffff0000u);
-                    row[ni][2] += __uint_as_float(rv[i][ni].y << 16);
-                    row[ni][3] += __uint_as_float(rv[i][ni].y & 0xffff0000u);
-                }
-                asm volatile("" : "+a"(row[0]), "+a"(row[1]), "+a"(row[2]), "+a"(row[3]), "+a"(row[4]), "+a"(row[5]), "+a"(row[6]),
-                                  "+a"(row[7]));
-            }
-        }
-    }
-    if (qkv) {   // rotated fragments already carry their bias
-        const int D = e.q.head_dim;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int n_grp = n_wave + p * 32;
-            const int within = n_grp % (3 * D);
-            const int part = within / D;
-            if (part < 2 && within == part * D) {
-                bv[2 * p] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-                bv[2 * p + 1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            }
-        }
-    }
-    asm volatile("" ::: "memory");
-    // ---- sweep B: per 16-row fragment row: registers -> wave-private patch -> 16 B per lane along rows -> 4 stores ----
-    const uint32_t patch_w = lds_addr(stage) + lrow * W4_PITCH + lcol * 2;
-    const uint32_t patch_r = lds_addr(stage) + (lane >> 4) * W4_PITCH + (lane & 15) * 16;
-#pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-        // keep one fragment row's accumulator reads (AGPR -> VGPR) live at a time: the values pass through an ordered
-        // asm, so their copies cannot be hoisted above the previous row's patch round trip
-        asm volatile("" : "+a"(acc[mi][0]), "+a"(acc[mi][1]), "+a"(acc[mi][2]), "+a"(acc[mi][3]), "+a"(acc[mi][4]),
-                          "+a"(acc[mi][5]), "+a"(acc[mi][6]), "+a"(acc[mi][7]));
-        uint2 o[8];
-#pragma unroll
-        for (int ni = 0; ni < 8; ++ni) {
-            float v[4] = {acc[mi][ni][0] + bv[ni][0], acc[mi][ni][1] + bv[ni][1], acc[mi][ni][2] + bv[ni][2],
-                          acc[mi][ni][3] + bv[ni][3]};
-            if (MODE == PP_GELU) gelu4(v);
-            o[ni].x = pack_bf16x2(v[0], v[1]);
-            o[ni].y = pack_bf16x2(v[2], v[3]);
-        }
-        uint4 vv[4];
-        asm volatile("ds_write_b64 %4, %6\n\tds_write_b64 %4, %7 offset:32\n\t"
-                     "ds_write_b64 %4, %8 offset:64\n\tds_write_b64 %4, %9 offset:96\n\t"
-                     "ds_write_b64 %4, %10 offset:128\n\tds_write_b64 %4, %11 offset:160\n\t"
-                     "ds_write_b64 %4, %12 offset:192\n\tds_write_b64 %4, %13 offset:224\n\t"
-                     "s_waitcnt lgkmcnt(0)\n\t"
-                     "ds_read_b128 %0, %5\n\tds_read_b128 %1, %5 offset:%14\n\t"
-                     "ds_read_b128 %2, %5 offset:%15\n\tds_read_b128 %3, %5 offset:%16\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(vv[0]), "=&v"(vv[1]), "=&v"(vv[2]), "=&v"(vv[3])
-                     : "v"(patch_w), "v"(patch_r), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "v"(o[4]), "v"(o[5]), "v"(o[6]),
-                       "v"(o[7]), "n"(4 * W4_PITCH), "n"(8 * W4_PITCH), "n"(12 * W4_PITCH)
-                     : "memory");
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-            const int m = m_wave + mi * 16 + h * 4 + (lane >> 4);
-            const int n = n_wave + (lane & 15) * 8;
-            {   // no bounds checks: the kernel runs only on M % 256 == 0, N % 256 == 0 (straight-line epilogue)
-                bf16* dst;
-                if (!qkv) {
-                    dst = e.out + (int64_t)m * e.ldo + n;
-                } else {
-                    const int D = e.q.head_dim;
-                    const int head = n / (3 * D);
-                    const int within = n - head * 3 * D;
-                    const int part = within / D;
-                    const int el = within - part * D;
-                    const int64_t b = m / e.q.q_len;
-                    const int t = m - (int)b * e.q.q_len;
-                    bf16* cache = part == 1 ? e.q.kc : e.q.vc;
-                    dst = part == 0 ? e.out + (int64_t)m * e.ldo + n
-                                    : cache + ((b * e.q.heads + head) * e.q.n_max + pos0 + t) * D + el;
-                }
-                *reinterpret_cast<uint4*>(dst) = vv[h];
-            }
-        }
-    }
-}
-
-// one step of the K-loop: straight-line code, no branches.  Source order is the issue order (sched_barrier pins it): each
-// group of 4 MFMAs is preceded by the fillers that ride in the matrix pipe's shadow -- one fragment ds_read_b128 per group
-// (F(g+1), 16 per step) and one LDS-DMA per group in the first half of the step (K-tile g+4, this wave's 8 instructions).
-// The kernel is only dispatched for M % 256 == 0 and N % 256 == 0 (no row clamping); past the workgroup's last K-tile the
-// cursor stays on it, so the trailing DMAs re-load valid data into ring buffers nobody reads again.
-struct W4Dma {          // wave-uniform: this wave's share of the K-tile to prefetch
-    const char* a;      // A + ((m0 + wave * 64) * lda + k0) * 2
-    const char* w;
-    int64_t sa, sw;     // byte stride between 16-row groups
-    uint32_t dst;       // LDS byte address of the wave's A rows in the target ring buffer (W rows: + 256 * 64)
-};
-
-// ABL (timing experiments only, results are wrong): 1 = no LDS-DMA in the steady state, 2 = no fragment ds_reads
-template <int ABL, bool FIRST>
-__device__ inline void w4_step(f32x4_t (&acc)[8][8], bf16x8_t (&af_cur)[8], bf16x8_t (&wf_cur)[8], bf16x8_t (&af_nxt)[8],
-                               bf16x8_t (&wf_nxt)[8], uint32_t pa, uint32_t pw, const W4Dma& d, uint32_t voff_a,
-                               uint32_t voff_w) {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        if (ABL & 2) {
-            if ((q & 1) == 0) asm volatile("" : "+v"(af_nxt[q >> 1]));
-            else asm volatile("" : "+v"(wf_nxt[q >> 1]));
-        } else if ((q & 1) == 0)
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af_nxt[q >> 1]) : "v"(pa), "n"((q >> 1) * 1024) : "memory");
-        else
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf_nxt[q >> 1]) : "v"(pw), "n"((q >> 1) * 1024) : "memory");
-        if (q < 8 && !(ABL & 1)) {
-            const int i = q & 3;
-            if (q < 4) glds16_sbase(d.a + i * d.sa, voff_a, d.dst + i * 1024);
-            else glds16_sbase(d.w + i * d.sw, voff_w, d.dst + 256 * 64 + i * 1024);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const int mi = q >> 1, n0 = (q & 1) * 4;
-#pragma unroll
-        for (int ni = n0; ni < n0 + 4; ++ni)   // FIRST: a tile's first step accumulates onto the inline constant 0 (no init pass)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf_cur[ni], af_cur[mi],
-                                                                  FIRST ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[mi][ni], 0, 0, 0);
-        if (FIRST)   // pin the fresh accumulators to AGPRs (with a constant C the compiler would otherwise pick VGPR results)
-            asm volatile("" : "+a"(acc[mi][n0]), "+a"(acc[mi][n0 + 1]), "+a"(acc[mi][n0 + 2]), "+a"(acc[mi][n0 + 3]));
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// Register-staged variant of the step (production).  An LDS-DMA instruction costs its issuing wave ~55 cycles (measured:
-// the K-loop without them runs 35 % faster) and with one wave per SIMD nobody else can absorb that, so the operand tiles
-// go  global_load_dwordx4 -> VGPRs (two steps in flight) -> ds_write_b128 -> ring  instead:
-//   step g, group i < 8:  ds_write piece i of K-tile g+2 (loaded during step g-2) ; global_load piece i of K-tile g+4
-//                         into the same registers ; every group: one fragment ds_read of F(g+1) ; 4 MFMAs
-// The wait in front of write i is the compiler's (the loads are ordinary loads): vmcnt(15) in the steady state -- pieces
-// i+1..7 of K-tile g+2, all of g+3 and pieces 0..i-1 of g+4 are younger -- and 15 + the epilogue's stores / loads in the
-// first two steps of a tile, which are separate code copies (STORES_YOUNGER) precisely so that those counts stay exact.
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-
-// a plain (compiler-visible) load: the compiler then owns the vmcnt wait in front of the ds_write that consumes it -- and in
-// front of any copy or spill of the register it might decide on (an inline-asm load would hide the pending state from it)
-__device__ inline void gload16(u32x4_t& dst, const char* base_uniform, uint32_t voff) {
-    dst = *reinterpret_cast<const u32x4_t*>(base_uniform + voff);
-}
-
-template <bool STORES_YOUNGER, bool FIRST>
-__device__ inline void w4_step_rl(f32x4_t (&acc)[8][8], bf16x8_t (&af_cur)[8], bf16x8_t (&wf_cur)[8], bf16x8_t (&af_nxt)[8],
-                                  bf16x8_t (&wf_nxt)[8], uint32_t pa, uint32_t pw, u32x4_t (&ls)[8], const char* src_a,
-                                  const char* src_w, int64_t sa, int64_t sw, uint32_t voff_a, uint32_t voff_w, uint32_t wr) {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        if ((q & 1) == 0)
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af_nxt[q >> 1]) : "v"(pa), "n"((q >> 1) * 1024) : "memory");
-        else
-            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf_nxt[q >> 1]) : "v"(pw), "n"((q >> 1) * 1024) : "memory");
-        if (q < 8) {
-            const int i = q & 3;
-            asm volatile("ds_write_b128 %1, %0 offset:%2"
-                         : : "v"(ls[q]), "v"(wr), "n"((q < 4 ? 0 : 256 * 64) + (q & 3) * 1024) : "memory");
-            if (q < 4) gload16(ls[q], src_a + i * sa, voff_a);
-            else gload16(ls[q], src_w + i * sw, voff_w);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        const int mi = q >> 1, n0 = (q & 1) * 4;
-#pragma unroll
-        for (int ni = n0; ni < n0 + 4; ++ni)   // FIRST: a tile's first step accumulates onto the inline constant 0 (no init pass)
-            acc[mi][ni] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf_cur[ni], af_cur[mi],
-                                                                  FIRST ? f32x4_t{0.f, 0.f, 0.f, 0.f} : acc[mi][ni], 0, 0, 0);
-        if (FIRST)   // pin the fresh accumulators to AGPRs (with a constant C the compiler would otherwise pick VGPR results)
-            asm volatile("" : "+a"(acc[mi][n0]), "+a"(acc[mi][n0 + 1]), "+a"(acc[mi][n0 + 2]), "+a"(acc[mi][n0 + 3]));
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-template <int MODE, int ABL = 0, bool RL = true>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
-void gemm_bf16_w4_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
-                         int K, int tiles_m, int tiles_n) {
-    const int M = ep.M, N = ep.N;
-    __shared__ __attribute__((aligned(16))) char smem[W4_SMEM];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    char* stage = smem + W4_EPI_OFF + wave * W4_PATCH;
-    // LDS-DMA lane part: row (lane >> 2) of a 16-row group, LDS slot (lane & 3) holds global k-slot (lane & 3) ^ ((row >> 2) & 3)
-    const uint32_t dma_slot = (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) * 16);
-    // (register-staged loads read the source unswizzled -- lane = 16 B of a 64 B row -- and swizzle on the ds_write address)
-    const uint32_t voff_a = (uint32_t)(lane >> 2) * (uint32_t)(lda * 2) + (RL ? (uint32_t)(lane & 3) * 16 : dma_slot);
-    const uint32_t voff_w = (uint32_t)(lane >> 2) * (uint32_t)(ldw * 2) + (RL ? (uint32_t)(lane & 3) * 16 : dma_slot);
-    const uint32_t wr_lane = (uint32_t)(lane >> 2) * 64 + dma_slot;
-    // fragment-read lane part: row (lane & 15), k-slot (lane >> 4) stored at slot ^ ((row >> 2) & 3)
-    const uint32_t frag_lane = (uint32_t)((lane & 15) * 64 + (((lane >> 4) ^ ((lane >> 2) & 3)) * 16));
-    const uint32_t frag_a = lds_addr(smem) + wm * 128 * 64 + frag_lane;
-    const uint32_t frag_w = lds_addr(smem) + (256 + wn * 128) * 64 + frag_lane;
-
-    const int nk = K / W4_KT;
-    const int nwg = tiles_m * tiles_n;
-    const int G = gridDim.x;
-    int nt = nwg / G;
-    {
-        int mm, nn;
-        if (nwg % G != 0 && pp_tile(nt, tiles_m, tiles_n, mm, nn)) ++nt;
-    }
-    const int total = nk * nt;   // K = 32 steps of this workgroup
-
-    LoadCursor lc;
-    lc.t = 0; lc.j = 0; lc.x = 0;
-    lc.valid = pp_tile(0, tiles_m, tiles_n, lc.m0, lc.n0);
-    // this wave's share of the cursor's K-tile: running source pointers (advanced 64 B per step, recomputed per tile)
-    const int64_t sa = 16 * lda * 2, sw = 16 * ldw * 2;
-    const char* cur_a = reinterpret_cast<const char*>(A) + (int64_t)(lc.m0 + wave * 64) * lda * 2;
-    const char* cur_w = reinterpret_cast<const char*>(W) + (int64_t)(lc.n0 + wave * 64) * ldw * 2;
-    const uint32_t ring_share = lds_addr(smem) + wave * 64 * 64;
-    auto describe = [&](W4Dma& d) {
-        d.a = cur_a;
-        d.w = cur_w;
-        d.sa = sa;
-        d.sw = sw;
-        d.dst = ring_share + (lc.x & 3) * W4_BUF;
-    };
-    auto bias_dma = [&]() {   // wave 0: bias[n0 .. n0+255] of the cursor's tile -> LDS row (j & 1), ahead of its first loads
-        if (wave == 0 && ep.bias && lc.valid && lc.t == 0)
-            glds16_vaddr(ep.bias + lc.n0 + (lane & 31) * 8, lds_addr(smem + W4_BIAS_OFF + (lc.j & 1) * 1024));
-    };
-    auto advance = [&]() {
-        ++lc.x;
-        if (!lc.valid) return;
-        if (lc.t + 1 < nk) {
-            ++lc.t;
-            cur_a += W4_KT * 2;
-            cur_w += W4_KT * 2;
-        } else if (lc.j + 1 < nt) {
-            ++lc.j;
-            lc.t = 0;
-            pp_tile(lc.j, tiles_m, tiles_n, lc.m0, lc.n0);
-            cur_a = reinterpret_cast<const char*>(A) + (int64_t)(lc.m0 + wave * 64) * lda * 2;
-            cur_w = reinterpret_cast<const char*>(W) + (int64_t)(lc.n0 + wave * 64) * ldw * 2;
-        } else {
-            lc.valid = false;   // stay on the last K-tile: trailing DMAs re-load it into ring buffers nobody reads again
-        }
-    };
-
-    f32x4_t acc[8][8];        // [m-fragment][n-fragment] of the wave's 128 x 128
-    bf16x8_t af[2][8], wf[2][8];
-    int pos0 = 0;
-    if (MODE == PP_QKV) pos0 = __builtin_amdgcn_readfirstlane(ep.q.pos0_dev ? *ep.q.pos0_dev : ep.q.pos0_host);
-
-    u32x4_t ls[2][8];   // RL: two K-tiles of this wave's share in flight between global memory and the ring
-    if (RL) {
-        // prologue: K-tiles 0 and 1 through registers into ring[0], ring[1]; K-tiles 2 and 3 stay in flight in registers
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            bias_dma();
-#pragma unroll
-            for (int i = 0; i < 4; ++i) gload16(ls[x][i], cur_a + i * sa, voff_a);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) gload16(ls[x][4 + i], cur_w + i * sw, voff_w);
-            advance();
-        }
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            const uint32_t wr = ring_share + x * W4_BUF + wr_lane;
-#pragma unroll
-            for (int q = 0; q < 8; ++q)
-                asm volatile("ds_write_b128 %1, %0 offset:%2"
-                             : : "v"(ls[x][q]), "v"(wr), "n"((q < 4 ? 0 : 256 * 64) + (q & 3) * 1024) : "memory");
-        }
-#pragma unroll
-        for (int x = 0; x < 2; ++x) {
-            bias_dma();
-#pragma unroll
-            for (int i = 0; i < 4; ++i) gload16(ls[x][i], cur_a + i * sa, voff_a);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) gload16(ls[x][4 + i], cur_w + i * sw, voff_w);
-            advance();
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    } else {
-        // prologue: K-tiles 0..3 into the four ring buffers (no MFMAs to hide behind yet)
-#pragma unroll 1
-        for (int x = 0; x < 4; ++x) {
-            W4Dma d;
-            bias_dma();
-            describe(d);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) glds16_sbase(d.a + i * d.sa, voff_a, d.dst + i * 1024);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) glds16_sbase(d.w + i * d.sw, voff_w, d.dst + 256 * 64 + i * 1024);
-            advance();
-        }
-    }
-
-    // K-tile 0 landed (own share; the prologue always issues 4 K-tiles) -> barrier -> F(0); the first tile's bias row is
-    // visible after the same barrier
-    if (!RL) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");   // (RL: the prologue drained its loads; a bias DMA is older than them)
-    cbarrier();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[0][i]) : "v"(frag_a), "n"(i * 1024) : "memory");
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[0][i]) : "v"(frag_w), "n"(i * 1024) : "memory");
-    }
-
-    int g = 0;
-    int cm0 = 0, cn0 = 0;
-    bool prev_full = false;
-    // two steps (fragment register sets 0 / 1, load register sets 0 / 1).  SY: a full tile's epilogue stores are younger
-    // than the loads being consumed -- the first two steps of every tile but the first (w4 tiles are always full tiles).
-    auto step = [&](auto sy_tag, auto first_tag, int h, int t) {
-        constexpr bool SY = decltype(sy_tag)::value, FIRST = decltype(first_tag)::value;
-        if (!RL) w4_wait(g, total, prev_full && (t + h) < 3);
-        // F(g) is in registers (read during step g-1): the wait both frees its ring buffer and orders the fragment
-        // registers before the MFMAs (the asm "touches" them so the compiler cannot hoist an MFMA above it)
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(af[h][0]), "+v"(af[h][1]), "+v"(af[h][2]), "+v"(af[h][3]), "+v"(af[h][4]), "+v"(af[h][5]),
-                       "+v"(af[h][6]), "+v"(af[h][7]), "+v"(wf[h][0]), "+v"(wf[h][1]), "+v"(wf[h][2]), "+v"(wf[h][3]),
-                       "+v"(wf[h][4]), "+v"(wf[h][5]), "+v"(wf[h][6]), "+v"(wf[h][7])
-                     :
-                     : "memory");
-        cbarrier();
-        bias_dma();
-        const uint32_t boff = (uint32_t)((g + 1) & 3) * W4_BUF;   // F(g+1) (past the last step: reads nobody uses)
-        if (RL) {
-            // K-tile g+2 (registers ls[h], loaded during step g-2) -> ring[(g+2) & 3]; K-tile g+4 -> ls[h]
-            const uint32_t wr = ring_share + (uint32_t)((g + 2) & 3) * W4_BUF + wr_lane;
-            w4_step_rl<SY, FIRST>(acc, af[h], wf[h], af[h ^ 1], wf[h ^ 1], frag_a + boff, frag_w + boff, ls[h], cur_a, cur_w, sa,
-                                  sw, voff_a, voff_w, wr);
-        } else {
-            W4Dma d;
-            describe(d);                                          // K-tile g + 4 -> ring[g & 3]
-            w4_step<ABL, FIRST>(acc, af[h], wf[h], af[h ^ 1], wf[h ^ 1], frag_a + boff, frag_w + boff, d, voff_a, voff_w);
-        }
-        advance();
-        ++g;
-    };
-    // SY: a full tile's epilogue stores are younger than the loads being consumed -- the first two steps of every tile
-    // but the first (w4 tiles are always full tiles).  The first step of a tile accumulates onto 0.
-    for (int j = 0; j < nt; ++j) {
-        pp_tile(j, tiles_m, tiles_n, cm0, cn0);
-        if (RL && j > 0) {
-            step(std::true_type{}, std::true_type{}, 0, 0);
-            step(std::true_type{}, std::false_type{}, 1, 0);
-        } else {
-            step(std::false_type{}, std::true_type{}, 0, 0);
-            step(std::false_type{}, std::false_type{}, 1, 0);
-        }
-        for (int t = 2; t < nk; t += 2) {
-            step(std::false_type{}, std::false_type{}, 0, t);
-            step(std::false_type{}, std::false_type{}, 1, t);
-        }
-        int lane_e = lane;
-        asm volatile("" : "+v"(lane_e));
-        w4_epilogue<MODE>(ep, pos0, stage, acc, cm0 + wm * 128, cn0 + wn * 128, lane_e,
-                          lds_addr(smem + W4_BIAS_OFF + (j & 1) * 1024) + wn * 128 * 2);
-        prev_full = (cm0 + BM2 <= M) && (cn0 + BN2 <= N);
-        if (j + 1 < nt) {   // F(g) again (set 0): re-reading it here keeps 64 registers free during the epilogue
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                asm volatile("ds_read_b128 %0, %1 offset:%2"
-                             : "=v"(af[0][i]) : "v"(frag_a + (uint32_t)(g & 3) * W4_BUF), "n"(i * 1024) : "memory");
-                asm volatile("ds_read_b128 %0, %1 offset:%2"
-                             : "=v"(wf[0][i]) : "v"(frag_w + (uint32_t)(g & 3) * W4_BUF), "n"(i * 1024) : "memory");
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing LDS-DMAs must land before the LDS allocation is released
-}
-
 // ---- generic tiled kernel (fp32 parity path; any M, N, K, strides) --------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_generic_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ W,
@@ -2173,42 +1672,12 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                                lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                 \
     } while (0)
                         // (the engine never combines these: QKV has no activation / residual, GELU has no residual)
-#define BT_LAUNCH_W4(MODE_)                                                                                          \
-    hipLaunchKernelGGL((gemm_bf16_w4_kernel<MODE_>), dim3(n_wg), dim3(256), 0, s, (const bf16*)A, lda, (const bf16*)W, K, \
-                       ep, (int)K, tiles_m, tiles_n)
-                        const bool w4 = g_gemm_variant != 12 && g_gemm_variant != 14 &&   // 12 / 14: the 8-wave kernels
-                                        M % BM2 == 0 && N % BN2 == 0 && K >= 4 * W4_KT && (uint64_t)(lda * 2) * 16 < (1ull << 31) &&
-                                        (uint64_t)(K * 2) * 16 < (1ull << 31);
-                        if (w4 && (ep.q.enabled || act == BT_ACT_NONE || !residual)) {
-                            if (g_gemm_variant == 19 && !ep.q.enabled && act == BT_ACT_NONE && !residual) {
-                                // A/B: operands via LDS-DMA instead of register-staged loads
-                                hipLaunchKernelGGL((gemm_bf16_w4_kernel<PP_PLAIN, 0, false>), dim3(n_wg), dim3(256), 0, s,
-                                                   (const bf16*)A, lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);
-                            } else
-                            if (g_gemm_variant >= 16 && g_gemm_variant <= 18 && !ep.q.enabled && act == BT_ACT_NONE && !residual) {
-                                // timing ablations of the K-loop (wrong results): 16 no DMA, 17 no ds_read, 18 neither
-                                if (g_gemm_variant == 16)
-                                    hipLaunchKernelGGL((gemm_bf16_w4_kernel<PP_PLAIN, 1, false>), dim3(n_wg), dim3(256), 0, s,
-                                                       (const bf16*)A, lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);
-                                else if (g_gemm_variant == 17)
-                                    hipLaunchKernelGGL((gemm_bf16_w4_kernel<PP_PLAIN, 2, false>), dim3(n_wg), dim3(256), 0, s,
-                                                       (const bf16*)A, lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);
-                                else
-                                    hipLaunchKernelGGL((gemm_bf16_w4_kernel<PP_PLAIN, 3, false>), dim3(n_wg), dim3(256), 0, s,
-                                                       (const bf16*)A, lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);
-                            } else
-                            if (ep.q.enabled) BT_LAUNCH_W4(PP_QKV);
-                            else if (act == BT_ACT_GELU) BT_LAUNCH_W4(PP_GELU);
-                            else if (residual) BT_LAUNCH_W4(PP_RES);
-                            else BT_LAUNCH_W4(PP_PLAIN);
-                        } else
                         if (ep.q.enabled) BT_LAUNCH_PP(PP_QKV);
                         else if (act == BT_ACT_GELU && !residual) BT_LAUNCH_PP(PP_GELU);
                         else if (act == BT_ACT_NONE && residual) BT_LAUNCH_PP(PP_RES);
                         else if (act == BT_ACT_NONE) BT_LAUNCH_PP(PP_PLAIN);
                         else BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<true>));   // GELU + residual: one-tile kernel
 #undef BT_LAUNCH_PP
-#undef BT_LAUNCH_W4
                     } else {
                         BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<true>));
                     }

@@ -216,106 +216,3 @@ def test_persistent_model_detects_miscounted_stores():
     with pytest.raises(AssertionError, match="WAR"):
         pp_model(8, 3, [True] * 3, [PP_STORES] * 3, pd=8)
 
-
-# ---- one-wave-per-SIMD kernel (gemm_bf16_w4_kernel): 4 ring buffers of one K = 32 tile, one barrier per step ---------------
-W4_STORES = int(re.search(r"constexpr int W4_STORES = (\d+);", SRC).group(1))
-W4_IMM = {(True,): int(re.search(r"if \(stores_younger\) wait_vmcnt_w4<(\d+)>\(\);", SRC).group(1)),
-          (False,): int(re.search(r"else wait_vmcnt_w4<(\d+)>\(\);\n\}", SRC).group(1))}
-
-
-def _w4_stream(wave0, nk, nt, full, stores, has_bias, prologue_imm=24):
-    """program-order events of one wave: ('vm', tag) / ('wait', N) / ('bar',) / ('read', tag); K-tile x lives in ring[x & 3]"""
-    total = nk * nt
-    ev = []
-
-    def dma(x):
-        xx = min(x, total - 1)                  # past the end the cursor re-issues the last K-tile (into ring[x & 3])
-        if has_bias and wave0 and x < total and x % nk == 0:
-            ev.append(("vm", ("bias", x // nk)))
-        for _ in range(8):
-            ev.append(("vm", ("ld", x, xx)))
-
-    for x in range(4):
-        dma(x)
-    ev.append(("wait", prologue_imm))
-    ev.append(("bar",))
-    ev.append(("read", ("ld", 0)))
-    if has_bias:
-        ev.append(("read", ("bias", 0)))
-    g = 0
-    prev_full = False
-    for j in range(nt):
-        for t in range(nk):
-            if g + 1 < total:
-                ev.append(("wait", W4_IMM[(prev_full and t < 3,)]))
-            ev.append(("bar",))
-            ev.append(("read", ("ld", g + 1)))  # F(g+1) <- ring[(g+1) & 3]  (past the end: garbage nobody uses)
-            dma(g + 4)                          # -> ring[g & 3]
-            g += 1
-        for _ in range(stores[j]):
-            ev.append(("vm", ("st", j)))
-        prev_full = full[j]
-        if j + 1 < nt and has_bias:
-            ev.append(("read", ("bias", j + 1)))
-    return ev
-
-
-def w4_model(nk, nt, full, stores, has_bias=True, **kw):
-    total = nk * nt
-    waves = {}
-    for w0 in (True, False):
-        ev = _w4_stream(w0, nk, nt, full, stores, has_bias, **kw)
-        bars, queue, done_upto = 0, [], 0
-        issue_bar, done_bar, reads = {}, {}, []
-        for e in ev:
-            if e[0] == "bar":
-                bars += 1
-            elif e[0] == "vm":
-                queue.append(e[1])
-                issue_bar.setdefault(e[1], bars)
-            elif e[0] == "wait":
-                upto = max(done_upto, len(queue) - e[1])
-                for tag in queue[done_upto:upto]:
-                    done_bar[tag] = bars
-                done_upto = upto
-            else:
-                reads.append((e[1], bars))
-        waves[w0] = (issue_bar, done_bar, reads, bars)
-    assert waves[True][3] == waves[False][3]
-    last_read = {}
-    for w0, (issue, done, reads, _) in waves.items():
-        for tag, b in reads:
-            last_read[tag] = max(last_read.get(tag, -1), b)
-            if tag[0] == "ld" and tag[1] >= total:
-                continue                                         # trailing fragment reads feed no MFMA
-            for o0, (_, odone, _, _) in waves.items():
-                if tag[0] == "bias":
-                    if o0:
-                        assert tag in odone and odone[tag] <= b - 1, f"RAW bias {tag}"
-                    continue
-                key = ("ld", tag[1], tag[1])
-                assert key in odone and odone[key] <= b - 1, f"RAW nk={nk} nt={nt}: K-tile {tag[1]} read before wave {o0} waited"
-    for w0, (issue, done, reads, _) in waves.items():
-        for tag, b in issue.items():
-            if tag[0] == "ld" and tag[1] >= 4:
-                prev = ("ld", tag[1] - 4)                        # same ring buffer, previous occupant
-            elif tag[0] == "bias" and tag[1] >= 2:
-                prev = ("bias", tag[1] - 2)
-            else:
-                continue
-            assert b >= last_read[prev] + 1, f"WAR nk={nk} nt={nt}: {tag} issued before the last read of {prev}"
-
-
-@pytest.mark.parametrize("nk", [2, 4, 6, 10, 64])
-@pytest.mark.parametrize("nt", [1, 2, 3, 5])
-def test_w4_gemm_schedule(nk, nt):
-    w4_model(nk, nt, [True] * nt, [W4_STORES] * nt)
-    w4_model(nk, nt, [True] * nt, [2 * W4_STORES] * nt)             # head_dim 32 QKV scatter issues more stores
-    w4_model(nk, nt, [True] * nt, [W4_STORES] * nt, has_bias=False)
-
-
-def test_w4_model_detects_miscounted_stores_and_shallow_wait():
-    with pytest.raises(AssertionError, match="RAW"):
-        w4_model(8, 3, [True] * 3, [W4_STORES - 8] * 3)
-    with pytest.raises(AssertionError, match="RAW"):
-        w4_model(8, 2, [True] * 2, [W4_STORES] * 2, prologue_imm=32)

@@ -179,7 +179,7 @@ def main():
                     res.append(probe_gemm(M, N, K, 30, scratch=sc))
     elif args.what == "abl":
         for (M, N, K) in ((32768, 6144, 2048), (32768, 2048, 8192)):
-            for v in (0, 16, 17, 18, 12, 0, 16, 17, 18, 12):   # w4: full / no DMA / no ds_read / neither; 12 = 8-wave kernel
+            for v in (0, 9, 11, 0, 9, 11):   # production persistent / one tile per workgroup / that without its epilogue
                 lib().bt_debug_gemm_variant(v)
                 r = probe_gemm(M, N, K, 10, bias=False)
                 r["variant"] = v
