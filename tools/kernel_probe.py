@@ -179,7 +179,7 @@ def main():
                     res.append(probe_gemm(M, N, K, 30, scratch=sc))
     elif args.what == "abl":
         for (M, N, K) in ((32768, 6144, 2048), (32768, 2048, 8192)):
-            for v in (0, 9, 11, 0, 9, 11):   # production persistent / one tile per workgroup / that without its epilogue
+            for v in (0, 3, 20, 21, 8, 0, 3, 20, 21, 8):   # production / 4-phase one-tile kernel: full, no MFMA, DMA only, MFMA+barriers only
                 lib().bt_debug_gemm_variant(v)
                 r = probe_gemm(M, N, K, 10, bias=False)
                 r["variant"] = v
