@@ -17,7 +17,6 @@
 #include "bt_common.h"
 
 #include <algorithm>
-#include <type_traits>
 
 namespace bt {
 
@@ -1517,193 +1516,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
     if (!grp1) cbarrier();
 }
 
-// ---- persistent 256x256 kernel, free-running waves ("fr") -----------------------------------------------------------------
-// Same tile, wave tile (128 rows x 64 contiguous columns, 8 waves = 2 per SIMD) and per-wave epilogue as the kernel above,
-// but no MFMA / load PHASES: every wave runs its own software pipeline -- 8 groups of 4 MFMAs per K = 32 step, each group
-// followed by the ds_read of the A fragment it just retired for the NEXT step (fragment registers roll in place), W
-// fragments double-buffered, this wave's 4 LDS-DMAs of the step issued one per group -- and the two waves of a SIMD simply
-// interleave on the matrix pipe: a wave stalled issuing an LDS-DMA (~55 cycles) or a ds_read is covered by its partner's
-// MFMAs without a barrier hand-over.  One barrier per step, in the MIDDLE of the step:
-//   ring = 4 x 32 KiB buffers [A rows 0..255 | W rows 0..255] x 64 B (K = 32), K-tile x in ring[x & 3];
-//   step g reads K-tile g+1 into registers (W_j before group j < 4, A_i after group i) while multiplying K-tile g;
-//   before group 4:  lgkmcnt(8)  -> every fragment of K-tile g is in registers (the 8 younger reads are K-tile g+1's)
-//                    vmcnt(4)    -> this wave's share of K-tile g+2 has landed (K-tile g+3's 4 DMAs stay in flight)
-//                    s_barrier   -> ring[g & 3] is free and K-tile g+2 is visible to everybody (first read: step g+1)
-//   groups 4..7:     LDS-DMA K-tile g+4 -> ring[g & 3], one instruction per group.
-// LDS reads return in order per wave, so the wait in front of group i is the constant lgkmcnt(11) (group 0: 6, it also
-// needs the last W fragment).  Stores of a full tile's epilogue are accounted like above (16 per wave; first two steps
-// of the next tile wait with vmcnt(4 + 16)).
-constexpr int FR_KT = 32;
-constexpr int FR_BUF = 512 * FR_KT * 2;                   // 32 KiB
-constexpr int FR_EPI_OFF = 4 * FR_BUF;
-constexpr int FR_BIAS_OFF = FR_EPI_OFF + 8 * PP_EPI_WAVE;
-constexpr int FR_SMEM = FR_BIAS_OFF + 2 * 1024;
-static_assert(FR_SMEM <= 160 * 1024, "free-running GEMM LDS budget");
-static_assert(PP_STORES == 16, "vmcnt(20) below = 4 DMAs + 16 stores");
-
-#define FR_READ(dst_, addr_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "n"(off_) : "memory")
-
-// one K = 32 step of one wave.  SY: a full tile's epilogue stores are younger than the DMAs waited for at the barrier.
-// LATE_DMA: the wave issues its DMA after the group's MFMAs instead of before (the two waves of a SIMD use different
-// positions so their ~55-cycle DMA issue stalls do not coincide).
-template <bool SY, bool LATE_DMA>
-__device__ inline void fr_step(f32x4_t (&acc)[8][4], bf16x8_t (&af)[8], bf16x8_t (&wf_cur)[4], bf16x8_t (&wf_nxt)[4],
-                               uint32_t pa, uint32_t pw, const char* src_a, const char* src_w, int64_t sa, int64_t sw,
-                               uint32_t voff_a, uint32_t voff_w, uint32_t dst) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        if (i < 4) FR_READ(wf_nxt[i], pw, i * 1024);                    // W_i of K-tile g+1
-        if (i == 4) {
-            asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");         // all fragments of K-tile g are in registers
-            if (SY) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");  // own share of K-tile g+2 landed
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            cbarrier();
-        }
-        if (i >= 4 && !LATE_DMA) {
-            const int q = i - 4;
-            if (q < 2) glds16_sbase(src_a + q * sa, voff_a, dst + q * 1024);
-            else glds16_sbase(src_w + (q - 2) * sw, voff_w, dst + 256 * 64 + (q - 2) * 1024);
-        }
-        if (i == 0)
-            asm volatile("s_waitcnt lgkmcnt(6)"
-                         : "+v"(af[0]), "+v"(wf_cur[0]), "+v"(wf_cur[1]), "+v"(wf_cur[2]), "+v"(wf_cur[3]) : : "memory");
-        else
-            asm volatile("s_waitcnt lgkmcnt(11)" : "+v"(af[i]) : : "memory");
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf_cur[j], af[i], acc[i][j], 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        FR_READ(af[i], pa, (i >> 2) * 8192 + (i & 3) * 1024);          // A_i of K-tile g+1 (the registers just retired)
-        if (i >= 4 && LATE_DMA) {
-            const int q = i - 4;
-            if (q < 2) glds16_sbase(src_a + q * sa, voff_a, dst + q * 1024);
-            else glds16_sbase(src_w + (q - 2) * sw, voff_w, dst + 256 * 64 + (q - 2) * 1024);
-        }
-    }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(512) void gemm_bf16_fr_kernel(const bf16* __restrict__ A, int64_t lda, const bf16* __restrict__ W,
-                                                          int64_t ldw, const EpiArgs ep, int K, int tiles_m, int tiles_n) {
-    const int M = ep.M, N = ep.N;
-    __shared__ __attribute__((aligned(16))) char smem[FR_SMEM];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
-    char* stage = smem + FR_EPI_OFF + wave * PP_EPI_WAVE;
-    // LDS-DMA lane part: row (lane >> 2) of a 16-row group, LDS slot (lane & 3) holds global k-slot (lane & 3) ^ ((row >> 2) & 3)
-    const uint32_t dma_slot = (uint32_t)(((lane & 3) ^ ((lane >> 4) & 3)) * 16);
-    const uint32_t voff_a = (uint32_t)(lane >> 2) * (uint32_t)(lda * 2) + dma_slot;
-    const uint32_t voff_w = (uint32_t)(lane >> 2) * (uint32_t)(ldw * 2) + dma_slot;
-    // fragment-read lane part: row (lane & 15), k-slot (lane >> 4) stored at slot ^ ((row >> 2) & 3)
-    const uint32_t frag_lane = (uint32_t)((lane & 15) * 64 + (((lane >> 4) ^ ((lane >> 2) & 3)) * 16));
-    const uint32_t frag_a = lds_addr(smem) + wm * 64 * 64 + frag_lane;              // + (i >> 2) * 128 rows + (i & 3) * 16 rows
-    const uint32_t frag_w = lds_addr(smem) + (256 + wn * 64) * 64 + frag_lane;      // + j * 16 rows
-
-    const int nk = K / FR_KT;
-    const int nwg = tiles_m * tiles_n;
-    const int G = gridDim.x;
-    int nt = nwg / G;
-    {
-        int mm, nn;
-        if (nwg % G != 0 && pp_tile(nt, tiles_m, tiles_n, mm, nn)) ++nt;
-    }
-
-    // load cursor: this wave's share (A rows and W rows [wave * 32, +32) = 2 + 2 DMA instructions) of the next K-tile
-    LoadCursor lc;
-    lc.t = 0; lc.j = 0; lc.x = 0;
-    lc.valid = pp_tile(0, tiles_m, tiles_n, lc.m0, lc.n0);
-    const int64_t sa = 16 * lda * 2, sw = 16 * ldw * 2;
-    const char* cur_a = reinterpret_cast<const char*>(A) + (int64_t)(lc.m0 + wave * 32) * lda * 2;
-    const char* cur_w = reinterpret_cast<const char*>(W) + (int64_t)(lc.n0 + wave * 32) * ldw * 2;
-    const uint32_t ring_share = lds_addr(smem) + wave * 32 * 64;
-    auto bias_dma = [&]() {   // wave 0: bias[n0 .. n0+255] of the cursor's tile -> LDS row (j & 1), ahead of its first loads
-        if (wave == 0 && ep.bias && lc.valid && lc.t == 0)
-            glds16_vaddr(ep.bias + lc.n0 + (lane & 31) * 8, lds_addr(smem + FR_BIAS_OFF + (lc.j & 1) * 1024));
-    };
-    auto advance = [&]() {
-        ++lc.x;
-        if (!lc.valid) return;
-        if (lc.t + 1 < nk) {
-            ++lc.t;
-            cur_a += FR_KT * 2;
-            cur_w += FR_KT * 2;
-        } else if (lc.j + 1 < nt) {
-            ++lc.j;
-            lc.t = 0;
-            pp_tile(lc.j, tiles_m, tiles_n, lc.m0, lc.n0);
-            cur_a = reinterpret_cast<const char*>(A) + (int64_t)(lc.m0 + wave * 32) * lda * 2;
-            cur_w = reinterpret_cast<const char*>(W) + (int64_t)(lc.n0 + wave * 32) * ldw * 2;
-        } else {
-            lc.valid = false;   // stay on the last K-tile: trailing DMAs re-load it into ring buffers nobody reads again
-        }
-    };
-    // prologue: K-tiles 0..3 into the four ring buffers
-#pragma unroll 1
-    for (int x = 0; x < 4; ++x) {
-        bias_dma();
-        const uint32_t dst = ring_share + (lc.x & 3) * FR_BUF;
-        glds16_sbase(cur_a, voff_a, dst);
-        glds16_sbase(cur_a + sa, voff_a, dst + 1024);
-        glds16_sbase(cur_w, voff_w, dst + 256 * 64);
-        glds16_sbase(cur_w + sw, voff_w, dst + 256 * 64 + 1024);
-        advance();
-    }
-
-    f32x4_t acc[8][4];
-    bf16x8_t af[8], wf[2][4];
-    int pos0 = 0;
-    if (MODE == PP_QKV) pos0 = __builtin_amdgcn_readfirstlane(ep.q.pos0_dev ? *ep.q.pos0_dev : ep.q.pos0_host);
-
-    auto read_all = [&](int g) {   // every fragment of K-tile g (W into set 0): prologue, and after an epilogue
-        const uint32_t boff = (uint32_t)(g & 3) * FR_BUF;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) FR_READ(wf[0][j], frag_w + boff, j * 1024);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) FR_READ(af[i], frag_a + boff, (i >> 2) * 8192 + (i & 3) * 1024);
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(af[0]), "+v"(af[1]), "+v"(af[2]), "+v"(af[3]), "+v"(af[4]), "+v"(af[5]), "+v"(af[6]), "+v"(af[7]),
-                       "+v"(wf[0][0]), "+v"(wf[0][1]), "+v"(wf[0][2]), "+v"(wf[0][3])
-                     :
-                     : "memory");
-    };
-    // K-tiles 0 and 1 landed (own share) -> barrier -> fragments of K-tile 0; the first tile's bias row is visible too
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    cbarrier();
-    read_all(0);
-
-    int g = 0;
-    int cm0 = 0, cn0 = 0;
-    auto step = [&](auto sy_tag, int h) {
-        constexpr bool SY = decltype(sy_tag)::value;
-        bias_dma();
-        const uint32_t boff = (uint32_t)((g + 1) & 3) * FR_BUF;   // K-tile g+1 (past the last step: reads nobody uses)
-        const uint32_t dst = ring_share + (uint32_t)(g & 3) * FR_BUF;   // K-tile g+4 -> ring[g & 3]
-        fr_step<SY, false>(acc, af, wf[h], wf[h ^ 1], frag_a + boff, frag_w + boff, cur_a, cur_w, sa, sw, voff_a, voff_w, dst);
-        advance();
-        ++g;
-    };
-    for (int j = 0; j < nt; ++j) {
-        pp_tile(j, tiles_m, tiles_n, cm0, cn0);
-        Mma16::init(acc, ep.bias != nullptr, lds_addr(smem + FR_BIAS_OFF + (j & 1) * 1024), wn * 64, lane);
-        if (j > 0) {   // the previous tile was a full tile (the kernel only runs on M, N multiples of 256): its epilogue's
-            step(std::true_type{}, 0);   // stores are younger than the DMAs these two steps wait for
-            step(std::true_type{}, 1);
-        }
-        for (int t = j > 0 ? 2 : 0; t < nk; t += 2) {
-            step(std::false_type{}, 0);
-            step(std::false_type{}, 1);
-        }
-        int lane_e = lane;
-        asm volatile("" : "+v"(lane_e));
-        pp_epilogue<MODE>(ep, pos0, stage, acc, cm0, cn0 + wn * 64, wm, lane_e);
-        if (j + 1 < nt) read_all(g);   // re-read K-tile g's fragments: nothing of the K-loop stays live across the epilogue
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // trailing LDS-DMAs must land before the LDS allocation is released
-    (void)M; (void)N;
-}
-#undef FR_READ
-
 // ---- generic tiled kernel (fp32 parity path; any M, N, K, strides) --------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_generic_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ W,
@@ -1862,25 +1674,12 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                                lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                 \
     } while (0)
                         // (the engine never combines these: QKV has no activation / residual, GELU has no residual)
-#define BT_LAUNCH_FR(MODE_)                                                                                          \
-    hipLaunchKernelGGL((gemm_bf16_fr_kernel<MODE_>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A, lda, (const bf16*)W, K, \
-                       ep, (int)K, tiles_m, tiles_n)
-                        const bool fr = g_gemm_variant == 15 && M % BM2 == 0 && N % BN2 == 0 && K >= 4 * FR_KT &&
-                                        (uint64_t)(lda * 2) * 16 < (1ull << 31) && (uint64_t)(K * 2) * 16 < (1ull << 31) &&
-                                        (ep.q.enabled || act == BT_ACT_NONE || !residual);
-                        if (fr) {
-                            if (ep.q.enabled) BT_LAUNCH_FR(PP_QKV);
-                            else if (act == BT_ACT_GELU) BT_LAUNCH_FR(PP_GELU);
-                            else if (residual) BT_LAUNCH_FR(PP_RES);
-                            else BT_LAUNCH_FR(PP_PLAIN);
-                        } else
                         if (ep.q.enabled) BT_LAUNCH_PP(PP_QKV);
                         else if (act == BT_ACT_GELU && !residual) BT_LAUNCH_PP(PP_GELU);
                         else if (act == BT_ACT_NONE && residual) BT_LAUNCH_PP(PP_RES);
                         else if (act == BT_ACT_NONE) BT_LAUNCH_PP(PP_PLAIN);
                         else BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<true>));   // GELU + residual: one-tile kernel
 #undef BT_LAUNCH_PP
-#undef BT_LAUNCH_FR
                     } else {
                         BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<true>));
                     }

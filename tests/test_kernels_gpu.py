@@ -98,7 +98,7 @@ def test_linear_256_tile_kernel(M, N, K, variant, kernel):
     assert rel_err(out, ref) <= 1.2e-2, rel_err(out, ref)
 
 
-@pytest.mark.parametrize("kernel", [0, 9, 12, 14, 15])
+@pytest.mark.parametrize("kernel", [0, 9, 12, 14])
 def test_gelu_epilogue_accuracy(kernel):
     """The bf16 epilogues' GELU (scaled-normal-tail polynomial, not erff) through an identity GEMM: within one bf16 ulp of
     the exact erf GELU everywhere -- including the negative tail, where 1 + erf cancels -- and bit-equal to the correctly
@@ -159,39 +159,7 @@ def test_linear_persistent_kernel(M, N, K, variant, max_wg, kernel):
     assert float((err - 1.6e-2 * ref.abs() - 2e-2).max()) <= 0, float(err.max())
 
 
-@pytest.mark.parametrize("M,N,K", [(512, 768, 2048), (2048, 1024, 512), (256, 2304, 320), (256, 256, 128), (1024, 512, 192)])
-@pytest.mark.parametrize("variant", ["plain", "bias", "bias_gelu", "bias_res", "res"])
-@pytest.mark.parametrize("max_wg", [0, 1, 3, 4])
-def test_linear_free_running_kernel(M, N, K, variant, max_wg):
-    """The free-running-waves persistent kernel (variant 15; M, N multiples of 256) against fp64: every epilogue flavour, K
-    from 4 to 64 steps, grid capped so workgroups walk several tiles incl. a partial last round."""
-    x = rnd(M, K, seed=1).bfloat16()
-    w = rnd(N, K, seed=2, scale=K ** -0.5).bfloat16()
-    b = rnd(N, seed=3).bfloat16() if variant.startswith("bias") else None
-    r = rnd(M, N, seed=4).bfloat16() if variant.endswith("res") else None
-    ref = x.double() @ w.double().T
-    if b is not None:
-        ref = ref + b.double()
-    if variant == "bias_gelu":
-        ref = F.gelu(ref)
-    if r is not None:
-        ref = ref + r.double()
-    lib().bt_debug_gemm_variant(15)
-    lib().bt_debug_gemm_max_wg(max_wg)
-    try:
-        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
-        ops.linear(x.to(DEV), w.to(DEV), None if b is None else b.to(DEV), None if r is None else r.to(DEV),
-                   act="gelu" if variant == "bias_gelu" else "none", out=out)
-        out = out.cpu()
-    finally:
-        lib().bt_debug_gemm_variant(0)
-        lib().bt_debug_gemm_max_wg(0)
-    assert rel_err(out, ref) <= 1.2e-2, rel_err(out, ref)
-    err = (out.double() - ref).abs()
-    assert float((err - 1.6e-2 * ref.abs() - 2e-2).max()) <= 0, float(err.max())
-
-
-@pytest.mark.parametrize("kernel", [12, 14, 15])
+@pytest.mark.parametrize("kernel", [12, 14])
 def test_linear_persistent_inplace_residual_and_strides(kernel):
     """hidden += x @ W^T through the persistent kernels, in place (res == out), row strides > row length."""
     M, N, K = 1024, 512, 256
@@ -220,7 +188,7 @@ def test_linear_256_tile_kernel_repeatable():
     lib().bt_debug_gemm_variant(1)
     base = ops.linear(x, w)
     try:
-        for kernel in (2, 3, 9, 10, 12, 14, 15):   # 12 / 14 = persistent (16x16x32 / 32x32x16 MFMA), 15 = free-running waves
+        for kernel in (2, 3, 9, 10, 12, 14):   # 12 / 14 = persistent (16x16x32 / 32x32x16 MFMA)
             lib().bt_debug_gemm_variant(kernel)
             lib().bt_debug_gemm_max_wg(5 if kernel >= 12 else 0)
             outs = [ops.linear(x, w) for _ in range(20)]
@@ -389,7 +357,7 @@ def test_qkv_rope_append_fused_head_dims(d, heads, kernel, max_wg):
 @pytest.mark.parametrize("B,q,pos0,heads,d", [(4, 64, 3, 2, 128), (2, 256, 0, 2, 128), (8, 32, 1, 8, 32), (1, 512, 0, 4, 64)])
 @pytest.mark.parametrize("use_dev_pos,use_table", [(False, False), (True, True)])
 @pytest.mark.parametrize("max_wg", [0, 2])
-@pytest.mark.parametrize("kernel", [12, 15])
+@pytest.mark.parametrize("kernel", [12, 14])
 def test_qkv_rope_append_fused_persistent_full_tiles(B, q, pos0, heads, d, use_dev_pos, use_table, max_wg, kernel):
     """Fused RoPE + KV append epilogue of the persistent kernels on full 256 x 256 tiles (the fast store-count waits)."""
     run_qkv_fused(B, q, pos0, heads, d, use_dev_pos, use_table, True, kernel, max_wg)
