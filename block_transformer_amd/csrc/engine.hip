@@ -38,9 +38,11 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
     // 256-byte align the workspace base
     uintptr_t base = (reinterpret_cast<uintptr_t>(ws) + 255u) & ~(uintptr_t)255u;
     const int64_t avail = ws_bytes - (int64_t)(base - reinterpret_cast<uintptr_t>(ws));
-    if (avail < ws_elems(dims, M) * (int64_t)es + splitk_bytes(dims, M) + 256) {
+    // the activation buffers are mandatory; the split-K scratch is an optimisation (a workspace sized for a larger M, e.g.
+    // the token decoder's B*E prefix rows reused for its B-row steps, simply runs the skinny GEMMs without split-K)
+    if (avail < ws_elems(dims, M) * (int64_t)es + 256) {
         set_error("bt_decoder_forward: workspace too small: %lld bytes for M=%lld (need %lld)", (long long)ws_bytes,
-                  (long long)M, (long long)bt_decoder_workspace_bytes(dims, dtype, M));
+                  (long long)M, (long long)(ws_elems(dims, M) * (int64_t)es + 512));
         return BT_ERR_WORKSPACE;
     }
     char* p = reinterpret_cast<char*>(base);
@@ -50,7 +52,8 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
     void* h4 = p + 5 * M * H * es;
     void* att = ln1;
     char* sk = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p + ws_elems(dims, M) * es) + 255u) & ~(uintptr_t)255u);
-    const int64_t sk_bytes = splitk_bytes(dims, M);
+    int64_t sk_bytes = splitk_bytes(dims, M);
+    if (sk_bytes && (sk + sk_bytes) > (reinterpret_cast<char*>(ws) + ws_bytes)) sk_bytes = 0;
     void* scratch = sk_bytes ? sk : nullptr;
 
     // When the caller consumes only the LAST row of every sequence (prefill -> context embedding; token-decoder step 0),

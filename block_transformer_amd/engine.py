@@ -67,7 +67,9 @@ class TokenBlockState:
         self.pos_table = torch.tensor(td_position_table(rope_policy, self.E, self.L), dtype=torch.int32, device=device)
         self.rope = ops.rope_tables(max(self.pos_table.tolist()) + 1, self.rt.dims.rot,
                                     float(getattr(cfg, "rotary_emb_base", 10000.0)), device)
-        self.ws = torch.empty(self.rt.workspace_bytes(batch * self.E), dtype=torch.uint8, device=device)
+        # step 0 runs B*E prefix rows, steps 1.. run B rows (which may want split-K scratch when B <= 256): size for both
+        self.ws = torch.empty(max(self.rt.workspace_bytes(batch * self.E), self.rt.workspace_bytes(batch)), dtype=torch.uint8,
+                              device=device)
         self.sample_step = torch.zeros(1, dtype=torch.int32, device=device)
         # split-K scratch for the skinny expansion GEMM (small batches stream the weights with every CU)
         self.scratch = (torch.empty(16 * batch * self.E * self.H, dtype=torch.float32, device=device)

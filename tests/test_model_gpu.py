@@ -174,6 +174,26 @@ def test_generate_shard_equivalence(gpu_model):
     assert torch.equal(whole, o.generate(prompt.cpu(), max_length=28))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B", [130, 200, 256, 257])
+def test_generate_batch_sizes_around_the_splitk_boundary(gpu_model, B, dtype):
+    """The token decoder runs B*E prefix rows at step 0 and B rows afterwards, and rows <= 256 take the split-K GEMM path
+    with its own scratch: batches with B <= 256 < B*E (and their neighbours) must size / use the workspace consistently
+    (regression: B = 256 failed with 'workspace too small')."""
+    model, dims, sd, fx = gpu_model("micro", dtype)
+    prompt = torch.randint(1, dims.vocab, (B, 8), generator=torch.Generator().manual_seed(B)).to(DEV)
+    out = model.generate(prompt, max_length=16).cpu()
+    assert out.shape == (B, 16) and torch.equal(out[:, :8], prompt.cpu())
+    # rows are independent: a slice of the batch generated on its own gives the same tokens
+    part = model.generate(prompt[5:9].contiguous(), max_length=16).cpu()
+    if dtype == torch.float32:
+        assert torch.equal(out[5:9], part)
+        o = oracle_from_dims(dims, sd)
+        assert torch.equal(out[:3], o.generate(prompt[:3].cpu(), max_length=16))
+    else:
+        assert (out[5:9] == part).float().mean() >= 0.9
+
+
 def test_generate_ragged_left_padded_batch(gpu_model):
     """Different prompt lengths, left-padded with an attention mask: fully masked leading blocks (Q4/Q5 masks)."""
     model, dims, sd, fx = gpu_model("micro")
