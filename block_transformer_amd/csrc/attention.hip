@@ -529,6 +529,7 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_v2_kernel(const bf16* __
     const int n_keys = pos0 + last_q + 1;
     const int n_tiles = (n_keys + FK_TILE - 1) / FK_TILE;
     const int wave_last_pos = pos0 + min(qbase + QF * 16, q_len) - 1;  // last query position this wave owns
+    const float sl2 = scale * 1.44269504088896340736f;                 // softmax in base 2
 
     flash_stage_tile<D>(kbase, vbase, 0, n_keys, smem, smem + TILE_B, wave, lane);
 
@@ -583,37 +584,57 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_v2_kernel(const bf16* __
                         sacc[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[f][kk], sacc[f][kf], 0, 0, 0);
                 }
             }
-            bool kvis[4][4];
-#pragma unroll
-            for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = key0 + kf * 16 + g * 4 + r;
-                    kvis[kf][r] = (key < n_keys) && (mrow == nullptr || mrow[key] != 0);
-                }
-#pragma unroll
-            for (int f = 0; f < QF; ++f) {
-                const int qpos = pos0 + qrow[f];
-                float tmax = -INFINITY;
+            // scores -> probabilities (online softmax, base 2: `sl2` = scale * log2(e) is folded into one multiply).
+            // Interior tiles -- every key of the tile visible to every query row of this wave, no padding mask, no key past
+            // n_keys -- skip the visibility compares and selects (most tiles of a causal prefill).
+            const bool need_mask = (mrow != nullptr) || (key0 + FK_TILE > n_keys) || (key0 + FK_TILE - 1 > pos0 + qbase);
+            if (need_mask) {
+                bool kvis[4][4];
 #pragma unroll
                 for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int key = key0 + kf * 16 + g * 4 + r;
-                        const float sv = (key <= qpos && kvis[kf][r]) ? sacc[f][kf][r] * scale : -INFINITY;
-                        sacc[f][kf][r] = sv;
-                        tmax = fmaxf(tmax, sv);
+                        kvis[kf][r] = (key < n_keys) && (mrow == nullptr || mrow[key] != 0);
                     }
+#pragma unroll
+                for (int f = 0; f < QF; ++f) {
+                    const int qpos = pos0 + qrow[f];
+#pragma unroll
+                    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int key = key0 + kf * 16 + g * 4 + r;
+                            sacc[f][kf][r] = (key <= qpos && kvis[kf][r]) ? sacc[f][kf][r] * sl2 : -INFINITY;
+                        }
+                }
+            } else {
+#pragma unroll
+                for (int f = 0; f < QF; ++f)
+#pragma unroll
+                    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sacc[f][kf][r] *= sl2;
+            }
+#pragma unroll
+            for (int f = 0; f < QF; ++f) {
+                float tmax = -INFINITY;
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, sacc[f][kf][r]);
                 tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
                 tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
                 const float mnew = fmaxf(mrun[f], tmax);
-                const float alpha = (mnew == -INFINITY) ? 1.0f : __expf(mrun[f] - mnew);
+                const bool dead = (mnew == -INFINITY);          // no visible key so far for this query row
+                const float msub = dead ? 0.f : mnew;
+                const float alpha = dead ? 1.0f : __builtin_amdgcn_exp2f(mrun[f] - mnew);
                 float psum = 0.f;
 #pragma unroll
                 for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float pv = (mnew == -INFINITY) ? 0.f : __expf(sacc[f][kf][r] - mnew);
+                        const float pv = __builtin_amdgcn_exp2f(sacc[f][kf][r] - msub);   // exp2(-inf) = 0 for masked keys
                         sacc[f][kf][r] = pv;
                         psum += pv;
                     }
