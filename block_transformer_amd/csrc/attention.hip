@@ -162,6 +162,18 @@ __global__ __launch_bounds__(NW * 64) void attend_rows_kernel(const T* __restric
     const T* vbase = vc + (b * heads + head) * n_max * D + c * V;
     const uint8_t* mrow = mask ? mask + b * mask_ld : nullptr;
 
+    // local-window variant (NW == 1, a handful of keys): the first batch of V rows does not depend on the scores -- issue
+    // it together with the K rows so the whole kernel is one memory round trip instead of two
+    float vpre[U][V];
+    if (NW == 1) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int r = k0 + u * RPW + sub;
+            r = r < k1 ? r : k1 - 1;
+            r = r < 0 ? 0 : r;
+            load_vec<T>(vbase + (int64_t)r * D, vpre[u]);
+        }
+    }
     // pass 1: scores
     for (int rb = k0 + wave * RPW; rb < k1; rb += NW * RPW * U) {
         float kv[U][V];
@@ -207,7 +219,10 @@ __global__ __launch_bounds__(NW * 64) void attend_rows_kernel(const T* __restric
             int r = rb + u * NW * RPW + sub;
             const bool ok = r < k1;
             r = ok ? r : k1 - 1;
-            if (NT) load_vec_nt<T>(vbase + (int64_t)r * D, vv[u]);
+            if (NW == 1 && rb == k0) {
+#pragma unroll
+                for (int i = 0; i < V; ++i) vv[u][i] = vpre[u][i];
+            } else if (NT) load_vec_nt<T>(vbase + (int64_t)r * D, vv[u]);
             else load_vec<T>(vbase + (int64_t)r * D, vv[u]);
             p[u] = ok ? sc[r - k0] : 0.f;
         }
