@@ -1,17 +1,20 @@
-// bt_linear: out[M,N] = act(A[M,K] . W[N,K]^T + bias) + residual
+// bt_linear / bt_linear_ws / bt_qkv_rope_append: out[M,N] = act(A[M,K] . W[N,K]^T + bias) + residual  (HF nn.Linear layout:
+// both operands K-contiguous), bf16 on MFMA, fp32 on a plain tiled kernel (the parity path).
 //
-// Two kernels:
-//  * gemm_bf16_mfma_kernel  — the production path.  128x128x64 block tile, 4 waves (2x2), each wave a 64x64 output
-//    tile = 4x4 fragments of v_mfma_f32_16x16x32_bf16.  Both operands are K-contiguous (HF nn.Linear weights are
-//    [out,in]), so A and W tiles are streamed HBM -> LDS with 16-byte global_load_lds (no VGPR round trip), double
-//    buffered, one barrier per K-step.  LDS rows are 128 B (64 bf16); the 16-byte slot index is XOR-swizzled with
-//    (row & 7) on the *source* address and on the ds_read_b128 address (the LDS image of an LDS-DMA is lane-linear),
-//    which makes every ds_read_b128 lane group conflict-free.  The MFMA "A" operand is the WEIGHT tile and the "B"
-//    operand the activation tile, so each lane ends up with 4 consecutive output columns of one row: bias / GELU /
-//    residual are fused into an 8-byte-per-lane epilogue store.  Block ids are remapped XCD-aware (each XCD's L2 sees
-//    a contiguous slab of the tile grid) and grouped along M so a group's A tiles stay L2-resident while W streams.
-//  * gemm_generic_kernel<T> — any dtype/shape (fp32 parity path, and bf16 shapes with K % 64 != 0): 64x64x16 LDS
-//    tiled, fp32 FMA accumulation.
+// Kernel family (dispatch in linear_impl; every bf16 kernel streams A and W tiles HBM/L2 -> LDS with 16-byte
+// global_load_lds, XOR-swizzles the 16-byte slots of an LDS row so ds_read_b128 fragment reads are conflict-free, feeds the
+// WEIGHT tile as the MFMA "A" operand -- so a lane ends up with 4 consecutive output columns of one row -- and remaps
+// block ids XCD-aware with grouping along M so an XCD's L2 sees a compact set of A / W panels):
+//  * gemm_bf16_mfma256pp_kernel<MODE, Mma16>  PRODUCTION for grids >= ~240 tiles: persistent 256x256x64 tiles, 8 waves, half-
+//      tile LDS ring, two staggered wave groups, per-wave epilogue (see the block comment at the kernel).  MODE = plain /
+//      GELU / residual / fused QKV (RoPE + KV-cache append in the epilogue).  Mma32 = 32x32x16 MFMA A/B variant.
+//  * gemm_bf16_mfma256p2_kernel               one 256x256 tile per workgroup, same ring (fallback: N % 8 != 0, K < 256; A/B).
+//  * gemm_bf16_mfma256_kernel<STAGGER, ABL>   the earlier four-phase ring + timing ablations (A/B probes only).
+//  * gemm_bf16_mfma_kernel<TBM, TBN, SPLITK>  128x128 / 128x64 / 64x64 tiles, 4 waves, double-buffered: grids that would
+//      leave CUs idle with 256^2 tiles (decode GEMMs at M = 4096 with N = 2048 / 6144, small batches); SPLITK + 
+//      splitk_reduce_kernel for the weight-streaming regime (M <~ 256 rows).
+//  * gemm_generic_kernel<T>                   any dtype / shape / stride: 64x64x16 LDS tile, fp32 FMA accumulation (fp32
+//      parity path with erff GELU; bf16 shapes with K % 64 != 0).
 //
 // Roofline: MFMA-bound for M >~ 300 rows (2*M*N*K flop vs 2*(M*K + N*K + M*N) bytes); HBM-bound on W below that.
 #include "bt_common.h"
