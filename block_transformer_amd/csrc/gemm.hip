@@ -1519,6 +1519,106 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
     if (!grp1) cbarrier();
 }
 
+// ---- GEMV for a handful of rows (M <= 4): the weight-streaming regime of small-batch decode ------------------------------
+// out[m, n] = epi(sum_k x[m, k] * W[n, k]).  One pass over W at HBM speed is the whole cost (N*K*2 bytes; x is a few KiB), so
+// the kernel is a pure streamer: a wave owns RW rows of W, every lane keeps 4 x 16-byte loads per row in flight (a 2048-wide
+// K chunk = 4 coalesced 1 KiB wave-loads per row), the x chunk sits in LDS (MR x 4 KiB, read as ds_read_b128 and reused
+// for the wave's RW rows), products accumulate in fp32 per lane, and one butterfly per (row, m) finishes the dot product.
+// Bias / GELU / residual are applied by the lane that stores the element.  Replaces the split-K MFMA kernel + reduce kernel
+// pair for M <= 4 (two launches, fp32 partial round trip): B = 1 decode 700 -> 1084 tok/s end to end.
+constexpr int GV_KC = 2048;   // K chunk staged in LDS
+
+__device__ inline float dot8_bf16(const uint4& w, const uint4& x, float acc) {
+    acc = fmaf(__uint_as_float(w.x << 16), __uint_as_float(x.x << 16), acc);
+    acc = fmaf(__uint_as_float(w.x & 0xffff0000u), __uint_as_float(x.x & 0xffff0000u), acc);
+    acc = fmaf(__uint_as_float(w.y << 16), __uint_as_float(x.y << 16), acc);
+    acc = fmaf(__uint_as_float(w.y & 0xffff0000u), __uint_as_float(x.y & 0xffff0000u), acc);
+    acc = fmaf(__uint_as_float(w.z << 16), __uint_as_float(x.z << 16), acc);
+    acc = fmaf(__uint_as_float(w.z & 0xffff0000u), __uint_as_float(x.z & 0xffff0000u), acc);
+    acc = fmaf(__uint_as_float(w.w << 16), __uint_as_float(x.w << 16), acc);
+    acc = fmaf(__uint_as_float(w.w & 0xffff0000u), __uint_as_float(x.w & 0xffff0000u), acc);
+    return acc;
+}
+
+template <int MR, int RW>
+__global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W,
+                                                       int64_t ldw, const EpiArgs ep, int K) {
+    __shared__ __attribute__((aligned(16))) char xs[MR * GV_KC * 2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = ep.M, N = ep.N;
+    const int n_blk = blockIdx.x * (4 * RW);
+    int rows[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) rows[r] = n_blk + wave + 4 * r;   // consecutive rows go to different waves
+    float acc[RW][MR];
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int m = 0; m < MR; ++m) acc[r][m] = 0.f;
+
+    for (int kc = 0; kc < K; kc += GV_KC) {
+        const int kw = min(GV_KC, K - kc);            // multiple of 512
+        __syncthreads();                               // previous chunk fully consumed
+        for (int idx = tid; idx < MR * (kw / 8); idx += 256) {
+            const int m = idx / (kw / 8), c = idx - m * (kw / 8);
+            uint4 v = uint4{0, 0, 0, 0};
+            if (m < M) v = *reinterpret_cast<const uint4*>(X + (int64_t)m * ldx + kc + c * 8);
+            *reinterpret_cast<uint4*>(xs + (m * GV_KC + c * 8) * 2) = v;
+        }
+        // this wave's W rows of the chunk: all loads in flight before the first use
+        uint4 wv[RW][GV_KC / 512];
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int n = rows[r] < N ? rows[r] : N - 1;
+            const bf16* wp = W + (int64_t)n * ldw + kc + lane * 8;
+#pragma unroll
+            for (int j = 0; j < GV_KC / 512; ++j)
+                wv[r][j] = (j * 512 < kw) ? *reinterpret_cast<const uint4*>(wp + j * 512) : uint4{0, 0, 0, 0};
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < GV_KC / 512; ++j) {
+            if (j * 512 < kw) {
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    const uint4 xv = *reinterpret_cast<const uint4*>(xs + (m * GV_KC + j * 512 + lane * 8) * 2);
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) acc[r][m] = dot8_bf16(wv[r][j], xv, acc[r][m]);
+                }
+            }
+        }
+    }
+    // finish the dot products; afterwards every lane holds every sum, and lane (r * MR + m) stores element (m, rows[r])
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int m = 0; m < MR; ++m) acc[r][m] = wave_sum(acc[r][m]);
+    float mine = 0.f;
+    int my_r = 0, my_m = 0;
+#pragma unroll
+    for (int r = 0; r < RW; ++r)
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+            if (lane == r * MR + m) {
+                mine = acc[r][m];
+                my_r = r;
+                my_m = m;
+            }
+    if (lane < RW * MR) {
+        int n = 0;
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+            if (my_r == r) n = rows[r];
+        if (my_m < M && n < N) {
+            float v = mine;
+            if (ep.bias) v += bf16_to_f32(ep.bias[n].x);
+            if (ep.act == BT_ACT_GELU) v = gelu_tail2(v2f{v, v}).x;
+            if (ep.res) v += bf16_to_f32(ep.res[(int64_t)my_m * ep.ldr + n].x);
+            ep.out[(int64_t)my_m * ep.ldo + n].x = f32_to_bf16(v);
+        }
+    }
+}
+
 // ---- generic tiled kernel (fp32 parity path; any M, N, K, strides) --------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_generic_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ W,
@@ -1690,6 +1790,28 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                 }
             }
 #undef BT_LAUNCH_256
+        } else if (M <= 4 && !ep.q.enabled && g_gemm_variant != 1 && g_gemm_variant != 22 && (K % 512 == 0) && (lda % 8 == 0) &&
+                   (K % 8 == 0) && aligned16(A) && aligned16(W) && !g_force_generic) {
+            // a handful of rows: pure weight streaming (one launch, no fp32 partials).  Measured (bench.py, hipGraph replay):
+            // B = 1 decode 700 -> 1084 tok/s; at M = 8 the per-row VALU work catches up with the split-K MFMA path, so M <= 4.
+            ProfScope ps(BT_PROF_LINEAR_MFMA, s);
+            const int mr = M <= 1 ? 1 : (M <= 2 ? 2 : 4);
+            // rows per wave: keep >= ~512 workgroups in flight while giving a wave several rows' loads to overlap
+            const int rw = N >= 32768 ? 4 : (N >= 4096 ? 2 : 1);
+#define BT_LAUNCH_GEMV(MR_, RW_)                                                                                       \
+    hipLaunchKernelGGL((gemv_bf16_kernel<MR_, RW_>), dim3((unsigned)ceil_div(N, 4 * RW_)), dim3(256), 0, s, (const bf16*)A, \
+                       lda, (const bf16*)W, K, ep, (int)K)
+#define BT_GEMV_RW(MR_)                                   \
+    do {                                                  \
+        if (rw == 4) BT_LAUNCH_GEMV(MR_, 4);              \
+        else if (rw == 2) BT_LAUNCH_GEMV(MR_, 2);         \
+        else BT_LAUNCH_GEMV(MR_, 1);                      \
+    } while (0)
+            if (mr == 1) BT_GEMV_RW(1);
+            else if (mr == 2) BT_GEMV_RW(2);
+            else BT_GEMV_RW(4);
+#undef BT_GEMV_RW
+#undef BT_LAUNCH_GEMV
         } else if (mfma_ok && scratch && !ep.q.enabled && g_gemm_variant != 1 && (N % 8 == 0) && (ldo % 8 == 0) &&
                    aligned16(out) && (!residual || (ldr % 8 == 0 && aligned16(residual))) && (!bias || aligned16(bias)) &&
                    aligned16(scratch) && ceil_div(M, 64) * ceil_div(N, 64) < 256) {

@@ -230,6 +230,42 @@ def test_linear_splitk_skinny(M, N, K, variant):
     assert rel_err(out, base.double()) <= 1.2e-2
 
 
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 8])
+@pytest.mark.parametrize("N,K", [(2048, 2048), (6144, 2048), (2048, 8192), (50, 512), (4099, 2560), (50304, 2048)])
+@pytest.mark.parametrize("variant", ["plain", "bias_gelu", "bias_res"])
+def test_linear_gemv_few_rows(M, N, K, variant):
+    """Few rows (M <= 4: the weight-streaming GEMV kernel, K % 512 == 0; 5..8: split-K / tile kernels) == fp64 reference, element-wise within bf16 rounding,
+    == the MFMA path (variant 22 disables the GEMV), with strided x / out / residual rows and N not a multiple of the
+    rows-per-workgroup."""
+    x = rnd(M, K + 64, seed=1).bfloat16().to(DEV)[:, :K]
+    w = rnd(N, K, seed=2, scale=K ** -0.5).bfloat16().to(DEV)
+    b = rnd(N, seed=3).bfloat16().to(DEV) if variant != "plain" else None
+    r = rnd(M, N + 8, seed=4).bfloat16().to(DEV)[:, :N] if variant == "bias_res" else None
+    ref = x.double().cpu() @ w.double().cpu().T
+    if b is not None:
+        ref = ref + b.double().cpu()
+    if variant == "bias_gelu":
+        ref = F.gelu(ref)
+    if r is not None:
+        ref = ref + r.double().cpu()
+    act = "gelu" if variant == "bias_gelu" else "none"
+    buf = torch.full((M, N + 16), float("nan"), dtype=torch.bfloat16, device=DEV)
+    out = buf[:, :N]
+    ops.linear(x, w, b, r, act=act, out=out)
+    torch.cuda.synchronize()
+    assert torch.isnan(buf[:, N:].float()).all(), "columns beyond N must not be written"
+    got = out.double().cpu()
+    assert rel_err(got, ref) <= 1.2e-2, rel_err(got, ref)
+    err = (got - ref).abs()
+    assert float((err - 1.6e-2 * ref.abs() - 2e-2).max()) <= 0, float(err.max())
+    lib().bt_debug_gemm_variant(22)
+    try:
+        base = ops.linear(x, w, b, r, act=act).double().cpu()
+    finally:
+        lib().bt_debug_gemm_variant(0)
+    assert rel_err(got, base) <= 1.2e-2
+
+
 def test_linear_strided_inplace_residual():
     """Row strides + in-place residual (x += att @ Wd^T + b), the way bt_decoder_forward calls it."""
     for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 1.2e-2)):

@@ -174,9 +174,15 @@ def main():
             res[-1]["max_rel_diff_vs_vendor"] = err
     elif args.what == "skinny":
         for M in (1, 8, 64, 128, 256):
-            for (N, K) in ((6144, 2048), (2048, 2048), (8192, 2048), (2048, 8192), (4096, 2048)):
+            for (N, K) in ((6144, 2048), (2048, 2048), (8192, 2048), (2048, 8192), (4096, 2048), (50304, 2048)):
                 for sc in (False, True):
                     res.append(probe_gemm(M, N, K, 30, scratch=sc))
+                if M <= 8:   # GEMV off: the split-K MFMA path it replaces
+                    lib().bt_debug_gemm_variant(22)
+                    r = probe_gemm(M, N, K, 30, scratch=True)
+                    r["variant"] = "no_gemv"
+                    res.append(r)
+                    lib().bt_debug_gemm_variant(0)
     elif args.what == "abl":
         for (M, N, K) in ((32768, 6144, 2048), (32768, 2048, 8192)):
             for v in (0, 3, 20, 21, 8, 0, 3, 20, 21, 8):   # production / 4-phase one-tile kernel: full, no MFMA, DMA only, MFMA+barriers only
