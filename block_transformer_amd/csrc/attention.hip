@@ -493,13 +493,14 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const bf16* __restri
 //   * waves whose 32 query rows all precede a key tile skip its MFMAs (causal), but still take part in staging.
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 
-template <int D>
+template <int D, int NW = 4>
 __device__ inline void flash_stage_tile(const bf16* __restrict__ kbase, const bf16* __restrict__ vbase, int key0,
                                         int n_keys, char* kbuf, char* vbuf, int wave, int lane) {
     constexpr int ROWB = D * 2;            // bytes per row
     constexpr int SLOTS = ROWB / 16;       // 16-byte slots per row (16 / 8 / 4)
     constexpr int RPI = 1024 / ROWB;       // rows per wave-instruction (4 / 8 / 16)
-    constexpr int NI = 64 / RPI / 4;       // instructions per wave per operand (4 / 2 / 1)
+    constexpr int NI = 64 / RPI / NW;      // instructions per wave per operand
+    static_assert(NI >= 1, "more waves than 1 KiB pieces in a K tile");
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int rbase = (wave * NI + i) * RPI;
@@ -518,8 +519,14 @@ __device__ inline void flash_stage_tile(const bf16* __restrict__ kbase, const bf
     }
 }
 
-template <int D>
-__global__ __launch_bounds__(256, 2) void flash_prefill_v2_kernel(const bf16* __restrict__ qkv, int64_t ld_qkv,
+// NW waves x 32 query rows per workgroup, ST-deep ring of 64-key K/V tiles (LDS-DMA, ST-1 tiles in flight).
+//   <D, 4, 2>  128 query rows, double buffer, two workgroups per CU: production.
+//   <D, 8, 4>  256 query rows (K/V tiles loaded once per 256 rows), three tiles in flight, one workgroup per CU: measured
+//              the SAME speed (287-307 TF at n = 512), i.e. the tile loop is not waiting for its loads -- it is
+//              instruction-issue / dependency bound (~450 non-MFMA instructions and ~30 waits per 64 MFMAs, two waves
+//              per SIMD at 240 VGPRs).  Kept as test variant 2.
+template <int D, int NW, int ST>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void flash_prefill_v2_kernel(const bf16* __restrict__ qkv, int64_t ld_qkv,
                                                               const bf16* __restrict__ kc, const bf16* __restrict__ vc,
                                                               int64_t n_max, const int32_t* __restrict__ pos0_dev,
                                                               int pos0_host, const uint8_t* __restrict__ mask,
@@ -528,25 +535,25 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_v2_kernel(const bf16* __
     constexpr int KK = D / 32, DF = D / 16, QF = 2;
     constexpr int ROWB = D * 2, SLOTS = ROWB / 16;
     constexpr int TILE_B = FK_TILE * ROWB;  // bytes of one K (or V) tile
-    __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];  // [buf][K | V]
+    constexpr int FQ = NW * 32;                                          // query rows per workgroup
+    constexpr int NI = 64 / (1024 / ROWB) / NW;                          // DMA instructions per wave, operand and tile
+    __shared__ __attribute__((aligned(16))) char smem[ST * 2 * TILE_B];  // [stage][K | V]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
     const int qb = blockIdx.x, head = blockIdx.y;
     const int64_t b = blockIdx.z;
     const int pos0 = pos0_dev ? *pos0_dev : pos0_host;
-    const int qbase = qb * FQ_ROWS + wave * (QF * 16);
+    const int qbase = qb * FQ + wave * (QF * 16);
 
     const bf16* kbase = kc + (b * heads + head) * n_max * D;
     const bf16* vbase = vc + (b * heads + head) * n_max * D;
     const uint8_t* mrow = mask ? mask + b * mask_ld : nullptr;
-    const int last_q = min(q_len, (qb + 1) * FQ_ROWS) - 1;
+    const int last_q = min(q_len, (qb + 1) * FQ) - 1;
     const int n_keys = pos0 + last_q + 1;
     const int n_tiles = (n_keys + FK_TILE - 1) / FK_TILE;
     const int wave_last_pos = pos0 + min(qbase + QF * 16, q_len) - 1;  // last query position this wave owns
     const float sl2 = scale * 1.44269504088896340736f;                 // softmax in base 2
-
-    flash_stage_tile<D>(kbase, vbase, 0, n_keys, smem, smem + TILE_B, wave, lane);
 
     bf16x8_t qf[QF][KK];
     int qrow[QF];
@@ -570,16 +577,47 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_v2_kernel(const bf16* __
         lrun[f] = 0.f;
     }
 
+    // lane-constant LDS offsets of the fragment reads (the XOR swizzles make them non-affine in kk / d, so they are
+    // tabulated once instead of being recomputed for every tile: ~350 VALU instructions per tile and wave)
+    int kaddr[KK], vaddr[DF];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) kaddr[kk] = l15 * ROWB + (((kk * 4 + g) ^ (l15 & (SLOTS - 1))) * 16);
+    {
+        const int rl = g * 4 + (l15 >> 2);                            // row inside a 16-row group of the transpose read
+        const int swz = (((rl & 7) << 1) & (SLOTS - 1)) << 4;
+#pragma unroll
+        for (int d = 0; d < DF; ++d) vaddr[d] = rl * ROWB + (((d * 16 + (l15 & 3) * 4) * 2) ^ swz);
+    }
+    // the Q fragments are loaded first (older than every DMA), then tiles 0 .. ST-2 go into the ring
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#pragma unroll
+    for (int x = 0; x < ST - 1; ++x)
+        if (x < n_tiles)
+            flash_stage_tile<D, NW>(kbase, vbase, x * FK_TILE, n_keys, smem + x * 2 * TILE_B, smem + x * 2 * TILE_B + TILE_B, wave,
+                                    lane);
 
     for (int kt = 0; kt < n_tiles; ++kt) {
         const int key0 = kt * FK_TILE;
-        const char* kb = smem + (kt & 1) * 2 * TILE_B;
+        const char* kb = smem + (kt % ST) * 2 * TILE_B;
         const char* vb = kb + TILE_B;
-        if (kt + 1 < n_tiles) {
-            char* nb = smem + ((kt + 1) & 1) * 2 * TILE_B;
-            flash_stage_tile<D>(kbase, vbase, key0 + FK_TILE, n_keys, nb, nb + TILE_B, wave, lane);
+        {   // this wave's share of tile kt has landed; the (up to ST-2) younger tiles stay in flight: 2*NI DMAs each
+            const int younger = min(ST - 2, n_tiles - 1 - kt);
+            if (younger >= 2) {
+                if (NI == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+                else if (NI == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            } else if (younger == 1) {
+                if (NI == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (NI == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+        }
+        __syncthreads();   // tile kt visible to everybody; everybody is done with tile kt-1 -> its stage can be refilled
+        if (kt + ST - 1 < n_tiles) {
+            char* nb = smem + ((kt + ST - 1) % ST) * 2 * TILE_B;
+            flash_stage_tile<D, NW>(kbase, vbase, key0 + (ST - 1) * FK_TILE, n_keys, nb, nb + TILE_B, wave, lane);
         }
         if (key0 <= wave_last_pos) {  // wave-uniform: some query of this wave can see this tile
             f32x4_t sacc[QF][4];
@@ -589,11 +627,9 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_v2_kernel(const bf16* __
                 for (int kf = 0; kf < 4; ++kf) sacc[f][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf) {
-                const int row = kf * 16 + l15;
 #pragma unroll
                 for (int kk = 0; kk < KK; ++kk) {
-                    const int slot = (kk * 4 + g) ^ (row & (SLOTS - 1));
-                    const bf16x8_t kfr = *reinterpret_cast<const bf16x8_t*>(kb + row * ROWB + slot * 16);
+                    const bf16x8_t kfr = *reinterpret_cast<const bf16x8_t*>(kb + kaddr[kk] + kf * 16 * ROWB);
 #pragma unroll
                     for (int f = 0; f < QF; ++f)
                         sacc[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[f][kk], sacc[f][kf], 0, 0, 0);
@@ -679,13 +715,11 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_v2_kernel(const bf16* __
                     pf[f] = pk.v;
                 }
                 // transpose-read addresses: lane i of a 16-lane group supplies row kb + (i >> 2), columns (i & 3) * 4
-                const int r1 = (2 * ks) * 16 + g * 4 + (l15 >> 2);
-                const int r2 = r1 + 16;
+                // (rows (2 ks) * 16 + rl and + 16; the row's swizzle depends on rl & 7 only)
 #pragma unroll
                 for (int d = 0; d < DF; ++d) {
-                    const int colb = (d * 16 + (l15 & 3) * 4) * 2;  // byte offset of the 8-byte chunk inside the row
-                    const int a1 = r1 * ROWB + (colb ^ ((((r1 & 7) << 1) & (SLOTS - 1)) << 4));
-                    const int a2 = r2 * ROWB + (colb ^ ((((r2 & 7) << 1) & (SLOTS - 1)) << 4));
+                    const int a1 = vaddr[d] + (2 * ks) * 16 * ROWB;
+                    const int a2 = a1 + 16 * ROWB;
                     union {
                         s16x4_t h[2];
                         bf16x8_t v;
@@ -698,13 +732,11 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_v2_kernel(const bf16* __
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
-    // epilogue: normalise, stage the 128 x D output tile through LDS (K/V buffers are free now) and store whole rows with
+    // epilogue: normalise, stage the FQ x D output tile through LDS (K/V buffers are free now) and store whole rows with
     // coalesced 16-byte accesses (a lane owns single bf16 values of 4 rows: direct stores would be 2 bytes per lane)
     constexpr int OP = ROWB + 16;  // padded LDS pitch of the output tile
-    static_assert(FQ_ROWS * OP <= 4 * TILE_B, "output tile must fit in the K/V staging LDS");
+    static_assert(FQ * OP <= ST * 2 * TILE_B, "output tile must fit in the K/V staging LDS");
     __syncthreads();
 #pragma unroll
     for (int f = 0; f < QF; ++f) {
@@ -723,9 +755,9 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_v2_kernel(const bf16* __
     }
     __syncthreads();
     constexpr int CPR = ROWB / 16;
-    for (int idx = tid; idx < FQ_ROWS * CPR; idx += 256) {
+    for (int idx = tid; idx < FQ * CPR; idx += NW * 64) {
         const int rl = idx / CPR, c = idx - rl * CPR;
-        const int row = qb * FQ_ROWS + rl;
+        const int row = qb * FQ + rl;
         if (row < q_len)
             *reinterpret_cast<uint4*>(out + (b * q_len + row) * ldo + (int64_t)head * D + c * 8) =
                 *reinterpret_cast<const uint4*>(smem + rl * OP + c * 16);
@@ -772,7 +804,8 @@ static int launch_attend(int64_t B, int q_len, int heads, const void* qkv, int64
     return BT_OK;
 }
 
-static int g_flash_variant = 0;  // 0 = v2 (LDS-DMA + transpose reads), 1 = v1 (register/LDS-transposed V)
+static int g_flash_variant = 0;  // 0 = v2 <4 waves, double buffer> (LDS-DMA + transpose reads), 2 = v2 <8 waves, 4-deep ring>,
+                                 // 1 = v1 (register/LDS-transposed V)
 
 template <int D>
 static int launch_flash(int64_t B, int q_len, int heads, const void* qkv, int64_t ld_qkv, const void* kc, const void* vc,
@@ -785,10 +818,16 @@ static int launch_flash(int64_t B, int q_len, int heads, const void* qkv, int64_
         hipLaunchKernelGGL(flash_prefill_kernel<D>, grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)kc,
                            (const bf16*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (bf16*)out, ldo, q_len, heads,
                            scale);
-    else
-        hipLaunchKernelGGL(flash_prefill_v2_kernel<D>, grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)kc,
-                           (const bf16*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (bf16*)out, ldo, q_len, heads,
-                           scale);
+    else if (g_flash_variant != 2 || D < 64)   // production: 4 waves, double buffer, two workgroups per CU
+        hipLaunchKernelGGL((flash_prefill_v2_kernel<D, 4, 2>), grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv,
+                           (const bf16*)kc, (const bf16*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (bf16*)out, ldo, q_len,
+                           heads, scale);
+    else if constexpr (D >= 64) {   // variant 2 (A/B): 8 waves, 4-deep ring -- same speed: the loop is issue-bound, not load-bound
+        const dim3 grid8((unsigned)ceil_div(q_len, 256), (unsigned)heads, (unsigned)B);
+        hipLaunchKernelGGL((flash_prefill_v2_kernel<D, 8, 4>), grid8, dim3(512), 0, s, (const bf16*)qkv, ld_qkv,
+                           (const bf16*)kc, (const bf16*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (bf16*)out, ldo, q_len,
+                           heads, scale);
+    }
     BT_LAUNCH_CHECK("bt_attention(flash) launch");
     return BT_OK;
 }

@@ -508,16 +508,17 @@ def test_attention_rows_mask(dtype):
         assert out.view(B, -1)[1].abs().max() == 0
 
 
-@pytest.fixture(params=[0, 1], ids=["flash_v2", "flash_v1"])
+@pytest.fixture(params=[0, 2, 1], ids=["flash_v2_4w2s", "flash_v2_8w4s", "flash_v1"])
 def flash_variant(request):
-    """0 = LDS-DMA + ds_read_b64_tr_b16 kernel (default), 1 = first-generation kernel (kept for A/B)."""
+    """0 = LDS-DMA + ds_read_b64_tr_b16 kernel, 4 waves / 128 query rows / double buffer (default), 2 = the same kernel
+    with 8 waves / 256 query rows / 4-deep K/V ring (d >= 64), 1 = first-generation kernel (kept for A/B)."""
     lib().bt_debug_flash_variant(request.param)
     yield request.param
     lib().bt_debug_flash_variant(0)
 
 
 @pytest.mark.parametrize("d", [32, 64, 128])
-@pytest.mark.parametrize("q,pos0", [(5, 0), (64, 0), (130, 0), (512, 0), (200, 56), (257, 0)])
+@pytest.mark.parametrize("q,pos0", [(5, 0), (64, 0), (130, 0), (512, 0), (200, 56), (257, 0), (700, 0), (300, 212)])
 def test_attention_flash_prefill(d, q, pos0, flash_variant):
     """bf16 MFMA flash kernels vs fp64 reference (tolerance: P is rounded to bf16 before PV, ~2^-8 relative)."""
     n_max = pos0 + q + 3

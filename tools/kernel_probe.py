@@ -122,10 +122,10 @@ def main():
             res.append(r)
         lib().bt_debug_attn_nt(0)
     elif args.what == "flash":
-        for v in (0, 1, 0, 1):
+        for v in (0, 2, 1, 0, 2, 1):
             lib().bt_debug_flash_variant(v)
             r = probe_flash(args.batch, args.keys, args.iters)
-            r["variant"] = "v2" if v == 0 else "v1"
+            r["variant"] = {0: "v2 <4 waves, double buffer>", 2: "v2 <8 waves, 4-deep ring>", 1: "v1"}[v]
             res.append(r)
         lib().bt_debug_flash_variant(0)
     elif args.what == "copy":
