@@ -37,8 +37,8 @@ def timed(fn, iters, warmup=3):
     return a.elapsed_time(b) / iters  # ms
 
 
-def probe_gemm(M, N, K, iters, act="none", bias=True, res=False, scratch=False):
-    x = (torch.randn(M, K, device=DEV) * 1.0).bfloat16()
+def probe_gemm(M, N, K, iters, act="none", bias=True, res=False, scratch=False, pad_a=0):
+    x = (torch.randn(M, K + pad_a, device=DEV) * 1.0).bfloat16()[:, :K]   # pad_a: row pitch of A = K + pad_a elements
     w = (torch.randn(N, K, device=DEV) * K ** -0.5).bfloat16()
     b = torch.randn(N, device=DEV).bfloat16() if bias else None
     r = torch.randn(M, N, device=DEV).bfloat16() if res else None
@@ -99,7 +99,7 @@ def probe_copy(nbytes, iters):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["gemm", "attn", "flash", "suite", "copy", "ab", "abl", "skinny", "decode", "vendor"])
+    ap.add_argument("what", choices=["gemm", "attn", "flash", "suite", "copy", "ab", "abl", "skinny", "decode", "vendor", "pitch"])
     ap.add_argument("--m", type=int, default=32768)
     ap.add_argument("--n", type=int, default=6144)
     ap.add_argument("--k", type=int, default=2048)
@@ -172,6 +172,13 @@ def main():
             ref = F.linear(x, w, b).float()
             err = float((out.float() - ref).abs().max() / ref.abs().max())
             res[-1]["max_rel_diff_vs_vendor"] = err
+    elif args.what == "pitch":
+        # partition-camping check: A rows at a power-of-two pitch (K * 2 bytes) vs padded pitches
+        for (M, N, K) in ((32768, 2048, 8192), (32768, 8192, 2048), (32768, 6144, 2048)):
+            for pad in (0, 64, 128, 0, 64, 128):
+                r = probe_gemm(M, N, K, 10, pad_a=pad)
+                r["pad_a"] = pad
+                res.append(r)
     elif args.what == "skinny":
         for M in (1, 8, 64, 128, 256):
             for (N, K) in ((6144, 2048), (2048, 2048), (8192, 2048), (2048, 8192), (4096, 2048), (50304, 2048)):
