@@ -11,6 +11,9 @@
 
 using namespace bt;
 
+static bool g_no_few_rows_fusion = false;   // test hook: run 1..4-row stacks through the unfused launch sequence (A/B, parity)
+extern "C" void bt_debug_no_few_rows_fusion(int on) { g_no_few_rows_fusion = on != 0; }
+
 static int64_t ws_elems(const bt_decoder_dims* d, int64_t M) {
     return M * ((int64_t)d->hidden * 5 + d->inter);
 }
@@ -60,11 +63,31 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
     // the last layer's attention output / dense / MLP are needed for that row alone: the other rows of that layer only
     // contribute their K,V (cache) — skip 9/12 of the last layer's GEMM flops and its attention, exactly.
     const bool tail_only = (q_len > 1) && (first_out_row == q_len - 1);
+    // the fused small-batch path: same conditions as bt_ln_linear / bt_ln_qkv_rope_append accept (checked up front so a
+    // layer never runs half fused), every row consumed (q_len rows per sequence all feed the next layer)
+    const bool few_rows = dtype == BT_BF16 && M <= 4 && !tail_only && H % 512 == 0 && H <= 2048 && dims->rot == 32 &&
+                          dims->head_dim % 32 == 0 && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) && !g_no_few_rows_fusion;
     for (int l = 0; l < dims->layers; ++l) {
         const bt_layer_weights& lw = w->layers_host[l];
         char* kc = reinterpret_cast<char*>(attn->k_cache) + (int64_t)l * attn->layer_stride * es;
         char* vc = reinterpret_cast<char*>(attn->v_cache) + (int64_t)l * attn->layer_stride * es;
         const bool last = tail_only && (l == dims->layers - 1);
+        if (few_rows) {
+            // 1..4 rows (small-batch decode, launch-bound): LayerNorms, RoPE and the KV append ride inside the weight-
+            // streaming GEMVs -- 5 launches per layer instead of 7.  The MLP's first projection reads the layer INPUT
+            // (parallel residual), so it runs before the attention output projection updates x in place.
+            BT_TRY(bt_ln_qkv_rope_append(dtype, B, q_len, dims->heads, dims->head_dim, dims->rot, x, H, lw.ln1_w, lw.ln1_b,
+                                         dims->ln_eps, lw.qkv_w, lw.qkv_b, qkv, 3 * H, kc, vc, attn->n_max, attn->pos0_dev,
+                                         attn->pos0_host, attn->pos_table, attn->cos_tab, attn->sin_tab, stream));
+            BT_TRY(bt_attention(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc, attn->n_max,
+                                attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H, attn->n_split,
+                                attn->split_ws, attn->split_ws_bytes, stream));
+            BT_TRY(bt_ln_linear(dtype, M, I, H, x, H, lw.ln2_w, lw.ln2_b, dims->ln_eps, lw.h4_w, lw.h4_b, nullptr, 0, h4, I,
+                                BT_ACT_GELU, stream));
+            BT_TRY(bt_linear_ws(dtype, M, H, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, BT_ACT_NONE, scratch, sk_bytes, stream));
+            BT_TRY(bt_linear_ws(dtype, M, H, I, h4, I, lw.h_w, lw.h_b, x, H, x, H, BT_ACT_NONE, scratch, sk_bytes, stream));
+            continue;
+        }
         if (!last) {
             BT_TRY(bt_layernorm(dtype, M, H, x, H, lw.ln1_w, lw.ln1_b, ln1, H, lw.ln2_w, lw.ln2_b, ln2, H, dims->ln_eps,
                                 stream));

@@ -1540,16 +1540,35 @@ __device__ inline float dot8_bf16(const uint4& w, const uint4& x, float acc) {
     return acc;
 }
 
-template <int MR, int RW>
+// LN: the staged x rows are LayerNorm-ed in LDS first (gamma / beta / eps in `ln`; needs K <= GV_KC so a row's statistics
+// see the whole row): removes the separate LayerNorm launch in front of the QKV and h->4h projections.  QKV: the wave owns
+// the row PAIR (n, n + 16) of a 32-column group, so the lane that finishes row m can rotate the pair (RoPE) and scatter
+// q to the qkv buffer / k, v to their KV-cache rows itself: removes the RoPE + append launch.  Small-batch decode is
+// launch-bound (~5 us per dependent launch): 7 -> 5 launches per layer.
+struct LnPro {
+    const bf16* w;
+    const bf16* b;
+    float eps;
+};
+
+template <int MR, int RW, bool LN = false, bool QKV = false>
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W,
-                                                       int64_t ldw, const EpiArgs ep, int K) {
+                                                       int64_t ldw, const EpiArgs ep, int K, const LnPro ln) {
+    static_assert(!QKV || RW == 2, "QKV mode works on row pairs");
     __shared__ __attribute__((aligned(16))) char xs[MR * GV_KC * 2];
+    __shared__ float red[2][4][MR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = ep.M, N = ep.N;
-    const int n_blk = blockIdx.x * (4 * RW);
     int rows[RW];
+    if (QKV) {   // pair p = (32-column group p >> 4, column p & 15 of it) and its rotate-half partner 16 columns further
+        const int p = blockIdx.x * 4 + wave;
+        rows[0] = (p >> 4) * 32 + (p & 15);
+        rows[RW - 1] = rows[0] + 16;
+    } else {
+        const int n_blk = blockIdx.x * (4 * RW);
 #pragma unroll
-    for (int r = 0; r < RW; ++r) rows[r] = n_blk + wave + 4 * r;   // consecutive rows go to different waves
+        for (int r = 0; r < RW; ++r) rows[r] = n_blk + wave + 4 * r;   // consecutive rows go to different waves
+    }
     float acc[RW][MR];
 #pragma unroll
     for (int r = 0; r < RW; ++r)
@@ -1576,6 +1595,56 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__
                 wv[r][j] = (j * 512 < kw) ? *reinterpret_cast<const uint4*>(wp + j * 512) : uint4{0, 0, 0, 0};
         }
         __syncthreads();
+        if (LN) {   // K <= GV_KC: the chunk is the whole row.  Thread t owns the 16-byte piece t of every row.
+            const bool own = tid < kw / 8;
+            float v[MR][8];
+            float part[MR];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                part[m] = 0.f;
+                if (own) {
+                    load_vec<bf16>(reinterpret_cast<const bf16*>(xs + (m * GV_KC + tid * 8) * 2), v[m]);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) part[m] += v[m][i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[m][i] = 0.f;
+                }
+                part[m] = wave_sum(part[m]);
+                if (lane == 0) red[0][wave][m] = part[m];
+            }
+            __syncthreads();
+            float mean[MR];
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                mean[m] = (red[0][0][m] + red[0][1][m] + red[0][2][m] + red[0][3][m]) / (float)kw;
+                float sq = 0.f;
+                if (own) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float d = v[m][i] - mean[m];
+                        sq = fmaf(d, d, sq);
+                    }
+                }
+                sq = wave_sum(sq);
+                if (lane == 0) red[1][wave][m] = sq;
+            }
+            __syncthreads();
+            if (own) {
+                float gam[8], bet[8];
+                load_vec<bf16>(ln.w + tid * 8, gam);
+                load_vec<bf16>(ln.b + tid * 8, bet);
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    const float rstd = rsqrtf((red[1][0][m] + red[1][1][m] + red[1][2][m] + red[1][3][m]) / (float)kw + ln.eps);
+                    float y[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) y[i] = (v[m][i] - mean[m]) * rstd * gam[i] + bet[i];
+                    store_vec<bf16>(reinterpret_cast<bf16*>(xs + (m * GV_KC + tid * 8) * 2), y);   // bf16, as bt_layernorm writes it
+                }
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int j = 0; j < GV_KC / 512; ++j) {
             if (j * 512 < kw) {
@@ -1588,11 +1657,49 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__
             }
         }
     }
-    // finish the dot products; afterwards every lane holds every sum, and lane (r * MR + m) stores element (m, rows[r])
+    // finish the dot products; afterwards every lane holds every sum
 #pragma unroll
     for (int r = 0; r < RW; ++r)
 #pragma unroll
         for (int m = 0; m < MR; ++m) acc[r][m] = wave_sum(acc[r][m]);
+    if (QKV) {   // lane m finishes row m: bias, rotate the (n, n + 16) pair when it lies in dims 0..31 of a q / k head, scatter
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int m = 0; m < MR; ++m)
+            if (lane == m) {
+                v0 = acc[0][m];
+                v1 = acc[RW - 1][m];
+            }
+        const int n0 = rows[0], n1 = rows[RW - 1];
+        if (lane < M && n1 < N) {
+            const int m = lane;
+            if (ep.bias) {
+                v0 += bf16_to_f32(ep.bias[n0].x);
+                v1 += bf16_to_f32(ep.bias[n1].x);
+            }
+            const int D = ep.q.head_dim;
+            const int head = n0 / (3 * D);
+            const int within = n0 - head * 3 * D;
+            const int part = within / D;              // 0 q, 1 k, 2 v
+            const int el = within - part * D;         // n1 holds el + 16 of the same part (D % 32 == 0)
+            const int64_t b = m / ep.q.q_len;
+            const int t = m - (int)b * ep.q.q_len;
+            const int pos0 = ep.q.pos0_dev ? *ep.q.pos0_dev : ep.q.pos0_host;
+            if (part < 2 && el < 16) {
+                const int rpos = ep.q.pos_table ? ep.q.pos_table[pos0 + t] : pos0 + t;
+                const float c = ep.q.cos_tab[(int64_t)rpos * 16 + el], sn = ep.q.sin_tab[(int64_t)rpos * 16 + el];
+                const float x1 = v0, x2 = v1;
+                v0 = x1 * c - x2 * sn;
+                v1 = x2 * c + x1 * sn;
+            }
+            bf16* dst = part == 0 ? ep.out + (int64_t)m * ep.ldo + n0
+                                  : (part == 1 ? ep.q.kc : ep.q.vc) + ((b * ep.q.heads + head) * ep.q.n_max + pos0 + t) * D + el;
+            dst[0].x = f32_to_bf16(v0);
+            dst[16].x = f32_to_bf16(v1);
+        }
+        return;
+    }
+    // lane (r * MR + m) stores element (m, rows[r])
     float mine = 0.f;
     int my_r = 0, my_m = 0;
 #pragma unroll
@@ -1800,7 +1907,7 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
             const int rw = N >= 32768 ? 4 : (N >= 4096 ? 2 : 1);
 #define BT_LAUNCH_GEMV(MR_, RW_)                                                                                       \
     hipLaunchKernelGGL((gemv_bf16_kernel<MR_, RW_>), dim3((unsigned)ceil_div(N, 4 * RW_)), dim3(256), 0, s, (const bf16*)A, \
-                       lda, (const bf16*)W, K, ep, (int)K)
+                       lda, (const bf16*)W, K, ep, (int)K, LnPro{})
 #define BT_GEMV_RW(MR_)                                   \
     do {                                                  \
         if (rw == 4) BT_LAUNCH_GEMV(MR_, 4);              \
@@ -1917,6 +2024,118 @@ extern "C" int bt_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_t h
     if (!fused)
         BT_TRY(bt_rope_kv_append(dtype, B, q_len, heads, head_dim, rot, qkv, ld_qkv, k_cache, v_cache, n_max, pos0_dev,
                                  pos0_host, pos_table, cos_tab, sin_tab, stream));
+    return BT_OK;
+}
+
+// ---- fused small-batch entry points (M <= 4 rows; see gemv_bf16_kernel) -------------------------------------------------
+static bool gemv_ln_ok(int dtype, int64_t M, int64_t N, int64_t K, const void* x, int64_t ldx, const void* W,
+                       const void* ln_w, const void* ln_b) {
+    return dtype == BT_BF16 && M >= 1 && M <= 4 && K % 512 == 0 && K <= GV_KC && ldx % 8 == 0 && aligned16(x) && aligned16(W) &&
+           aligned16(ln_w) && aligned16(ln_b) && !g_force_generic && g_gemm_variant != 22 && N > 0;
+}
+
+extern "C" int bt_ln_linear(int dtype, int64_t M, int64_t N, int64_t K, const void* x, int64_t ldx, const void* ln_w,
+                            const void* ln_b, float eps, const void* W, const void* bias, const void* residual, int64_t ldr,
+                            void* out, int64_t ldo, int act, bt_stream stream) {
+    BT_CHECK_ARG(x && ln_w && ln_b && W && out, "bt_ln_linear: null pointer");
+    BT_CHECK_ARG(act == BT_ACT_NONE || act == BT_ACT_GELU, "bt_ln_linear: bad activation %d", act);
+    if (!gemv_ln_ok(dtype, M, N, K, x, ldx, W, ln_w, ln_b)) {
+        set_error("bt_ln_linear: only bf16, 1 <= M <= 4, K %% 512 == 0, K <= %d, 16-byte aligned operands (M=%lld K=%lld)", GV_KC,
+                  (long long)M, (long long)K);
+        return BT_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    EpiArgs ep;
+    ep.bias = (const bf16*)bias;
+    ep.res = (const bf16*)residual;
+    ep.ldr = ldr;
+    ep.out = (bf16*)out;
+    ep.ldo = ldo;
+    ep.M = (int)M;
+    ep.N = (int)N;
+    ep.act = act;
+    ep.q = QkvEpi{};
+    const LnPro ln{(const bf16*)ln_w, (const bf16*)ln_b, eps};
+    ProfScope ps(BT_PROF_LINEAR_MFMA, s);
+    const int rw = N >= 32768 ? 4 : (N >= 4096 ? 2 : 1);
+#define BT_LAUNCH_GEMV_LN(MR_, RW_)                                                                                        \
+    hipLaunchKernelGGL((gemv_bf16_kernel<MR_, RW_, true, false>), dim3((unsigned)ceil_div(N, 4 * RW_)), dim3(256), 0, s,       \
+                       (const bf16*)x, ldx, (const bf16*)W, K, ep, (int)K, ln)
+#define BT_GEMV_LN_RW(MR_)                                   \
+    do {                                                     \
+        if (rw == 4) BT_LAUNCH_GEMV_LN(MR_, 4);              \
+        else if (rw == 2) BT_LAUNCH_GEMV_LN(MR_, 2);         \
+        else BT_LAUNCH_GEMV_LN(MR_, 1);                      \
+    } while (0)
+    if (M <= 1) BT_GEMV_LN_RW(1);
+    else if (M <= 2) BT_GEMV_LN_RW(2);
+    else BT_GEMV_LN_RW(4);
+#undef BT_GEMV_LN_RW
+#undef BT_LAUNCH_GEMV_LN
+    BT_LAUNCH_CHECK("bt_ln_linear launch");
+    return BT_OK;
+}
+
+extern "C" int bt_ln_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim, int32_t rot,
+                                     const void* x, int64_t ldx, const void* ln_w, const void* ln_b, float eps,
+                                     const void* qkv_w, const void* qkv_b, void* qkv, int64_t ld_qkv, void* k_cache,
+                                     void* v_cache, int64_t n_max, const int32_t* pos0_dev, int32_t pos0_host,
+                                     const int32_t* pos_table, const float* cos_tab, const float* sin_tab, bt_stream stream) {
+    BT_CHECK_ARG(B >= 0 && q_len > 0 && heads > 0 && head_dim > 0, "bt_ln_qkv_rope_append: bad shape");
+    BT_CHECK_ARG(x && qkv_w && qkv && k_cache && v_cache && cos_tab && sin_tab, "bt_ln_qkv_rope_append: null pointer");
+    BT_CHECK_ARG(pos0_dev || (pos0_host >= 0 && pos0_host + q_len <= n_max), "bt_ln_qkv_rope_append: cache overflow");
+    const int64_t H = (int64_t)heads * head_dim;
+    const int64_t M = B * q_len;
+    // ln_w == NULL: no LayerNorm prologue (x is already normalised) -- RoPE / append fusion only
+    const bool ln_on = ln_w != nullptr;
+    const bool ok = dtype == BT_BF16 && M >= 1 && M <= 4 && H % 512 == 0 && (!ln_on || H <= GV_KC) && ldx % 8 == 0 && aligned16(x) &&
+                    aligned16(qkv_w) && (!ln_on || (ln_b && aligned16(ln_w) && aligned16(ln_b))) && rot == 32 &&
+                    head_dim % 32 == 0 && !g_force_generic && g_gemm_variant != 22;
+    if (!ok) {
+        set_error("bt_ln_qkv_rope_append: only bf16, 1 <= rows <= 4, hidden %% 512 == 0 (<= %d with LayerNorm), rot == 32, "
+                  "head_dim %% 32 == 0", GV_KC);
+        return BT_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    EpiArgs ep;
+    ep.bias = (const bf16*)qkv_b;
+    ep.res = nullptr;
+    ep.ldr = 0;
+    ep.out = (bf16*)qkv;
+    ep.ldo = ld_qkv;
+    ep.M = (int)M;
+    ep.N = (int)(3 * H);
+    ep.act = BT_ACT_NONE;
+    ep.q = QkvEpi{};
+    ep.q.kc = (bf16*)k_cache;
+    ep.q.vc = (bf16*)v_cache;
+    ep.q.n_max = n_max;
+    ep.q.pos0_dev = pos0_dev;
+    ep.q.pos_table = pos_table;
+    ep.q.cos_tab = cos_tab;
+    ep.q.sin_tab = sin_tab;
+    ep.q.pos0_host = pos0_host;
+    ep.q.q_len = q_len;
+    ep.q.heads = heads;
+    ep.q.head_dim = head_dim;
+    ep.q.enabled = 1;
+    const LnPro ln{(const bf16*)ln_w, (const bf16*)ln_b, eps};
+    ProfScope ps(BT_PROF_LINEAR_MFMA, s);
+    const unsigned grid = (unsigned)ceil_div(3 * H / 2, 4);   // one wave per (n, n + 16) pair, 4 pairs per workgroup
+#define BT_LAUNCH_GEMV_QKV(MR_)                                                                                       \
+    do {                                                                                                              \
+        if (ln_on)                                                                                                    \
+            hipLaunchKernelGGL((gemv_bf16_kernel<MR_, 2, true, true>), dim3(grid), dim3(256), 0, s, (const bf16*)x, ldx, \
+                               (const bf16*)qkv_w, H, ep, (int)H, ln);                                                \
+        else                                                                                                          \
+            hipLaunchKernelGGL((gemv_bf16_kernel<MR_, 2, false, true>), dim3(grid), dim3(256), 0, s, (const bf16*)x, ldx, \
+                               (const bf16*)qkv_w, H, ep, (int)H, ln);                                                \
+    } while (0)
+    if (M <= 1) BT_LAUNCH_GEMV_QKV(1);
+    else if (M <= 2) BT_LAUNCH_GEMV_QKV(2);
+    else BT_LAUNCH_GEMV_QKV(4);
+#undef BT_LAUNCH_GEMV_QKV
+    BT_LAUNCH_CHECK("bt_ln_qkv_rope_append launch");
     return BT_OK;
 }
 

@@ -135,6 +135,23 @@ int bt_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_t heads, int32
                        const int32_t* pos_table, const float* cos_tab, const float* sin_tab, void* scratch,
                        int64_t scratch_bytes, bt_stream stream);   /* scratch: optional split-K scratch, see bt_linear_ws */
 
+/* Small-batch decode (1 <= rows <= 4, bf16): the same projections as single weight-streaming launches with the neighbouring
+ * elementwise ops folded in (small-batch decode is launch-bound: ~5 us per dependent launch).
+ *   bt_ln_linear:          out = act(LayerNorm(x; ln_w, ln_b, eps) . W^T + bias) + residual      (K % 512 == 0, K <= 2048)
+ *                          = HF GPTNeoXLayer.{input,post_attention}_layernorm + the nn.Linear that follows it
+ *   bt_ln_qkv_rope_append: bt_qkv_rope_append with the layer's input LayerNorm in front (ln_w == NULL: no LayerNorm) and
+ *                          RoPE + KV append done by the GEMV itself (rot == 32, head_dim % 32 == 0, hidden % 512 == 0)
+ * Both return BT_ERR_UNSUPPORTED (nothing launched) for any other configuration; the caller then uses bt_layernorm +
+ * bt_linear / bt_qkv_rope_append (bt_decoder_forward does exactly that). */
+int bt_ln_linear(int dtype, int64_t M, int64_t N, int64_t K, const void* x, int64_t ldx, const void* ln_w, const void* ln_b,
+                 float eps, const void* W, const void* bias, const void* residual, int64_t ldr, void* out, int64_t ldo,
+                 int act, bt_stream stream);
+int bt_ln_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim, int32_t rot, const void* x,
+                          int64_t ldx, const void* ln_w, const void* ln_b, float eps, const void* qkv_w, const void* qkv_b,
+                          void* qkv, int64_t ld_qkv, void* k_cache, void* v_cache, int64_t n_max, const int32_t* pos0_dev,
+                          int32_t pos0_host, const int32_t* pos_table, const float* cos_tab, const float* sin_tab,
+                          bt_stream stream);
+
 /* Causal softmax attention of q_len (already rotated) query rows per sequence over the cache:
  *   query t sees keys j <= pos0 + t with mask[b, j] != 0 (mask may be NULL);  out[b*q_len+t, head*d + :]
  * mode: 0 = row-wise streaming kernel (decode: q_len = 1 global step, or the token decoder's <= E+L-1 window);

@@ -266,6 +266,94 @@ def test_linear_gemv_few_rows(M, N, K, variant):
     assert rel_err(got, base) <= 1.2e-2
 
 
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+@pytest.mark.parametrize("N,K", [(2048, 2048), (8192, 2048), (1000, 512), (4099, 1536), (50304, 1024)])
+@pytest.mark.parametrize("variant", ["plain", "bias_gelu", "bias_res"])
+def test_ln_linear_few_rows(M, N, K, variant):
+    """bt_ln_linear: LayerNorm folded into the weight-streaming GEMV (small-batch decode) == LayerNorm (bf16 output, as
+    bt_layernorm writes it) followed by the linear layer, in fp64; and == the unfused pair of calls."""
+    x = (rnd(M, K + 8, seed=1) * 3.0 + 0.5).bfloat16().to(DEV)[:, :K]
+    g_, b_ = (1.0 + 0.2 * rnd(K, seed=5)).bfloat16().to(DEV), (0.1 * rnd(K, seed=6)).bfloat16().to(DEV)
+    w = rnd(N, K, seed=2, scale=K ** -0.5).bfloat16().to(DEV)
+    bias = rnd(N, seed=3).bfloat16().to(DEV) if variant != "plain" else None
+    r = rnd(M, N, seed=4).bfloat16().to(DEV) if variant == "bias_res" else None
+    eps = 1e-5
+    ln = F.layer_norm(x.double().cpu(), (K,), g_.double().cpu(), b_.double().cpu(), eps).bfloat16().double()
+    ref = ln @ w.double().cpu().T
+    if bias is not None:
+        ref = ref + bias.double().cpu()
+    if variant == "bias_gelu":
+        ref = F.gelu(ref)
+    if r is not None:
+        ref = ref + r.double().cpu()
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    check(lib().bt_ln_linear(_lib.BT_BF16, M, N, K, ptr(x), x.stride(0), ptr(g_), ptr(b_), eps, ptr(w), ptr(bias), ptr(r),
+                             0 if r is None else r.stride(0), ptr(out), N, 1 if variant == "bias_gelu" else 0,
+                             current_stream()))
+    torch.cuda.synchronize()
+    got = out.double().cpu()
+    assert rel_err(got, ref) <= 1.2e-2, rel_err(got, ref)
+    err = (got - ref).abs()
+    assert float((err - 2e-2 * ref.abs() - 3e-2).max()) <= 0, float(err.max())
+    unfused = ops.linear(ops.layernorm(x.contiguous(), g_, b_, eps), w, bias, r,
+                         act="gelu" if variant == "bias_gelu" else "none").double().cpu()
+    assert rel_err(got, unfused) <= 6e-3
+
+
+def test_ln_linear_rejects_what_it_cannot_fuse():
+    x = rnd(5, 2048, seed=1).bfloat16().to(DEV)
+    w = rnd(64, 2048, seed=2).bfloat16().to(DEV)
+    g_ = torch.ones(2048, dtype=torch.bfloat16, device=DEV)
+    out = torch.empty(5, 64, dtype=torch.bfloat16, device=DEV)
+    rc = lib().bt_ln_linear(_lib.BT_BF16, 5, 64, 2048, ptr(x), 2048, ptr(g_), ptr(g_), 1e-5, ptr(w), None, None, 0, ptr(out),
+                            64, 0, current_stream())
+    assert rc == -2 and b"M" in lib().bt_last_error()           # BT_ERR_UNSUPPORTED: 5 rows
+    rc = lib().bt_ln_linear(_lib.BT_BF16, 2, 64, 4096, ptr(x), 4096, ptr(g_), ptr(g_), 1e-5, ptr(w), None, None, 0, ptr(out),
+                            64, 0, current_stream())
+    assert rc == -2                                             # K > 2048: a row's statistics would span chunks
+
+
+@pytest.mark.parametrize("B,q", [(1, 1), (3, 1), (4, 1), (1, 2), (2, 2)])
+@pytest.mark.parametrize("heads,d", [(16, 128), (8, 64), (16, 32), (4, 128)])
+@pytest.mark.parametrize("use_ln", [True, False])
+@pytest.mark.parametrize("use_dev_pos,use_table", [(False, False), (True, True)])
+def test_ln_qkv_rope_append_few_rows(B, q, heads, d, use_ln, use_dev_pos, use_table):
+    """bt_ln_qkv_rope_append (LayerNorm + QKV GEMV + RoPE + KV append in one launch) == bt_layernorm + bt_qkv_rope_append
+    (unfused reference path of this library, itself pinned against fp64 above)."""
+    H, rot, pos0 = heads * d, 32, 3
+    n_max = pos0 + q + 2
+    x = (rnd(B * q, H, seed=1) * 2.0).bfloat16().to(DEV)
+    g_, b_ = (1.0 + 0.2 * rnd(H, seed=5)).bfloat16().to(DEV), (0.1 * rnd(H, seed=6)).bfloat16().to(DEV)
+    w = rnd(3 * H, H, seed=2, scale=H ** -0.5).bfloat16().to(DEV)
+    bias = rnd(3 * H, seed=3, scale=0.1).bfloat16().to(DEV)
+    tab = ops.rope_tables(1024, rot, 10000.0, DEV)
+    table = (torch.arange(n_max, dtype=torch.int32) * 3 % 17).to(DEV) if use_table else None
+    pos_dev = torch.tensor([pos0], dtype=torch.int32, device=DEV) if use_dev_pos else None
+
+    def caches():
+        return (torch.zeros(B, heads, n_max, d, dtype=torch.bfloat16, device=DEV),
+                torch.zeros(B, heads, n_max, d, dtype=torch.bfloat16, device=DEV),
+                torch.full((B * q, 3 * H), float("nan"), dtype=torch.bfloat16, device=DEV))
+
+    kc1, vc1, qkv1 = caches()
+    check(lib().bt_ln_qkv_rope_append(_lib.BT_BF16, B, q, heads, d, rot, ptr(x), H, ptr(g_) if use_ln else None,
+                                      ptr(b_) if use_ln else None, 1e-5, ptr(w), ptr(bias), ptr(qkv1), 3 * H, ptr(kc1),
+                                      ptr(vc1), n_max, ptr(pos_dev), 0 if use_dev_pos else pos0, ptr(table), ptr(tab[0]),
+                                      ptr(tab[1]), current_stream()))
+    kc2, vc2, qkv2 = caches()
+    xin = ops.layernorm(x, g_, b_, 1e-5) if use_ln else x
+    check(lib().bt_qkv_rope_append(_lib.BT_BF16, B, q, heads, d, rot, ptr(xin), H, ptr(w), ptr(bias), ptr(qkv2), 3 * H,
+                                   ptr(kc2), ptr(vc2), n_max, ptr(pos_dev), 0 if use_dev_pos else pos0, ptr(table),
+                                   ptr(tab[0]), ptr(tab[1]), None, 0, current_stream()))
+    torch.cuda.synchronize()
+    q1 = qkv1.view(B * q, heads, 3, d)[:, :, 0].double().cpu()
+    q2 = qkv2.view(B * q, heads, 3, d)[:, :, 0].double().cpu()
+    assert rel_err(q1, q2) <= 6e-3
+    assert rel_err(kc1.double().cpu(), kc2.double().cpu()) <= 6e-3 and rel_err(vc1.double().cpu(), vc2.double().cpu()) <= 6e-3
+    assert float(kc1[:, :, :pos0].abs().sum()) == 0 and float(kc1[:, :, pos0 + q:].abs().sum()) == 0
+    assert torch.isnan(qkv1.view(B * q, heads, 3, d)[:, :, 1:].float()).all(), "k / v columns of qkv are not written"
+
+
 def test_linear_strided_inplace_residual():
     """Row strides + in-place residual (x += att @ Wd^T + b), the way bt_decoder_forward calls it."""
     for dtype, tol in ((torch.float32, 2e-5), (torch.bfloat16, 1.2e-2)):
