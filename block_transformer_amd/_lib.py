@@ -59,6 +59,8 @@ _SIGS = {
                                    c_void_p, c_void_p, c_int64, c_void_p]),
     "bt_ln_linear": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_float, c_void_p,
                              c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
+    "bt_linear2": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                           c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "bt_ln_qkv_rope_append": (c_int, [c_int, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p,
                                       c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                       c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -74,7 +74,7 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
         const bool last = tail_only && (l == dims->layers - 1);
         if (few_rows) {
             // 1..4 rows (small-batch decode, launch-bound): LayerNorms, RoPE and the KV append ride inside the weight-
-            // streaming GEMVs -- 5 launches per layer instead of 7.  The MLP's first projection reads the layer INPUT
+            // streaming GEMVs, and the two residual-stream projections share one -- 4 launches per layer instead of 7.  The MLP's first projection reads the layer INPUT
             // (parallel residual), so it runs before the attention output projection updates x in place.
             BT_TRY(bt_ln_qkv_rope_append(dtype, B, q_len, dims->heads, dims->head_dim, dims->rot, x, H, lw.ln1_w, lw.ln1_b,
                                          dims->ln_eps, lw.qkv_w, lw.qkv_b, qkv, 3 * H, kc, vc, attn->n_max, attn->pos0_dev,
@@ -84,8 +84,13 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
                                 attn->split_ws, attn->split_ws_bytes, stream));
             BT_TRY(bt_ln_linear(dtype, M, I, H, x, H, lw.ln2_w, lw.ln2_b, dims->ln_eps, lw.h4_w, lw.h4_b, nullptr, 0, h4, I,
                                 BT_ACT_GELU, stream));
-            BT_TRY(bt_linear_ws(dtype, M, H, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, BT_ACT_NONE, scratch, sk_bytes, stream));
-            BT_TRY(bt_linear_ws(dtype, M, H, I, h4, I, lw.h_w, lw.h_b, x, H, x, H, BT_ACT_NONE, scratch, sk_bytes, stream));
+            // x += mlp_down(h4) + attn_dense(att): both residual-stream projections in one launch (K = I, then K = H)
+            if (I % 2048 == 0) {
+                BT_TRY(bt_linear2(dtype, M, H, I, h4, I, lw.h_w, lw.h_b, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, stream));
+            } else {
+                BT_TRY(bt_linear_ws(dtype, M, H, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, BT_ACT_NONE, scratch, sk_bytes, stream));
+                BT_TRY(bt_linear_ws(dtype, M, H, I, h4, I, lw.h_w, lw.h_b, x, H, x, H, BT_ACT_NONE, scratch, sk_bytes, stream));
+            }
             continue;
         }
         if (!last) {

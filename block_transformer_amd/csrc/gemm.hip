@@ -1551,9 +1551,20 @@ struct LnPro {
     float eps;
 };
 
+// optional second (x2, W2) operand pair accumulated onto the same outputs: out = x . W^T + x2 . W2^T + bias + bias2 [+ res]
+// (the two residual-stream projections of a parallel-residual layer -- attention output and MLP down -- in one launch)
+struct Seg2 {
+    const bf16* x;
+    const bf16* w;
+    const bf16* bias;
+    int64_t ldx, ldw;
+    int K;
+};
+
 template <int MR, int RW, bool LN = false, bool QKV = false>
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W,
-                                                       int64_t ldw, const EpiArgs ep, int K, const LnPro ln) {
+                                                       int64_t ldw, const EpiArgs ep, int K, const LnPro ln,
+                                                       const Seg2 s2 = Seg2{}) {
     static_assert(!QKV || RW == 2, "QKV mode works on row pairs");
     __shared__ __attribute__((aligned(16))) char xs[MR * GV_KC * 2];
     __shared__ float red[2][4][MR];
@@ -1575,13 +1586,19 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__
 #pragma unroll
         for (int m = 0; m < MR; ++m) acc[r][m] = 0.f;
 
-    for (int kc = 0; kc < K; kc += GV_KC) {
-        const int kw = min(GV_KC, K - kc);            // multiple of 512
+    const int k_all = K + ((LN || QKV) ? 0 : s2.K);   // K chunks of the first operand pair, then of the second
+    for (int kg = 0; kg < k_all; kg += GV_KC) {
+        const bool second = kg >= K;                   // (K is a multiple of GV_KC whenever a second segment follows)
+        const int kc = second ? kg - K : kg;
+        const bf16* Xs = second ? s2.x : X;
+        const bf16* Ws = second ? s2.w : W;
+        const int64_t ldxs = second ? s2.ldx : ldx, ldws = second ? s2.ldw : ldw;
+        const int kw = min(GV_KC, (second ? s2.K : K) - kc);   // multiple of 512
         __syncthreads();                               // previous chunk fully consumed
         for (int idx = tid; idx < MR * (kw / 8); idx += 256) {
             const int m = idx / (kw / 8), c = idx - m * (kw / 8);
             uint4 v = uint4{0, 0, 0, 0};
-            if (m < M) v = *reinterpret_cast<const uint4*>(X + (int64_t)m * ldx + kc + c * 8);
+            if (m < M) v = *reinterpret_cast<const uint4*>(Xs + (int64_t)m * ldxs + kc + c * 8);
             *reinterpret_cast<uint4*>(xs + (m * GV_KC + c * 8) * 2) = v;
         }
         // this wave's W rows of the chunk: all loads in flight before the first use
@@ -1589,7 +1606,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             const int n = rows[r] < N ? rows[r] : N - 1;
-            const bf16* wp = W + (int64_t)n * ldw + kc + lane * 8;
+            const bf16* wp = Ws + (int64_t)n * ldws + kc + lane * 8;
 #pragma unroll
             for (int j = 0; j < GV_KC / 512; ++j)
                 wv[r][j] = (j * 512 < kw) ? *reinterpret_cast<const uint4*>(wp + j * 512) : uint4{0, 0, 0, 0};
@@ -1719,6 +1736,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__
         if (my_m < M && n < N) {
             float v = mine;
             if (ep.bias) v += bf16_to_f32(ep.bias[n].x);
+            if (s2.bias) v += bf16_to_f32(s2.bias[n].x);
             if (ep.act == BT_ACT_GELU) v = gelu_tail2(v2f{v, v}).x;
             if (ep.res) v += bf16_to_f32(ep.res[(int64_t)my_m * ep.ldr + n].x);
             ep.out[(int64_t)my_m * ep.ldo + n].x = f32_to_bf16(v);
@@ -2136,6 +2154,55 @@ extern "C" int bt_ln_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_
     else BT_LAUNCH_GEMV_QKV(4);
 #undef BT_LAUNCH_GEMV_QKV
     BT_LAUNCH_CHECK("bt_ln_qkv_rope_append launch");
+    return BT_OK;
+}
+
+extern "C" int bt_linear2(int dtype, int64_t M, int64_t N, int64_t K1, const void* x1, int64_t ldx1, const void* W1,
+                          const void* bias1, int64_t K2, const void* x2, int64_t ldx2, const void* W2, const void* bias2,
+                          const void* residual, int64_t ldr, void* out, int64_t ldo, bt_stream stream) {
+    BT_CHECK_ARG(x1 && W1 && x2 && W2 && out, "bt_linear2: null pointer");
+    const bool ok = dtype == BT_BF16 && M >= 1 && M <= 4 && N > 0 && K1 % GV_KC == 0 && K2 % 512 == 0 && K1 > 0 && K2 > 0 &&
+                    ldx1 % 8 == 0 && ldx2 % 8 == 0 && aligned16(x1) && aligned16(x2) && aligned16(W1) && aligned16(W2) &&
+                    !g_force_generic && g_gemm_variant != 22;
+    if (!ok) {
+        set_error("bt_linear2: only bf16, 1 <= M <= 4, K1 %% %d == 0, K2 %% 512 == 0, 16-byte aligned operands", GV_KC);
+        return BT_ERR_UNSUPPORTED;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    EpiArgs ep;
+    ep.bias = (const bf16*)bias1;
+    ep.res = (const bf16*)residual;
+    ep.ldr = ldr;
+    ep.out = (bf16*)out;
+    ep.ldo = ldo;
+    ep.M = (int)M;
+    ep.N = (int)N;
+    ep.act = BT_ACT_NONE;
+    ep.q = QkvEpi{};
+    Seg2 s2;
+    s2.x = (const bf16*)x2;
+    s2.w = (const bf16*)W2;
+    s2.bias = (const bf16*)bias2;
+    s2.ldx = ldx2;
+    s2.ldw = K2;
+    s2.K = (int)K2;
+    ProfScope ps(BT_PROF_LINEAR_MFMA, s);
+    const int rw = N >= 32768 ? 4 : (N >= 4096 ? 2 : 1);
+#define BT_LAUNCH_GEMV2(MR_, RW_)                                                                                        \
+    hipLaunchKernelGGL((gemv_bf16_kernel<MR_, RW_>), dim3((unsigned)ceil_div(N, 4 * RW_)), dim3(256), 0, s, (const bf16*)x1, \
+                       ldx1, (const bf16*)W1, K1, ep, (int)K1, LnPro{}, s2)
+#define BT_GEMV2_RW(MR_)                                   \
+    do {                                                   \
+        if (rw == 4) BT_LAUNCH_GEMV2(MR_, 4);              \
+        else if (rw == 2) BT_LAUNCH_GEMV2(MR_, 2);         \
+        else BT_LAUNCH_GEMV2(MR_, 1);                      \
+    } while (0)
+    if (M <= 1) BT_GEMV2_RW(1);
+    else if (M <= 2) BT_GEMV2_RW(2);
+    else BT_GEMV2_RW(4);
+#undef BT_GEMV2_RW
+#undef BT_LAUNCH_GEMV2
+    BT_LAUNCH_CHECK("bt_linear2 launch");
     return BT_OK;
 }
 

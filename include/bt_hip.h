@@ -146,6 +146,12 @@ int bt_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_t heads, int32
 int bt_ln_linear(int dtype, int64_t M, int64_t N, int64_t K, const void* x, int64_t ldx, const void* ln_w, const void* ln_b,
                  float eps, const void* W, const void* bias, const void* residual, int64_t ldr, void* out, int64_t ldo,
                  int act, bt_stream stream);
+/*   bt_linear2:            out = x1 . W1^T + bias1 + x2 . W2^T + bias2 + residual   (K1 % 2048 == 0, K2 % 512 == 0): the two
+ *                          projections that feed the residual stream of a parallel-residual layer (attention.dense and
+ *                          mlp.dense_4h_to_h) as one launch */
+int bt_linear2(int dtype, int64_t M, int64_t N, int64_t K1, const void* x1, int64_t ldx1, const void* W1, const void* bias1,
+               int64_t K2, const void* x2, int64_t ldx2, const void* W2, const void* bias2, const void* residual,
+               int64_t ldr, void* out, int64_t ldo, bt_stream stream);
 int bt_ln_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim, int32_t rot, const void* x,
                           int64_t ldx, const void* ln_w, const void* ln_b, float eps, const void* qkv_w, const void* qkv_b,
                           void* qkv, int64_t ld_qkv, void* k_cache, void* v_cache, int64_t n_max, const int32_t* pos0_dev,

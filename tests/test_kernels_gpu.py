@@ -300,6 +300,31 @@ def test_ln_linear_few_rows(M, N, K, variant):
     assert rel_err(got, unfused) <= 6e-3
 
 
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+@pytest.mark.parametrize("N,K1,K2", [(2048, 8192, 2048), (1024, 4096, 1024), (1000, 2048, 512), (50, 2048, 1536)])
+def test_linear2_two_projections_one_launch(M, N, K1, K2):
+    """bt_linear2: out = res + x1 W1^T + b1 + x2 W2^T + b2 (mlp down + attention dense of a parallel-residual layer), in
+    place on the residual stream, == fp64 and == the two separate bt_linear calls."""
+    x1 = rnd(M, K1, seed=1).bfloat16().to(DEV)
+    x2 = rnd(M, K2 + 8, seed=2).bfloat16().to(DEV)[:, :K2]
+    w1 = rnd(N, K1, seed=3, scale=K1 ** -0.5).bfloat16().to(DEV)
+    w2 = rnd(N, K2, seed=4, scale=K2 ** -0.5).bfloat16().to(DEV)
+    b1, b2 = rnd(N, seed=5).bfloat16().to(DEV), rnd(N, seed=6).bfloat16().to(DEV)
+    hid = rnd(M, N + 16, seed=7).bfloat16().to(DEV)
+    view = hid[:, :N]
+    ref = (view.double().cpu() + x1.double().cpu() @ w1.double().cpu().T + b1.double().cpu()
+           + x2.double().cpu() @ w2.double().cpu().T + b2.double().cpu())
+    two = ops.linear(x2.contiguous(), w2, b2, ops.linear(x1, w1, b1, view.contiguous())).double().cpu()
+    pad = hid[:, N:].clone()
+    check(lib().bt_linear2(_lib.BT_BF16, M, N, K1, ptr(x1), K1, ptr(w1), ptr(b1), K2, ptr(x2), x2.stride(0), ptr(w2), ptr(b2),
+                           ptr(view), hid.stride(0), ptr(view), hid.stride(0), current_stream()))
+    torch.cuda.synchronize()
+    got = view.double().cpu()
+    assert rel_err(got, ref) <= 8e-3, rel_err(got, ref)
+    assert rel_err(got, two) <= 1.2e-2
+    assert torch.equal(hid[:, N:], pad)
+
+
 def test_ln_linear_rejects_what_it_cannot_fuse():
     x = rnd(5, 2048, seed=1).bfloat16().to(DEV)
     w = rnd(64, 2048, seed=2).bfloat16().to(DEV)
