@@ -64,8 +64,9 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
     // contribute their K,V (cache) — skip 9/12 of the last layer's GEMM flops and its attention, exactly.
     const bool tail_only = (q_len > 1) && (first_out_row == q_len - 1);
     // the fused small-batch path: same conditions as bt_ln_linear / bt_ln_qkv_rope_append accept (checked up front so a
-    // layer never runs half fused), every row consumed (q_len rows per sequence all feed the next layer)
-    const bool few_rows = dtype == BT_BF16 && M <= 4 && !tail_only && H % 512 == 0 && H <= 2048 && dims->rot == 32 &&
+    // layer never runs half fused).  With so few rows the last-layer shortcut for tail-only callers is not worth a
+    // second launch sequence: every layer runs on every row and the final LayerNorm picks the rows the caller consumes.
+    const bool few_rows = dtype == BT_BF16 && M <= 4 && H % 512 == 0 && H <= 2048 && dims->rot == 32 &&
                           dims->head_dim % 32 == 0 && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) && !g_no_few_rows_fusion;
     for (int l = 0; l < dims->layers; ++l) {
         const bt_layer_weights& lw = w->layers_host[l];
