@@ -699,7 +699,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256_kernel(const bf16* __re
 // Two half-tile loads are issued per phase, PD2 = 6 loads ahead (consumption order A0,W0,W1,A1).
 //   RAW: before the barrier that opens phase g every wave has waited for the loads that phase reads;
 //   WAR: load s+8 reuses the slot of load s and is issued >= 1 barrier after the last read of s (checked by simulation,
-//        tests/test_host_logic.py::test_gemm_ring_schedules).
+//        tests/test_gemm_ring_schedule.py).
 constexpr int PD2 = 6;
 
 __device__ inline void wait_for_phase2(int g, int total_loads) {
