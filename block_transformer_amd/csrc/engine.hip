@@ -11,6 +11,9 @@
 
 using namespace bt;
 
+static int g_few_rows_max = 16;             // rows up to which a stack takes the fused single-launch projections (the
+                                            // entry points accept <= 64; beyond ~16 rows split-K + reduce is faster)
+extern "C" void bt_debug_few_rows_max(int n) { g_few_rows_max = n; }
 static bool g_no_few_rows_fusion = false;   // test hook: run 1..4-row stacks through the unfused launch sequence (A/B, parity)
 extern "C" void bt_debug_no_few_rows_fusion(int on) { g_no_few_rows_fusion = on != 0; }
 
@@ -66,7 +69,8 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
     // the fused small-batch path: same conditions as bt_ln_linear / bt_ln_qkv_rope_append accept (checked up front so a
     // layer never runs half fused).  With so few rows the last-layer shortcut for tail-only callers is not worth a
     // second launch sequence: every layer runs on every row and the final LayerNorm picks the rows the caller consumes.
-    const bool few_rows = dtype == BT_BF16 && M <= 4 && H % 512 == 0 && H <= 2048 && dims->rot == 32 &&
+    const bool few_rows = dtype == BT_BF16 && M <= g_few_rows_max && (M > 4 ? (H % 32 == 0 && I % 32 == 0) : (H % 512 == 0 && H <= 2048)) &&
+                          dims->rot == 32 &&
                           dims->head_dim % 32 == 0 && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) && !g_no_few_rows_fusion;
     for (int l = 0; l < dims->layers; ++l) {
         const bt_layer_weights& lw = w->layers_host[l];
@@ -86,7 +90,7 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
             BT_TRY(bt_ln_linear(dtype, M, I, H, x, H, lw.ln2_w, lw.ln2_b, dims->ln_eps, lw.h4_w, lw.h4_b, nullptr, 0, h4, I,
                                 BT_ACT_GELU, stream));
             // x += mlp_down(h4) + attn_dense(att): both residual-stream projections in one launch (K = I, then K = H)
-            if (I % 2048 == 0) {
+            if (M > 4 || I % 2048 == 0) {
                 BT_TRY(bt_linear2(dtype, M, H, I, h4, I, lw.h_w, lw.h_b, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, stream));
             } else {
                 BT_TRY(bt_linear_ws(dtype, M, H, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, BT_ACT_NONE, scratch, sk_bytes, stream));

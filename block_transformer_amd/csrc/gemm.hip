@@ -1744,6 +1744,250 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__
     }
 }
 
+// ---- MFMA weight streamer for 5 .. 64 rows (mid-batch decode) ----------------------------------------------------------------
+// Same contract as gemv_bf16_kernel (one launch, W streamed once at HBM speed, LayerNorm / RoPE+append / second operand
+// pair folded in), but the products run on the matrix pipe -- at 8+ rows the GEMV's per-row VALU work is slower than the
+// weight stream.  A workgroup (8 waves) owns 32 rows of W over the whole K; wave w multiplies K slice w: per 32-wide
+// k-step it loads two W fragments (rows n0 .. n0+15 / +16 .. +31; lane = row (lane & 15), 16-byte k-slot (lane >> 4) --
+// 64 contiguous bytes per row) and MT x fragments straight from global memory (x is a few KiB per row and lives in L2)
+// into MFMA operand registers, no LDS.  The 8 partial 32 x M tiles are summed through LDS, and wave mt finishes the 16
+// columns m = 16 mt .. of both row tiles (so the rotate-half partner n + 16 is in the same lane).  LN: per-row mean / rstd
+// are computed first (wave per row), x fragments are normalised in registers as they arrive.
+constexpr int SK_ROWS = 32;
+
+template <int MT, bool LN, bool QKV>
+__global__ __launch_bounds__(512) void skinny_mfma_kernel(const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W,
+                                                         int64_t ldw, const EpiArgs ep, int K, const LnPro ln, const Seg2 s2) {
+    __shared__ __attribute__((aligned(16))) float red[8][2][MT][64][4];
+    __shared__ float stats[MT * 16][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int M = ep.M, N = ep.N;
+    const int n0 = blockIdx.x * SK_ROWS;
+    const int l15 = lane & 15, g = lane >> 4;
+
+    if (LN) {   // a wave per row: two passes over the row (K * 2 bytes, L2-resident)
+        for (int m = wave; m < M; m += 8) {
+            const bf16* xr = X + (int64_t)m * ldx;
+            float sum = 0.f;
+            for (int c = lane * 8; c < K; c += 512) {
+                float v[8];
+                load_vec<bf16>(xr + c, v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) sum += v[i];
+            }
+            const float mean = wave_sum(sum) / (float)K;
+            float sq = 0.f;
+            for (int c = lane * 8; c < K; c += 512) {
+                float v[8];
+                load_vec<bf16>(xr + c, v);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float d = v[i] - mean;
+                    sq = fmaf(d, d, sq);
+                }
+            }
+            const float rstd = rsqrtf(wave_sum(sq) / (float)K + ln.eps);
+            if (lane == 0) {
+                stats[m][0] = mean;
+                stats[m][1] = rstd;
+            }
+        }
+        __syncthreads();
+    }
+    float mean[MT], rstd[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = mt * 16 + l15;
+        mean[mt] = (LN && m < M) ? stats[m][0] : 0.f;
+        rstd[mt] = (LN && m < M) ? stats[m][1] : 0.f;
+    }
+
+    f32x4_t acc[2][MT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[t][mt] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    // k-steps of the first operand pair, then of the second; wave w takes a contiguous range of them
+    const int nks1 = K / 32, nks = nks1 + ((LN || QKV) ? 0 : s2.K / 32);
+    const int per = (nks + 7) / 8;
+    const int ks_lo = wave * per, ks_hi = min(nks, ks_lo + per);
+    int wr[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = n0 + t * 16 + l15;
+        wr[t] = n < N ? n : N - 1;
+    }
+    constexpr int U = 2;
+    for (int ks = ks_lo; ks < ks_hi; ks += U) {
+        uint4 wfr[U][2], xfr[U][MT], gam[U], bet[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int kq = min(ks + u, ks_hi - 1);           // a repeated last step contributes nothing (see below)
+            const bool second = kq >= nks1;
+            const int k0 = (second ? kq - nks1 : kq) * 32 + g * 8;
+            const bf16* Ws = second ? s2.w : W;
+            const bf16* Xs = second ? s2.x : X;
+            const int64_t ldws = second ? s2.ldw : ldw, ldxs = second ? s2.ldx : ldx;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) wfr[u][t] = *reinterpret_cast<const uint4*>(Ws + (int64_t)wr[t] * ldws + k0);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = mt * 16 + l15;
+                xfr[u][mt] = (m < M && ks + u < ks_hi) ? *reinterpret_cast<const uint4*>(Xs + (int64_t)m * ldxs + k0)
+                                                        : uint4{0, 0, 0, 0};
+            }
+            if (LN) {
+                gam[u] = *reinterpret_cast<const uint4*>(ln.w + k0);
+                bet[u] = *reinterpret_cast<const uint4*>(ln.b + k0);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                uint4 xv = xfr[u][mt];
+                if (LN) {   // (x - mean) * rstd * gamma + beta, rounded to bf16 as bt_layernorm writes it
+                    const int m = mt * 16 + l15;
+                    const uint32_t xi[4] = {xv.x, xv.y, xv.z, xv.w};
+                    const uint32_t gi[4] = {gam[u].x, gam[u].y, gam[u].z, gam[u].w};
+                    const uint32_t bi[4] = {bet[u].x, bet[u].y, bet[u].z, bet[u].w};
+                    uint32_t yo[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const float a = (__uint_as_float(xi[i] << 16) - mean[mt]) * rstd[mt] * __uint_as_float(gi[i] << 16) +
+                                        __uint_as_float(bi[i] << 16);
+                        const float b = (__uint_as_float(xi[i] & 0xffff0000u) - mean[mt]) * rstd[mt] *
+                                            __uint_as_float(gi[i] & 0xffff0000u) +
+                                        __uint_as_float(bi[i] & 0xffff0000u);
+                        yo[i] = pack_bf16x2(a, b);
+                    }
+                    const bool live = m < M && ks + u < ks_hi;
+                    xv = live ? uint4{yo[0], yo[1], yo[2], yo[3]} : uint4{0, 0, 0, 0};
+                }
+                union {
+                    uint4 q;
+                    bf16x8_t v;
+                } xb, wb0, wb1;
+                xb.q = xv;
+                wb0.q = wfr[u][0];
+                wb1.q = wfr[u][1];
+                acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb0.v, xb.v, acc[0][mt], 0, 0, 0);
+                acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb1.v, xb.v, acc[1][mt], 0, 0, 0);
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<f32x4_t*>(red[wave][t][mt][lane]) = acc[t][mt];
+    __syncthreads();
+    if (wave >= MT) return;
+    const int mt = wave;
+    f32x4_t v[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        v[t] = *reinterpret_cast<const f32x4_t*>(red[0][t][mt][lane]);
+#pragma unroll
+        for (int w = 1; w < 8; ++w) {
+            const f32x4_t p = *reinterpret_cast<const f32x4_t*>(red[w][t][mt][lane]);
+            v[t][0] += p[0]; v[t][1] += p[1]; v[t][2] += p[2]; v[t][3] += p[3];
+        }
+    }
+    // lane: row m of x, columns n0 + t * 16 + g * 4 .. + 3 of the output
+    const int m = mt * 16 + l15;
+    if (m >= M) return;
+    float o[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = n0 + t * 16 + g * 4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[t][r] = v[t][r];
+        if (n < N) {
+            if (ep.bias) {
+                const uint2 b2 = *reinterpret_cast<const uint2*>(ep.bias + n);
+                o[t][0] += __uint_as_float(b2.x << 16); o[t][1] += __uint_as_float(b2.x & 0xffff0000u);
+                o[t][2] += __uint_as_float(b2.y << 16); o[t][3] += __uint_as_float(b2.y & 0xffff0000u);
+            }
+            if (s2.bias) {
+                const uint2 b2 = *reinterpret_cast<const uint2*>(s2.bias + n);
+                o[t][0] += __uint_as_float(b2.x << 16); o[t][1] += __uint_as_float(b2.x & 0xffff0000u);
+                o[t][2] += __uint_as_float(b2.y << 16); o[t][3] += __uint_as_float(b2.y & 0xffff0000u);
+            }
+        }
+    }
+    if (QKV) {
+        const int D = ep.q.head_dim;
+        const int head = n0 / (3 * D);
+        const int within = n0 - head * 3 * D;
+        const int part = within / D;              // the 32-column group n0 .. n0+31 lies in one part (D % 32 == 0)
+        const int el0 = within - part * D;
+        const int64_t b = m / ep.q.q_len;
+        const int tq = m - (int)b * ep.q.q_len;
+        const int pos0 = ep.q.pos0_dev ? *ep.q.pos0_dev : ep.q.pos0_host;
+        if (part < 2 && el0 == 0) {               // dims 0..31 of a q / k head: column e pairs with e + 16 (the other row tile)
+            const int rpos = ep.q.pos_table ? ep.q.pos_table[pos0 + tq] : pos0 + tq;
+            const float4 c4 = *reinterpret_cast<const float4*>(ep.q.cos_tab + (int64_t)rpos * 16 + g * 4);
+            const float4 s4 = *reinterpret_cast<const float4*>(ep.q.sin_tab + (int64_t)rpos * 16 + g * 4);
+            const float c[4] = {c4.x, c4.y, c4.z, c4.w}, sn[4] = {s4.x, s4.y, s4.z, s4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x1 = o[0][r], x2 = o[1][r];
+                o[0][r] = x1 * c[r] - x2 * sn[r];
+                o[1][r] = x2 * c[r] + x1 * sn[r];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int n = n0 + t * 16 + g * 4;
+            if (n >= N) continue;
+            const int el = el0 + t * 16 + g * 4;
+            bf16* dst = part == 0 ? ep.out + (int64_t)m * ep.ldo + n
+                                  : (part == 1 ? ep.q.kc : ep.q.vc) + ((b * ep.q.heads + head) * ep.q.n_max + pos0 + tq) * D + el;
+            uint2 pk;
+            pk.x = pack_bf16x2(o[t][0], o[t][1]);
+            pk.y = pack_bf16x2(o[t][2], o[t][3]);
+            *reinterpret_cast<uint2*>(dst) = pk;
+        }
+        return;
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = n0 + t * 16 + g * 4;
+        if (n >= N) continue;
+        if (ep.act == BT_ACT_GELU) gelu4(o[t]);
+        if (ep.res) {
+            const uint2 r2 = *reinterpret_cast<const uint2*>(ep.res + (int64_t)m * ep.ldr + n);
+            o[t][0] += __uint_as_float(r2.x << 16); o[t][1] += __uint_as_float(r2.x & 0xffff0000u);
+            o[t][2] += __uint_as_float(r2.y << 16); o[t][3] += __uint_as_float(r2.y & 0xffff0000u);
+        }
+        uint2 pk;
+        pk.x = pack_bf16x2(o[t][0], o[t][1]);
+        pk.y = pack_bf16x2(o[t][2], o[t][3]);
+        *reinterpret_cast<uint2*>(ep.out + (int64_t)m * ep.ldo + n) = pk;
+    }
+}
+
+// launch helper: MT = ceil(M / 16) in 1..4
+template <bool LN, bool QKV>
+static void launch_skinny(hipStream_t s, int64_t M, int64_t N, const bf16* X, int64_t ldx, const bf16* W, int64_t ldw,
+                          const EpiArgs& ep, int64_t K, const LnPro& ln, const Seg2& s2) {
+    const dim3 grid((unsigned)ceil_div(N, SK_ROWS));
+    const int mt = (int)ceil_div(M, 16);
+    if (mt <= 1) hipLaunchKernelGGL((skinny_mfma_kernel<1, LN, QKV>), grid, dim3(512), 0, s, X, ldx, W, ldw, ep, (int)K, ln, s2);
+    else if (mt == 2) hipLaunchKernelGGL((skinny_mfma_kernel<2, LN, QKV>), grid, dim3(512), 0, s, X, ldx, W, ldw, ep, (int)K, ln, s2);
+    else if (mt == 3) hipLaunchKernelGGL((skinny_mfma_kernel<3, LN, QKV>), grid, dim3(512), 0, s, X, ldx, W, ldw, ep, (int)K, ln, s2);
+    else hipLaunchKernelGGL((skinny_mfma_kernel<4, LN, QKV>), grid, dim3(512), 0, s, X, ldx, W, ldw, ep, (int)K, ln, s2);
+}
+
+// common preconditions of the streamer (beyond M <= 64): 8-byte output / bias / residual groups, 16-byte operand pieces
+static bool skinny_ok(int64_t M, int64_t N, int64_t K, const void* x, int64_t ldx, const void* W, const void* bias,
+                      const void* residual, int64_t ldr, const void* out, int64_t ldo) {
+    return M >= 1 && M <= 64 && N % 4 == 0 && K % 32 == 0 && ldx % 8 == 0 && aligned16(x) && aligned16(W) && ldo % 4 == 0 &&
+           (reinterpret_cast<uintptr_t>(out) & 7u) == 0 && (!bias || (reinterpret_cast<uintptr_t>(bias) & 7u) == 0) &&
+           (!residual || (ldr % 4 == 0 && (reinterpret_cast<uintptr_t>(residual) & 7u) == 0));
+}
+
 // ---- generic tiled kernel (fp32 parity path; any M, N, K, strides) --------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_generic_kernel(const T* __restrict__ A, int64_t lda, const T* __restrict__ W,
@@ -1819,6 +2063,8 @@ static int num_cus() {
 }
 
 static bool g_force_generic = false;
+static int g_skinny_rows = 16;   // bt_linear takes the MFMA weight streamer for 5 .. g_skinny_rows rows (kernel: <= 64; measured
+                                 // B = 8: +21 %, 16: +4 %, 32: -20 %, 64: -30 % vs split-K + reduce -> 16)
 static int g_max_wg = 0;   // test hook: cap the persistent kernel's grid so small problems walk several tiles per workgroup
 static bool g_no_qkv_fusion = false;
 static int g_gemm_variant = 0;  // 0 auto; 1 force 128^2; 2/3 256^2 four-phase ring (plain/staggered); 4-8 timing ablations; 9/10 256^2 two-phase
@@ -1937,6 +2183,11 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
             else BT_GEMV_RW(4);
 #undef BT_GEMV_RW
 #undef BT_LAUNCH_GEMV
+        } else if (M <= g_skinny_rows && M <= 64 && !ep.q.enabled && g_gemm_variant != 1 && g_gemm_variant != 22 && !g_force_generic &&
+                   skinny_ok(M, N, K, A, lda, W, bias, residual, ldr, out, ldo)) {
+            // 5 .. 64 rows: one pass over W on the matrix pipe, one launch (no fp32 partials, no reduce kernel)
+            ProfScope ps(BT_PROF_LINEAR_MFMA, s);
+            launch_skinny<false, false>(s, M, N, (const bf16*)A, lda, (const bf16*)W, K, ep, K, LnPro{}, Seg2{});
         } else if (mfma_ok && scratch && !ep.q.enabled && g_gemm_variant != 1 && (N % 8 == 0) && (ldo % 8 == 0) &&
                    aligned16(out) && (!residual || (ldr % 8 == 0 && aligned16(residual))) && (!bias || aligned16(bias)) &&
                    aligned16(scratch) && ceil_div(M, 64) * ceil_div(N, 64) < 256) {
@@ -2057,9 +2308,12 @@ extern "C" int bt_ln_linear(int dtype, int64_t M, int64_t N, int64_t K, const vo
                             void* out, int64_t ldo, int act, bt_stream stream) {
     BT_CHECK_ARG(x && ln_w && ln_b && W && out, "bt_ln_linear: null pointer");
     BT_CHECK_ARG(act == BT_ACT_NONE || act == BT_ACT_GELU, "bt_ln_linear: bad activation %d", act);
-    if (!gemv_ln_ok(dtype, M, N, K, x, ldx, W, ln_w, ln_b)) {
-        set_error("bt_ln_linear: only bf16, 1 <= M <= 4, K %% 512 == 0, K <= %d, 16-byte aligned operands (M=%lld K=%lld)", GV_KC,
-                  (long long)M, (long long)K);
+    const bool gemv = gemv_ln_ok(dtype, M, N, K, x, ldx, W, ln_w, ln_b);
+    const bool skinny = !gemv && dtype == BT_BF16 && M > 4 && skinny_ok(M, N, K, x, ldx, W, bias, residual, ldr, out, ldo) &&
+                        aligned16(ln_w) && aligned16(ln_b) && !g_force_generic && g_gemm_variant != 22;
+    if (!gemv && !skinny) {
+        set_error("bt_ln_linear: only bf16 with 1 <= M <= 4 (K %% 512 == 0, K <= %d) or 5 <= M <= 64 (K %% 32 == 0, N %% 4 == 0), "
+                  "16-byte aligned operands (M=%lld K=%lld)", GV_KC, (long long)M, (long long)K);
         return BT_ERR_UNSUPPORTED;
     }
     hipStream_t s = (hipStream_t)stream;
@@ -2075,6 +2329,11 @@ extern "C" int bt_ln_linear(int dtype, int64_t M, int64_t N, int64_t K, const vo
     ep.q = QkvEpi{};
     const LnPro ln{(const bf16*)ln_w, (const bf16*)ln_b, eps};
     ProfScope ps(BT_PROF_LINEAR_MFMA, s);
+    if (skinny) {
+        launch_skinny<true, false>(s, M, N, (const bf16*)x, ldx, (const bf16*)W, K, ep, K, ln, Seg2{});
+        BT_LAUNCH_CHECK("bt_ln_linear launch");
+        return BT_OK;
+    }
     const int rw = N >= 32768 ? 4 : (N >= 4096 ? 2 : 1);
 #define BT_LAUNCH_GEMV_LN(MR_, RW_)                                                                                        \
     hipLaunchKernelGGL((gemv_bf16_kernel<MR_, RW_, true, false>), dim3((unsigned)ceil_div(N, 4 * RW_)), dim3(256), 0, s,       \
@@ -2106,12 +2365,17 @@ extern "C" int bt_ln_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_
     const int64_t M = B * q_len;
     // ln_w == NULL: no LayerNorm prologue (x is already normalised) -- RoPE / append fusion only
     const bool ln_on = ln_w != nullptr;
-    const bool ok = dtype == BT_BF16 && M >= 1 && M <= 4 && H % 512 == 0 && (!ln_on || H <= GV_KC) && ldx % 8 == 0 && aligned16(x) &&
-                    aligned16(qkv_w) && (!ln_on || (ln_b && aligned16(ln_w) && aligned16(ln_b))) && rot == 32 &&
-                    head_dim % 32 == 0 && !g_force_generic && g_gemm_variant != 22;
-    if (!ok) {
-        set_error("bt_ln_qkv_rope_append: only bf16, 1 <= rows <= 4, hidden %% 512 == 0 (<= %d with LayerNorm), rot == 32, "
-                  "head_dim %% 32 == 0", GV_KC);
+    const bool common = dtype == BT_BF16 && ldx % 8 == 0 && aligned16(x) && aligned16(qkv_w) &&
+                        (!ln_on || (ln_b && aligned16(ln_w) && aligned16(ln_b))) && rot == 32 && head_dim % 32 == 0 &&
+                        !g_force_generic && g_gemm_variant != 22;
+    const bool ok = common && M >= 1 && M <= 4 && H % 512 == 0 && (!ln_on || H <= GV_KC);
+    const bool skinny = common && !ok && M > 4 && M <= 64 && H % 32 == 0 && ld_qkv % 4 == 0 &&
+                        (reinterpret_cast<uintptr_t>(qkv) & 7u) == 0 && (reinterpret_cast<uintptr_t>(k_cache) & 7u) == 0 &&
+                        (reinterpret_cast<uintptr_t>(v_cache) & 7u) == 0 && (!qkv_b || (reinterpret_cast<uintptr_t>(qkv_b) & 7u) == 0) &&
+                        (reinterpret_cast<uintptr_t>(cos_tab) & 15u) == 0 && (reinterpret_cast<uintptr_t>(sin_tab) & 15u) == 0;
+    if (!ok && !skinny) {
+        set_error("bt_ln_qkv_rope_append: only bf16, rot == 32, head_dim %% 32 == 0, and 1 <= rows <= 4 (hidden %% 512 == 0, <= %d "
+                  "with LayerNorm) or 5 <= rows <= 64", GV_KC);
         return BT_ERR_UNSUPPORTED;
     }
     hipStream_t s = (hipStream_t)stream;
@@ -2139,6 +2403,12 @@ extern "C" int bt_ln_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_
     ep.q.enabled = 1;
     const LnPro ln{(const bf16*)ln_w, (const bf16*)ln_b, eps};
     ProfScope ps(BT_PROF_LINEAR_MFMA, s);
+    if (skinny) {
+        if (ln_on) launch_skinny<true, true>(s, M, 3 * H, (const bf16*)x, ldx, (const bf16*)qkv_w, H, ep, H, ln, Seg2{});
+        else launch_skinny<false, true>(s, M, 3 * H, (const bf16*)x, ldx, (const bf16*)qkv_w, H, ep, H, ln, Seg2{});
+        BT_LAUNCH_CHECK("bt_ln_qkv_rope_append launch");
+        return BT_OK;
+    }
     const unsigned grid = (unsigned)ceil_div(3 * H / 2, 4);   // one wave per (n, n + 16) pair, 4 pairs per workgroup
 #define BT_LAUNCH_GEMV_QKV(MR_)                                                                                       \
     do {                                                                                                              \
@@ -2164,8 +2434,12 @@ extern "C" int bt_linear2(int dtype, int64_t M, int64_t N, int64_t K1, const voi
     const bool ok = dtype == BT_BF16 && M >= 1 && M <= 4 && N > 0 && K1 % GV_KC == 0 && K2 % 512 == 0 && K1 > 0 && K2 > 0 &&
                     ldx1 % 8 == 0 && ldx2 % 8 == 0 && aligned16(x1) && aligned16(x2) && aligned16(W1) && aligned16(W2) &&
                     !g_force_generic && g_gemm_variant != 22;
-    if (!ok) {
-        set_error("bt_linear2: only bf16, 1 <= M <= 4, K1 %% %d == 0, K2 %% 512 == 0, 16-byte aligned operands", GV_KC);
+    const bool skinny = !ok && dtype == BT_BF16 && M > 4 && K2 > 0 && K2 % 32 == 0 && ldx2 % 8 == 0 && aligned16(x2) && aligned16(W2) &&
+                        skinny_ok(M, N, K1, x1, ldx1, W1, bias1, residual, ldr, out, ldo) &&
+                        (!bias2 || (reinterpret_cast<uintptr_t>(bias2) & 7u) == 0) && !g_force_generic && g_gemm_variant != 22;
+    if (!ok && !skinny) {
+        set_error("bt_linear2: only bf16 with 1 <= M <= 4 (K1 %% %d == 0, K2 %% 512 == 0) or 5 <= M <= 64 (K %% 32 == 0, N %% 4 == 0), "
+                  "16-byte aligned operands", GV_KC);
         return BT_ERR_UNSUPPORTED;
     }
     hipStream_t s = (hipStream_t)stream;
@@ -2187,6 +2461,11 @@ extern "C" int bt_linear2(int dtype, int64_t M, int64_t N, int64_t K1, const voi
     s2.ldw = K2;
     s2.K = (int)K2;
     ProfScope ps(BT_PROF_LINEAR_MFMA, s);
+    if (skinny) {
+        launch_skinny<false, false>(s, M, N, (const bf16*)x1, ldx1, (const bf16*)W1, K1, ep, K1, LnPro{}, s2);
+        BT_LAUNCH_CHECK("bt_linear2 launch");
+        return BT_OK;
+    }
     const int rw = N >= 32768 ? 4 : (N >= 4096 ? 2 : 1);
 #define BT_LAUNCH_GEMV2(MR_, RW_)                                                                                        \
     hipLaunchKernelGGL((gemv_bf16_kernel<MR_, RW_>), dim3((unsigned)ceil_div(N, 4 * RW_)), dim3(256), 0, s, (const bf16*)x1, \
@@ -2210,4 +2489,5 @@ extern "C" int bt_linear2(int dtype, int64_t M, int64_t N, int64_t K1, const voi
 extern "C" void bt_debug_force_generic_gemm(int on) { g_force_generic = on != 0; }
 extern "C" void bt_debug_gemm_variant(int v) { g_gemm_variant = v; }
 extern "C" void bt_debug_gemm_max_wg(int n) { g_max_wg = n; }
+extern "C" void bt_debug_skinny_rows(int n) { g_skinny_rows = n; }
 extern "C" void bt_debug_no_qkv_fusion(int on) { g_no_qkv_fusion = on != 0; }

@@ -135,18 +135,21 @@ int bt_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_t heads, int32
                        const int32_t* pos_table, const float* cos_tab, const float* sin_tab, void* scratch,
                        int64_t scratch_bytes, bt_stream stream);   /* scratch: optional split-K scratch, see bt_linear_ws */
 
-/* Small-batch decode (1 <= rows <= 4, bf16): the same projections as single weight-streaming launches with the neighbouring
- * elementwise ops folded in (small-batch decode is launch-bound: ~5 us per dependent launch).
- *   bt_ln_linear:          out = act(LayerNorm(x; ln_w, ln_b, eps) . W^T + bias) + residual      (K % 512 == 0, K <= 2048)
+/* Small-batch decode (bf16; 1..4 rows: weight-streaming GEMV kernel, 5..64 rows: MFMA weight streamer): the same
+ * projections as ONE launch each with the neighbouring elementwise ops folded in (small-batch decode is launch-bound:
+ * ~5 us per dependent launch).
+ *   bt_ln_linear:          out = act(LayerNorm(x; ln_w, ln_b, eps) . W^T + bias) + residual
  *                          = HF GPTNeoXLayer.{input,post_attention}_layernorm + the nn.Linear that follows it
+ *                          (1..4 rows: K % 512 == 0, K <= 2048; 5..64 rows: K % 32 == 0, N % 4 == 0)
  *   bt_ln_qkv_rope_append: bt_qkv_rope_append with the layer's input LayerNorm in front (ln_w == NULL: no LayerNorm) and
- *                          RoPE + KV append done by the GEMV itself (rot == 32, head_dim % 32 == 0, hidden % 512 == 0)
- * Both return BT_ERR_UNSUPPORTED (nothing launched) for any other configuration; the caller then uses bt_layernorm +
- * bt_linear / bt_qkv_rope_append (bt_decoder_forward does exactly that). */
+ *                          RoPE + KV append done by the same kernel (rot == 32, head_dim % 32 == 0; 1..4 rows: hidden % 512 == 0)
+ * All three return BT_ERR_UNSUPPORTED (nothing launched) for any other configuration; the caller then uses bt_layernorm +
+ * bt_linear / bt_qkv_rope_append (bt_decoder_forward does exactly that, and takes this route up to 16 rows). */
 int bt_ln_linear(int dtype, int64_t M, int64_t N, int64_t K, const void* x, int64_t ldx, const void* ln_w, const void* ln_b,
                  float eps, const void* W, const void* bias, const void* residual, int64_t ldr, void* out, int64_t ldo,
                  int act, bt_stream stream);
-/*   bt_linear2:            out = x1 . W1^T + bias1 + x2 . W2^T + bias2 + residual   (K1 % 2048 == 0, K2 % 512 == 0): the two
+/*   bt_linear2:            out = x1 . W1^T + bias1 + x2 . W2^T + bias2 + residual   (1..4 rows: K1 % 2048 == 0, K2 % 512 == 0;
+ *                          5..64 rows: K % 32 == 0, N % 4 == 0): the two
  *                          projections that feed the residual stream of a parallel-residual layer (attention.dense and
  *                          mlp.dense_4h_to_h) as one launch */
 int bt_linear2(int dtype, int64_t M, int64_t N, int64_t K1, const void* x1, int64_t ldx1, const void* W1, const void* bias1,

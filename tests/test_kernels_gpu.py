@@ -266,8 +266,8 @@ def test_linear_gemv_few_rows(M, N, K, variant):
     assert rel_err(got, base) <= 1.2e-2
 
 
-@pytest.mark.parametrize("M", [1, 2, 3, 4])
-@pytest.mark.parametrize("N,K", [(2048, 2048), (8192, 2048), (1000, 512), (4099, 1536), (50304, 1024)])
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 16, 33, 64])
+@pytest.mark.parametrize("N,K", [(2048, 2048), (8192, 2048), (1000, 512), (4100, 1536), (50304, 1024)])
 @pytest.mark.parametrize("variant", ["plain", "bias_gelu", "bias_res"])
 def test_ln_linear_few_rows(M, N, K, variant):
     """bt_ln_linear: LayerNorm folded into the weight-streaming GEMV (small-batch decode) == LayerNorm (bf16 output, as
@@ -297,11 +297,11 @@ def test_ln_linear_few_rows(M, N, K, variant):
     assert float((err - 2e-2 * ref.abs() - 3e-2).max()) <= 0, float(err.max())
     unfused = ops.linear(ops.layernorm(x.contiguous(), g_, b_, eps), w, bias, r,
                          act="gelu" if variant == "bias_gelu" else "none").double().cpu()
-    assert rel_err(got, unfused) <= 6e-3
+    assert rel_err(got, unfused) <= 1e-2     # (one bf16 ulp at the largest output: the unfused path adds the residual in bf16)
 
 
-@pytest.mark.parametrize("M", [1, 2, 3, 4])
-@pytest.mark.parametrize("N,K1,K2", [(2048, 8192, 2048), (1024, 4096, 1024), (1000, 2048, 512), (50, 2048, 1536)])
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 7, 16, 40, 64])
+@pytest.mark.parametrize("N,K1,K2", [(2048, 8192, 2048), (1024, 4096, 1024), (1000, 2048, 512), (52, 2048, 1536)])
 def test_linear2_two_projections_one_launch(M, N, K1, K2):
     """bt_linear2: out = res + x1 W1^T + b1 + x2 W2^T + b2 (mlp down + attention dense of a parallel-residual layer), in
     place on the residual stream, == fp64 and == the two separate bt_linear calls."""
@@ -326,19 +326,22 @@ def test_linear2_two_projections_one_launch(M, N, K1, K2):
 
 
 def test_ln_linear_rejects_what_it_cannot_fuse():
-    x = rnd(5, 2048, seed=1).bfloat16().to(DEV)
-    w = rnd(64, 2048, seed=2).bfloat16().to(DEV)
-    g_ = torch.ones(2048, dtype=torch.bfloat16, device=DEV)
-    out = torch.empty(5, 64, dtype=torch.bfloat16, device=DEV)
-    rc = lib().bt_ln_linear(_lib.BT_BF16, 5, 64, 2048, ptr(x), 2048, ptr(g_), ptr(g_), 1e-5, ptr(w), None, None, 0, ptr(out),
+    x = rnd(65, 4096, seed=1).bfloat16().to(DEV)
+    w = rnd(64, 4096, seed=2).bfloat16().to(DEV)
+    g_ = torch.ones(4096, dtype=torch.bfloat16, device=DEV)
+    out = torch.empty(65, 64, dtype=torch.bfloat16, device=DEV)
+    rc = lib().bt_ln_linear(_lib.BT_BF16, 65, 64, 2048, ptr(x), 4096, ptr(g_), ptr(g_), 1e-5, ptr(w), None, None, 0, ptr(out),
                             64, 0, current_stream())
-    assert rc == -2 and b"M" in lib().bt_last_error()           # BT_ERR_UNSUPPORTED: 5 rows
+    assert rc == -2 and b"M" in lib().bt_last_error()           # BT_ERR_UNSUPPORTED: 65 rows
     rc = lib().bt_ln_linear(_lib.BT_BF16, 2, 64, 4096, ptr(x), 4096, ptr(g_), ptr(g_), 1e-5, ptr(w), None, None, 0, ptr(out),
                             64, 0, current_stream())
-    assert rc == -2                                             # K > 2048: a row's statistics would span chunks
+    assert rc == -2                                             # 1..4 rows: K > 2048 would span LDS chunks
+    rc = lib().bt_ln_linear(_lib.BT_BF16, 8, 62, 4096, ptr(x), 4096, ptr(g_), ptr(g_), 1e-5, ptr(w), None, None, 0, ptr(out),
+                            64, 0, current_stream())
+    assert rc == -2                                             # 5..64 rows: N % 4 != 0
 
 
-@pytest.mark.parametrize("B,q", [(1, 1), (3, 1), (4, 1), (1, 2), (2, 2)])
+@pytest.mark.parametrize("B,q", [(1, 1), (3, 1), (4, 1), (1, 2), (2, 2), (8, 1), (16, 2), (64, 1), (5, 7)])
 @pytest.mark.parametrize("heads,d", [(16, 128), (8, 64), (16, 32), (4, 128)])
 @pytest.mark.parametrize("use_ln", [True, False])
 @pytest.mark.parametrize("use_dev_pos,use_table", [(False, False), (True, True)])

