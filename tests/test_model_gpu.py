@@ -419,10 +419,11 @@ def test_checkpoint_roundtrip_safetensors(gpu_model, tmp_path):
 
 @pytest.mark.parametrize("name", ["block_main_b4_5", "block_main_b4_19", "block_main_b4_85", "block_main_b4_300",
                                   "block_main_b4_800", "block_main_b4_1.2b", "block_main_b8_1.2b"])
-@pytest.mark.parametrize("B,P,D", [(3, 38, 10), (100, 24, 8), (300, 16, 8)])
+@pytest.mark.parametrize("B,P,D", [(3, 38, 10), (8, 24, 8), (13, 16, 8), (100, 24, 8), (300, 16, 8)])
 def test_generate_every_reference_config_smoke(name, B, P, D):
     """Every `block_main_*` architecture of the reference at odd batch sizes / prompt lengths (left pad, partial last
-    block, M not a multiple of any tile: the persistent GEMM's edge tiles and the 128^2 / split-K kernels in real use),
+    block, M not a multiple of any tile: the persistent GEMM's edge tiles, the 128^2 / split-K kernels, and -- B = 3 / 8 / 13
+    -- the fused GEMV and MFMA-streamer launch sequences of small stacks, in real use),
     bf16, random init: prompt preserved, ids in range, deterministic, hipGraph replay == eager launches, and rows
     independent of the batch they ride in."""
     import dataclasses
@@ -510,3 +511,34 @@ def test_small_batch_fused_stack_matches_unfused(B):
     if same.any():   # sequences whose tokens agree went through identical inputs: their last context must agree closely
         d = (ctx_f[same] - ctx_u[same]).abs().max() / ctx_u[same].abs().max()
         assert d <= 3e-2, d
+
+
+@pytest.mark.parametrize("B", [6, 16])
+def test_mid_batch_streamer_stack_matches_unfused(B):
+    """5..16 rows: the stacks run on the MFMA weight streamer with LayerNorm / RoPE / KV append / the second residual
+    projection folded in.  Same weights and prompt through the unfused launch sequence (bt_debug_few_rows_max(4) +
+    bt_debug_skinny_rows(4)): same greedy tokens up to rare bf16 near-ties."""
+    import dataclasses
+    from block_transformer_amd._lib import lib
+    base = named_dims("block_main_b4_1.2b")
+    dims = dataclasses.replace(base, name="b4_1.2b_2layer", bd=dataclasses.replace(base.bd, layers=2),
+                               td=dataclasses.replace(base.td, layers=2))
+    sd = random_state_dict(dims, seed=5, include_unused_embed_in=True)
+    model = load_block_transformer_from_dims(dims, "fp32")
+    model.load_state_dict(sd, strict=True)
+    model = model.bfloat16().to(DEV)
+    model.token_decoder.generation_config.eos_token_id = None
+    prompt = torch.randint(0, dims.vocab, (B, 32), generator=torch.Generator().manual_seed(B)).to(DEV)
+    fused = model.generate(prompt, max_length=48).cpu()
+    lib().bt_debug_few_rows_max(4)
+    lib().bt_debug_skinny_rows(4)
+    try:
+        model._engine = None
+        unfused = model.generate(prompt, max_length=48).cpu()
+    finally:
+        lib().bt_debug_few_rows_max(16)
+        lib().bt_debug_skinny_rows(16)
+        model._engine = None
+    assert torch.equal(fused[:, :32], prompt.cpu())
+    assert (fused == unfused).all(dim=1).float().mean() >= 0.6, (fused == unfused).float().mean()
+    assert (fused[:, 32] == unfused[:, 32]).float().mean() >= 0.8
