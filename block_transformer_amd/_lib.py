@@ -9,6 +9,8 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 import torch  # noqa: F401  (must be imported first: libbt_hip.so binds to the HIP runtime torch already loaded)
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbt_hip.so")
+# the same sources compiled with -DBT_DEBUG_HOOKS: bt_debug_* setters + A/B / ablation kernels; tests and probes only
+DEBUG_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbt_hip_dbg.so")
 
 BT_F32, BT_BF16 = 0, 1
 BT_ACT_NONE, BT_ACT_GELU = 0, 1
@@ -31,6 +33,28 @@ class bt_layer_weights(Structure):
 
 class bt_decoder_weights(Structure):
     _fields_ = [("layers_host", POINTER(bt_layer_weights)), ("lnf_w", c_void_p), ("lnf_b", c_void_p)]
+
+
+class bt_engine_desc(Structure):
+    """include/bt_hip.h bt_engine_desc (field order and types must match the header exactly)."""
+    _fields_ = [("dtype", c_int32), ("L", c_int32), ("E", c_int32), ("vocab", c_int32), ("B", c_int64),
+                ("bd_dims", bt_decoder_dims), ("bd_w", bt_decoder_weights),
+                ("td_dims", bt_decoder_dims), ("td_w", bt_decoder_weights),
+                ("emb_table", c_void_p), ("emb_width", c_int32), ("do_sample", c_int32),
+                ("exp_w", c_void_p), ("exp_b", c_void_p), ("embed_in", c_void_p), ("embed_out", c_void_p),
+                ("gk", c_void_p), ("gv", c_void_p), ("g_layer_stride", c_int64), ("g_nmax", c_int64),
+                ("g_cos", c_void_p), ("g_sin", c_void_p),
+                ("lk", c_void_p), ("lv", c_void_p), ("l_layer_stride", c_int64), ("l_nmax", c_int64),
+                ("l_cos", c_void_p), ("l_sin", c_void_p), ("l_pos_table", c_void_p),
+                ("x_blk", c_void_p), ("ctx", c_void_p), ("x_pre", c_void_p), ("x_tok", c_void_p), ("hid", c_void_p),
+                ("logits", c_void_p), ("raw", c_void_p), ("out_ids", c_void_p), ("nb_max", c_int64),
+                ("n_cur", c_void_p), ("finished", c_void_p), ("finished_prev", c_void_p), ("mask", c_void_p),
+                ("mask_ld", c_int64),
+                ("ws_tok", c_void_p), ("ws_tok_bytes", c_int64), ("ws_step", c_void_p), ("ws_step_bytes", c_int64),
+                ("exp_scratch", c_void_p), ("exp_scratch_bytes", c_int64),
+                ("n_split", c_int32), ("top_k", c_int32), ("split_ws", c_void_p), ("split_ws_bytes", c_int64),
+                ("temperature", c_float), ("reserved0", c_int32), ("seed", c_uint64), ("sample_step", c_void_p),
+                ("config_pad", c_int64), ("gen_eos", c_int64), ("gen_pad", c_int64)]
 
 
 class bt_attn_args(Structure):
@@ -67,6 +91,7 @@ _SIGS = {
     "bt_attention": (c_int, [c_int, c_int, c_int64, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p, c_void_p,
                              c_int64, c_void_p, c_int32, c_void_p, c_int64, c_void_p, c_int64, c_int32, c_void_p,
                              c_int64, c_void_p]),
+    "bt_attention_split_count": (c_int32, [c_int32, c_int64, c_int32]),
     "bt_argmax": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "bt_topk_sample": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_float, c_int32, c_uint64, c_void_p,
                                c_void_p, c_int64, c_void_p]),
@@ -75,6 +100,11 @@ _SIGS = {
     "bt_finish_block": (c_int, [c_int64, c_int32, c_int32, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p,
                                 c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p]),
     "bt_bump": (c_int, [c_void_p, c_int32, c_void_p]),
+    "bt_prefill_enqueue": (c_int, [POINTER(bt_engine_desc), c_void_p, c_int32, c_int64, c_int64, c_void_p, c_void_p, c_int64,
+                                   c_void_p]),
+    "bt_token_block_enqueue": (c_int, [POINTER(bt_engine_desc), c_int32, c_int32, c_int32, c_void_p]),
+    "bt_roll_over_enqueue": (c_int, [POINTER(bt_engine_desc), c_void_p]),
+    "bt_block_step_enqueue": (c_int, [POINTER(bt_engine_desc), c_int32, c_int32, c_void_p]),
     "bt_graph_begin_capture": (c_int, [c_void_p]),
     "bt_graph_end_capture": (c_int, [c_void_p, POINTER(c_void_p)]),
     "bt_graph_launch": (c_int, [c_void_p, c_void_p]),
@@ -85,34 +115,59 @@ _SIGS = {
     "bt_event_destroy": (c_int, [c_void_p]),
     "bt_prof_enable": (c_int, [c_int]),
     "bt_prof_collect": (c_int, [POINTER(ctypes.c_double), POINTER(c_int64), c_int]),
+}
+
+# test / A-B hooks: exported by libbt_hip_dbg.so only
+_DEBUG_SIGS = {
     "bt_debug_force_generic_gemm": (None, [c_int]),
     "bt_debug_gemm_variant": (None, [c_int]),
+    "bt_debug_gemm_max_wg": (None, [c_int]),
+    "bt_debug_skinny_rows": (None, [c_int]),
     "bt_debug_no_qkv_fusion": (None, [c_int]),
     "bt_debug_flash_variant": (None, [c_int]),
+    "bt_debug_attn_nt": (None, [c_int]),
+    "bt_debug_few_rows_max": (None, [c_int]),
+    "bt_debug_no_few_rows_fusion": (None, [c_int]),
     "bt_debug_tr_probe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 # every symbol include/bt_hip.h declares (tests check the library exports all of them)
-EXPORTED_SYMBOLS = [k for k in _SIGS if not k.startswith("bt_debug")]
+EXPORTED_SYMBOLS = list(_SIGS)
 
-_lib = None
+_handles = {}
+_debug_active = False
 
 
-def lib() -> ctypes.CDLL:
-    """Load (once) and return the library; raises ImportError with the build recipe when it is missing."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+def _load(path: str, debug: bool) -> ctypes.CDLL:
+    if path not in _handles:
+        if not os.path.exists(path):
             raise ImportError(
-                f"{LIB_PATH} is missing: the Block Transformer decode path has no fallback without its HIP kernels. "
+                f"{path} is missing: the Block Transformer decode path has no fallback without its HIP kernels. "
                 "Build it with `python -m block_transformer_amd.build` (needs hipcc, no GPU required).")
-        handle = ctypes.CDLL(LIB_PATH)
-        for name, (res, args) in _SIGS.items():
+        handle = ctypes.CDLL(path)
+        sigs = dict(_SIGS, **_DEBUG_SIGS) if debug else _SIGS
+        for name, (res, args) in sigs.items():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args
-        _lib = handle
-    return _lib
+        _handles[path] = handle
+    return _handles[path]
+
+
+def lib() -> ctypes.CDLL:
+    """Load (once) and return the active library — the product libbt_hip.so unless a test switched to the debug build;
+    raises ImportError with the build recipe when it is missing."""
+    return _load(DEBUG_LIB_PATH, True) if _debug_active else _load(LIB_PATH, False)
+
+
+def use_debug_library(on: bool = True) -> bool:
+    """tests / tools only: route every op through libbt_hip_dbg.so (same kernels + bt_debug_* hooks).  Returns the
+    previous setting.  Engines that captured hipGraphs keep replaying the kernels they were captured with."""
+    global _debug_active
+    prev, _debug_active = _debug_active, bool(on)
+    if on:
+        _load(DEBUG_LIB_PATH, True)
+    return prev
 
 
 PROF_FAMILIES = ["linear_mfma", "linear_generic", "layernorm", "embed", "rope_kv_append", "attn_rows", "attn_flash",

@@ -297,6 +297,7 @@ __global__ void attn_combine_kernel(const float* __restrict__ ws, T* __restrict_
 // block = 4 waves x (QF = 2 fragments of 16 query rows) = 128 query rows; key tiles of 64.
 constexpr int FQ_ROWS = 128, FK_TILE = 64, VT_PITCH = 72;  // Vt row pitch in bf16 elements (64 keys + 8 pad)
 
+#ifdef BT_DEBUG_HOOKS   // v1 flash prefill (register/LDS-transposed V): A/B baseline only, not in the product library
 template <int D>
 __global__ __launch_bounds__(256) void flash_prefill_kernel(const bf16* __restrict__ qkv, int64_t ld_qkv,
                                                            const bf16* __restrict__ kc, const bf16* __restrict__ vc,
@@ -481,6 +482,7 @@ __global__ __launch_bounds__(256) void flash_prefill_kernel(const bf16* __restri
         }
     }
 }
+#endif  // BT_DEBUG_HOOKS
 
 // ---- bf16 MFMA flash prefill, v2 ------------------------------------------------------------------------------------------
 // Same math and fragment mapping as flash_prefill_kernel, different data movement:
@@ -765,7 +767,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void flash_prefill_v2_ker
 }
 
 // ---- host dispatch ------------------------------------------------------------------------------------------------------
-static int g_attn_nt = 0;   // A/B hook: non-temporal K/V loads in the global (NW = 4) streaming kernel
+#ifdef BT_DEBUG_HOOKS
+static int g_attn_nt = 0;   // A/B hook (debug library only): non-temporal K/V loads in the global (NW = 4) streaming kernel
+#endif
 
 template <typename T, int D>
 static int launch_attend(int64_t B, int q_len, int heads, const void* qkv, int64_t ld_qkv, const void* kc, const void* vc,
@@ -786,11 +790,13 @@ static int launch_attend(int64_t B, int q_len, int heads, const void* qkv, int64
             set_error("bt_attention: %lld keys per split need %zu B of LDS; raise n_split", (long long)cap, shm);
             return BT_ERR_ARG;
         }
+#ifdef BT_DEBUG_HOOKS
         if (g_attn_nt)
             hipLaunchKernelGGL((attend_rows_kernel<T, D, 4, true>), grid, dim3(256), shm, s, (const T*)qkv, ld_qkv,
                                (const T*)kc, (const T*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (T*)out, ldo, ws, q_len,
                                heads, n_split, scale);
         else
+#endif
             hipLaunchKernelGGL((attend_rows_kernel<T, D, 4>), grid, dim3(256), shm, s, (const T*)qkv, ld_qkv, (const T*)kc,
                                (const T*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (T*)out, ldo, ws, q_len, heads,
                                n_split, scale);
@@ -804,7 +810,12 @@ static int launch_attend(int64_t B, int q_len, int heads, const void* qkv, int64
     return BT_OK;
 }
 
-static int g_flash_variant = 0;  // 0 = v2 <4 waves, double buffer> (LDS-DMA + transpose reads), 2 = v2 <8 waves, 4-deep ring>,
+#ifdef BT_DEBUG_HOOKS
+static int g_flash_variant = 0;
+#else
+static constexpr int g_flash_variant = 0;
+#endif
+                                 // 0 = v2 <4 waves, double buffer> (LDS-DMA + transpose reads), 2 = v2 <8 waves, 4-deep ring>,
                                  // 1 = v1 (register/LDS-transposed V)
 
 template <int D>
@@ -814,20 +825,25 @@ static int launch_flash(int64_t B, int q_len, int heads, const void* qkv, int64_
     const float scale = 1.0f / sqrtf((float)D);
     ProfScope ps(BT_PROF_ATTN_FLASH, s);
     const dim3 grid((unsigned)ceil_div(q_len, FQ_ROWS), (unsigned)heads, (unsigned)B);
+#ifdef BT_DEBUG_HOOKS
     if (g_flash_variant == 1)
         hipLaunchKernelGGL(flash_prefill_kernel<D>, grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)kc,
                            (const bf16*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (bf16*)out, ldo, q_len, heads,
                            scale);
-    else if (g_flash_variant != 2 || D < 64)   // production: 4 waves, double buffer, two workgroups per CU
+    else
+#endif
+    if (g_flash_variant != 2 || D < 64)   // production: 4 waves, double buffer, two workgroups per CU
         hipLaunchKernelGGL((flash_prefill_v2_kernel<D, 4, 2>), grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv,
                            (const bf16*)kc, (const bf16*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (bf16*)out, ldo, q_len,
                            heads, scale);
+#ifdef BT_DEBUG_HOOKS
     else if constexpr (D >= 64) {   // variant 2 (A/B): 8 waves, 4-deep ring -- same speed: the loop is issue-bound, not load-bound
         const dim3 grid8((unsigned)ceil_div(q_len, 256), (unsigned)heads, (unsigned)B);
         hipLaunchKernelGGL((flash_prefill_v2_kernel<D, 8, 4>), grid8, dim3(512), 0, s, (const bf16*)qkv, ld_qkv,
                            (const bf16*)kc, (const bf16*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (bf16*)out, ldo, q_len,
                            heads, scale);
     }
+#endif
     BT_LAUNCH_CHECK("bt_attention(flash) launch");
     return BT_OK;
 }
@@ -869,6 +885,13 @@ extern "C" int bt_rope_kv_append(int dtype, int64_t B, int32_t q_len, int32_t he
     return BT_OK;
 }
 
+// effective split-N factor of the row-wise kernel: the hint, raised until one split's score row fits the 64 KiB LDS budget
+extern "C" int32_t bt_attention_split_count(int32_t head_dim, int64_t n_max, int32_t n_split_hint) {
+    int32_t n_split = n_split_hint < 1 ? 1 : n_split_hint;
+    while ((4 + 4 * (int64_t)head_dim + bt::ceil_div(n_max, n_split)) * 4 > 64 * 1024) ++n_split;
+    return n_split;
+}
+
 extern "C" int bt_attention(int dtype, int mode, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim,
                             const void* qkv, int64_t ld_qkv, const void* k_cache, const void* v_cache, int64_t n_max,
                             const int32_t* pos0_dev, int32_t pos0_host, const uint8_t* mask, int64_t mask_ld, void* out,
@@ -896,9 +919,7 @@ extern "C" int bt_attention(int dtype, int mode, int64_t B, int32_t q_len, int32
             default: return launch_flash<128>(B, q_len, heads, qkv, ld_qkv, k_cache, v_cache, n_max, pos0_dev, pos0_host, mask, mask_ld, out, ldo, s);
         }
     }
-    if (n_split < 1) n_split = 1;
-    // LDS score row capacity: raise the split count until one split's keys fit
-    while ((4 + 4 * (int64_t)head_dim + ceil_div(n_max, n_split)) * 4 > 64 * 1024) ++n_split;
+    n_split = bt_attention_split_count(head_dim, n_max, n_split);
     if (n_split > 1) {
         const int64_t need = B * heads * q_len * n_split * (head_dim + 2) * (int64_t)sizeof(float);
         if (!ws || ws_bytes < need) {
@@ -922,5 +943,7 @@ extern "C" int bt_attention(int dtype, int mode, int64_t B, int32_t q_len, int32
 #undef BT_ATT
 }
 
+#ifdef BT_DEBUG_HOOKS
 extern "C" void bt_debug_flash_variant(int v) { bt::g_flash_variant = v; }
 extern "C" void bt_debug_attn_nt(int v) { bt::g_attn_nt = v; }
+#endif

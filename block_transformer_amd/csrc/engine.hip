@@ -11,11 +11,18 @@
 
 using namespace bt;
 
-static int g_few_rows_max = 16;             // rows up to which a stack takes the fused single-launch projections (the
-                                            // entry points accept <= 64; beyond ~16 rows split-K + reduce is faster)
+// rows up to which a stack takes the fused single-launch projections (the entry points accept <= 64; beyond ~16 rows
+// split-K + reduce is faster).  Compile-time constants in the product library; the debug build (-DBT_DEBUG_HOOKS,
+// libbt_hip_dbg.so: tests and A/B probes only) can flip them at run time.
+#ifdef BT_DEBUG_HOOKS
+static int g_few_rows_max = 16;
 extern "C" void bt_debug_few_rows_max(int n) { g_few_rows_max = n; }
-static bool g_no_few_rows_fusion = false;   // test hook: run 1..4-row stacks through the unfused launch sequence (A/B, parity)
+static bool g_no_few_rows_fusion = false;   // run 1..16-row stacks through the unfused launch sequence (A/B, parity)
 extern "C" void bt_debug_no_few_rows_fusion(int on) { g_no_few_rows_fusion = on != 0; }
+#else
+static constexpr int g_few_rows_max = 16;
+static constexpr bool g_no_few_rows_fusion = false;
+#endif
 
 static int64_t ws_elems(const bt_decoder_dims* d, int64_t M) {
     return M * ((int64_t)d->hidden * 5 + d->inter);
@@ -159,4 +166,159 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
         }
     }
     return BT_OK;
+}
+
+// ---- the two-level block step (BlockTransformer.generate loop body, model/block_transformer.py:370-426) -----------------------
+// Pure launch sequencing over the ops above: what a non-Python binder of bt_hip.h calls, and what the Python engine captures
+// into a hipGraph.  Nothing here reads device memory on the host.
+
+// descriptor checks: the fields every entry point reads, then the token-side / block-side buffers each one needs (a
+// token-decoder-only user, e.g. GPTNeoXTokenDecoder.generate, leaves the block-decoder half of the descriptor empty)
+static int check_desc(const bt_engine_desc* e, const char* who, bool token_side, bool block_side) {
+    BT_CHECK_ARG(e, "%s: null descriptor", who);
+    BT_CHECK_ARG(e->dtype == BT_F32 || e->dtype == BT_BF16, "%s: bad dtype %d", who, e->dtype);
+    BT_CHECK_ARG(e->B >= 0 && e->L > 0 && e->E > 0 && e->vocab > 0, "%s: bad shape", who);
+    BT_CHECK_ARG(e->ctx && e->raw, "%s: null ctx / raw buffer", who);
+    if (token_side) {
+        BT_CHECK_ARG(e->l_nmax >= e->E + e->L - 1, "%s: local KV window smaller than E + L - 1", who);
+        BT_CHECK_ARG(e->exp_w && e->embed_in && e->embed_out && e->lk && e->lv && e->x_pre && e->x_tok && e->hid && e->logits &&
+                         e->ws_tok && e->l_cos && e->l_sin && e->td_w.layers_host,
+                     "%s: null token-decoder buffer in descriptor", who);
+        BT_CHECK_ARG(!e->do_sample || e->sample_step, "%s: sampling needs the sample_step device counter", who);
+    }
+    if (block_side) {
+        BT_CHECK_ARG((int64_t)e->emb_width * e->L == e->bd_dims.hidden, "%s: emb_width * L != block-decoder hidden size", who);
+        BT_CHECK_ARG(e->emb_table && e->gk && e->gv && e->x_blk && e->n_cur && e->finished_prev && e->ws_step && e->g_cos &&
+                         e->g_sin && e->bd_w.layers_host,
+                     "%s: null block-decoder buffer in descriptor", who);
+    }
+    return BT_OK;
+}
+
+static bt_attn_args local_attn(const bt_engine_desc* e, int32_t pos0) {
+    bt_attn_args a{};
+    a.k_cache = e->lk;
+    a.v_cache = e->lv;
+    a.layer_stride = e->l_layer_stride;
+    a.n_max = e->l_nmax;
+    a.pos0_dev = nullptr;
+    a.pos0_host = pos0;
+    a.pos_table = e->l_pos_table;
+    a.mask = nullptr;
+    a.mask_ld = 0;
+    a.cos_tab = e->l_cos;
+    a.sin_tab = e->l_sin;
+    a.mode = 0;
+    a.n_split = 1;
+    a.split_ws = nullptr;
+    a.split_ws_bytes = 0;
+    return a;
+}
+
+extern "C" int bt_token_block_enqueue(const bt_engine_desc* e, int32_t t_begin, int32_t t_end, int32_t finish_count,
+                                      bt_stream stream) {
+    BT_TRY(check_desc(e, "bt_token_block_enqueue", true, false));
+    BT_CHECK_ARG(t_begin >= 0 && t_begin <= t_end && t_end <= e->L && finish_count >= 0 && finish_count <= e->L,
+                 "bt_token_block_enqueue: bad step range [%d, %d) / finish %d for L = %d", t_begin, t_end, finish_count, e->L);
+    if (e->B == 0) return BT_OK;
+    const int64_t B = e->B, Htd = e->td_dims.hidden, Hbd = e->bd_dims.hidden;
+    const size_t es = dtype_size(e->dtype);
+    for (int32_t t = t_begin; t < t_end; ++t) {
+        if (t == 0) {
+            // expansion_layer: Conv1d(k=1) == Linear; ctx [B, H_bd] -> [B, E*H_td] == E prefix rows per sequence
+            BT_TRY(bt_linear_ws(e->dtype, B, (int64_t)e->E * Htd, Hbd, e->ctx, Hbd, e->exp_w, e->exp_b, nullptr, 0, e->x_pre,
+                                (int64_t)e->E * Htd, BT_ACT_NONE, e->exp_scratch, e->exp_scratch_bytes, stream));
+            bt_attn_args a = local_attn(e, 0);
+            BT_TRY(bt_decoder_forward(e->dtype, &e->td_dims, &e->td_w, B, e->E, e->x_pre, &a, e->E - 1, e->hid, e->ws_tok,
+                                      e->ws_tok_bytes, stream));
+        } else {
+            BT_TRY(bt_embed_rows(e->dtype, B, Htd, e->raw + (t - 1), e->L, e->vocab, e->embed_in, e->x_tok, Htd, nullptr, 1,
+                                 stream));
+            bt_attn_args a = local_attn(e, e->E + t - 1);
+            BT_TRY(bt_decoder_forward(e->dtype, &e->td_dims, &e->td_w, B, 1, e->x_tok, &a, 0, e->hid, e->ws_tok,
+                                      e->ws_tok_bytes, stream));
+        }
+        BT_TRY(bt_linear(e->dtype, B, e->vocab, Htd, e->hid, Htd, e->embed_out, nullptr, nullptr, 0, e->logits, e->vocab,
+                         BT_ACT_NONE, stream));
+        if (e->do_sample) {
+            BT_TRY(bt_topk_sample(e->dtype, B, e->vocab, e->logits, e->vocab, e->temperature, e->top_k, e->seed,
+                                  e->sample_step, e->raw + t, e->L, stream));
+            BT_TRY(bt_bump(e->sample_step, 1, stream));
+        } else {
+            BT_TRY(bt_argmax(e->dtype, B, e->vocab, e->logits, e->vocab, e->raw + t, e->L, stream));
+        }
+    }
+    (void)es;
+    if (finish_count > 0) {
+        BT_CHECK_ARG(e->out_ids && e->n_cur && e->finished && e->finished_prev, "bt_token_block_enqueue: finish needs out_ids / n_cur / finished[_prev]");
+        BT_TRY(bt_finish_block(B, e->L, finish_count, e->raw, e->out_ids, e->nb_max, e->n_cur, e->finished, e->finished_prev,
+                               e->mask, e->mask_ld, e->config_pad, e->gen_eos, e->gen_pad, stream));
+    }
+    return BT_OK;
+}
+
+extern "C" int bt_roll_over_enqueue(const bt_engine_desc* e, bt_stream stream) {
+    BT_TRY(check_desc(e, "bt_roll_over_enqueue", false, true));
+    if (e->B == 0) return BT_OK;
+    const int64_t B = e->B, Hbd = e->bd_dims.hidden;
+    // embedder lookup + concat of the block just finished; zero rows for sequences that were finished before it (:419-421)
+    BT_TRY(bt_embed_rows(e->dtype, B * e->L, e->emb_width, e->raw, 1, e->vocab, e->emb_table, e->x_blk, e->emb_width,
+                         e->finished_prev, e->L, stream));
+    bt_attn_args a{};
+    a.k_cache = e->gk;
+    a.v_cache = e->gv;
+    a.layer_stride = e->g_layer_stride;
+    a.n_max = e->g_nmax;
+    a.pos0_dev = e->n_cur;
+    a.pos0_host = 0;
+    a.pos_table = nullptr;
+    a.mask = e->mask;
+    a.mask_ld = e->mask ? e->mask_ld : 0;
+    a.cos_tab = e->g_cos;
+    a.sin_tab = e->g_sin;
+    a.mode = 0;
+    a.n_split = e->n_split > 0 ? e->n_split : 1;
+    a.split_ws = e->split_ws;
+    a.split_ws_bytes = e->split_ws_bytes;
+    BT_TRY(bt_decoder_forward(e->dtype, &e->bd_dims, &e->bd_w, B, 1, e->x_blk, &a, 0, e->ctx, e->ws_step, e->ws_step_bytes,
+                              stream));
+    (void)Hbd;
+    return bt_bump(e->n_cur, 1, stream);
+}
+
+extern "C" int bt_block_step_enqueue(const bt_engine_desc* e, int32_t count, int32_t roll, bt_stream stream) {
+    BT_TRY(bt_token_block_enqueue(e, 0, count, count, stream));
+    if (roll) BT_TRY(bt_roll_over_enqueue(e, stream));
+    return BT_OK;
+}
+
+extern "C" int bt_prefill_enqueue(const bt_engine_desc* e, const int64_t* block_ids, int32_t nb, int64_t b0, int64_t nseq,
+                                  void* x, void* ws, int64_t ws_bytes, bt_stream stream) {
+    BT_TRY(check_desc(e, "bt_prefill_enqueue", false, true));
+    BT_CHECK_ARG(block_ids && x && ws, "bt_prefill_enqueue: null pointer");
+    BT_CHECK_ARG(nb > 0 && nb <= e->g_nmax && b0 >= 0 && nseq >= 0 && b0 + nseq <= e->B, "bt_prefill_enqueue: bad range");
+    if (nseq == 0) return BT_OK;
+    const int64_t Hbd = e->bd_dims.hidden;
+    const size_t es = dtype_size(e->dtype);
+    BT_TRY(bt_embed_rows(e->dtype, nseq * nb * e->L, e->emb_width, block_ids + b0 * nb * e->L, 1, e->vocab, e->emb_table, x,
+                         e->emb_width, nullptr, 1, stream));
+    const int64_t seq_off = b0 * e->bd_dims.heads * e->g_nmax * e->bd_dims.head_dim;   // elements of one layer's slab
+    bt_attn_args a{};
+    a.k_cache = reinterpret_cast<char*>(e->gk) + seq_off * es;
+    a.v_cache = reinterpret_cast<char*>(e->gv) + seq_off * es;
+    a.layer_stride = e->g_layer_stride;
+    a.n_max = e->g_nmax;
+    a.pos0_dev = nullptr;
+    a.pos0_host = 0;
+    a.pos_table = nullptr;
+    a.mask = e->mask ? e->mask + b0 * e->mask_ld : nullptr;
+    a.mask_ld = e->mask ? e->mask_ld : 0;
+    a.cos_tab = e->g_cos;
+    a.sin_tab = e->g_sin;
+    a.mode = (e->dtype == BT_BF16 && nb > 1) ? 1 : 0;
+    a.n_split = 1;
+    a.split_ws = nullptr;
+    a.split_ws_bytes = 0;
+    return bt_decoder_forward(e->dtype, &e->bd_dims, &e->bd_w, nseq, nb, x, &a, nb - 1,
+                              reinterpret_cast<char*>(e->ctx) + b0 * Hbd * es, ws, ws_bytes, stream);
 }

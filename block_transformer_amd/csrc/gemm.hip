@@ -546,6 +546,7 @@ __device__ inline void cbarrier() {
     asm volatile("" ::: "memory");
 }
 
+#ifdef BT_DEBUG_HOOKS   // four-phase ring + timing ablations: A/B probes only, not in the product library
 // STAGGER: waves 4-7 run half a phase behind waves 0-3 (two barriers per phase): while one wave of a SIMD is in its
 // 16-MFMA cluster (s_setprio 1) its partner issues the DMA and ds_reads of its own phase, so the matrix pipe does not
 // idle during LDS latency.  Group 1 therefore waits for phase g+1's data before the barrier that opens group 0's phase
@@ -691,6 +692,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256_kernel(const bf16* __re
         }
     }
 }
+
+#endif  // BT_DEBUG_HOOKS
 
 // ---- 256x256, two 32-MFMA phases per K-tile ---------------------------------------------------------------------------------
 // Same tile, LDS ring and fragment mapping as gemm_bf16_mfma256_kernel, but a phase is 32 MFMAs (half of the wave's output
@@ -2062,13 +2065,21 @@ static int num_cus() {
     return n;
 }
 
-static bool g_force_generic = false;
-static int g_skinny_rows = 16;   // bt_linear takes the MFMA weight streamer for 5 .. g_skinny_rows rows (kernel: <= 64; measured
-                                 // B = 8: +21 %, 16: +4 %, 32: -20 %, 64: -30 % vs split-K + reduce -> 16)
-static int g_max_wg = 0;   // test hook: cap the persistent kernel's grid so small problems walk several tiles per workgroup
-static bool g_no_qkv_fusion = false;
-static int g_gemm_variant = 0;  // 0 auto; 1 force 128^2; 2/3 256^2 four-phase ring (plain/staggered); 4-8 timing ablations; 9/10 256^2 two-phase
-// ring, one tile per workgroup (staggered/plain); default: persistent two-phase ring.  Tests and A/B probes only.
+// Dispatch knobs.  In the product library they are compile-time constants (no process-global mutable state); the debug
+// build (-DBT_DEBUG_HOOKS -> libbt_hip_dbg.so, loaded by tests and tools/kernel_probe.py only) exposes bt_debug_* setters and
+// additionally compiles the A/B and timing-ablation kernels.
+#ifdef BT_DEBUG_HOOKS
+#define BT_KNOB static
+#else
+#define BT_KNOB static constexpr
+#endif
+BT_KNOB bool g_force_generic = false;
+BT_KNOB int g_skinny_rows = 16;   // bt_linear takes the MFMA weight streamer for 5 .. g_skinny_rows rows (kernel: <= 64; measured
+                                  // B = 8: +21 %, 16: +4 %, 32: -20 %, 64: -30 % vs split-K + reduce -> 16)
+BT_KNOB int g_max_wg = 0;         // cap the persistent kernel's grid so small problems walk several tiles per workgroup
+BT_KNOB bool g_no_qkv_fusion = false;
+BT_KNOB int g_gemm_variant = 0;   // 0 auto; 1 force 128^2; 2/3 256^2 four-phase ring (plain/staggered); 4-8 timing ablations; 9/10 256^2
+// two-phase ring, one tile per workgroup (staggered/plain); 14 persistent on 32x32x16 MFMA; default: persistent two-phase ring.
 
 }  // namespace bt
 
@@ -2120,6 +2131,8 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
 #define BT_LAUNCH_256(KERN_)                                                                                        \
     hipLaunchKernelGGL((KERN_), dim3(tiles_m * tiles_n), dim3(512), 0, s, (const bf16*)A, lda, (const bf16*)W, K, ep, \
                        (int)K, tiles_m, tiles_n)
+#ifdef BT_DEBUG_HOOKS
+            bool dbg_done = true;
             switch (g_gemm_variant) {
                 case 2: BT_LAUNCH_256((gemm_bf16_mfma256_kernel<false, 0>)); break;
                 case 3: BT_LAUNCH_256((gemm_bf16_mfma256_kernel<true, 0>)); break;
@@ -2133,19 +2146,30 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                 case 10: BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<false>)); break;
                 case 11: BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<true, true>)); break;  // timing ablation: no epilogue
                 case 9: BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<true>)); break;    // one tile per workgroup
-                default: {
+                default: dbg_done = false; break;
+            }
+            if (!dbg_done)
+#endif
+            {
+                {
                     const bool pp_ok = (N % 8 == 0) && (ldo % 8 == 0) && aligned16(out) && K / BK >= 4 &&
                                        (!residual || (ldr % 8 == 0 && aligned16(residual))) && (!bias || aligned16(bias));
                     if (pp_ok) {   // production: persistent, per-wave epilogue
                         const int n_wg = (int)std::min<int64_t>((int64_t)tiles_m * tiles_n, g_max_wg > 0 ? g_max_wg : num_cus());
+#ifdef BT_DEBUG_HOOKS   /* A/B: 32x32x16 MFMA blocks (measured 5-8 % slower in this schedule) */
+#define BT_PP_MMA32_AB(MODE_)                                                                                       \
+    if (g_gemm_variant == 14)                                                                                       \
+        hipLaunchKernelGGL((gemm_bf16_mfma256pp_kernel<MODE_, Mma32>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,   \
+                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
+    else
+#else
+#define BT_PP_MMA32_AB(MODE_)
+#endif
 #define BT_LAUNCH_PP(MODE_)                                                                                           \
     do {                                                                                                              \
-        if (g_gemm_variant == 14)   /* A/B: 32x32x16 MFMA blocks (measured 5-8 % slower in this schedule) */        \
-            hipLaunchKernelGGL((gemm_bf16_mfma256pp_kernel<MODE_, Mma32>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A, \
-                               lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                 \
-        else                                                                                                          \
-            hipLaunchKernelGGL((gemm_bf16_mfma256pp_kernel<MODE_, Mma16>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A, \
-                               lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                 \
+        BT_PP_MMA32_AB(MODE_)                                                                                       \
+        hipLaunchKernelGGL((gemm_bf16_mfma256pp_kernel<MODE_, Mma16>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,     \
+                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                     \
     } while (0)
                         // (the engine never combines these: QKV has no activation / residual, GELU has no residual)
                         if (ep.q.enabled) BT_LAUNCH_PP(PP_QKV);
@@ -2154,10 +2178,10 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                         else if (act == BT_ACT_NONE) BT_LAUNCH_PP(PP_PLAIN);
                         else BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<true>));   // GELU + residual: one-tile kernel
 #undef BT_LAUNCH_PP
+#undef BT_PP_MMA32_AB
                     } else {
                         BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<true>));
                     }
-                    break;
                 }
             }
 #undef BT_LAUNCH_256
@@ -2485,9 +2509,11 @@ extern "C" int bt_linear2(int dtype, int64_t M, int64_t N, int64_t K1, const voi
     return BT_OK;
 }
 
-// test hook: force the generic kernel for bf16 (A/B checks of the MFMA kernel against the simple one)
+#ifdef BT_DEBUG_HOOKS
+// test / A-B hooks (libbt_hip_dbg.so only): force the generic kernel for bf16, pick a kernel variant, cap the persistent grid
 extern "C" void bt_debug_force_generic_gemm(int on) { g_force_generic = on != 0; }
 extern "C" void bt_debug_gemm_variant(int v) { g_gemm_variant = v; }
 extern "C" void bt_debug_gemm_max_wg(int n) { g_max_wg = n; }
 extern "C" void bt_debug_skinny_rows(int n) { g_skinny_rows = n; }
 extern "C" void bt_debug_no_qkv_fusion(int on) { g_no_qkv_fusion = on != 0; }
+#endif

@@ -90,10 +90,11 @@ __global__ __launch_bounds__(256) void topk_sample_kernel(const T* __restrict__ 
                                                          int64_t* __restrict__ ids_out, int64_t ids_stride) {
     __shared__ int hist[256];
     __shared__ uint32_t s_prefix, s_mask;
-    __shared__ int s_k, s_ncand;
+    __shared__ int s_k;
     __shared__ float c_val[MAX_CAND];
     __shared__ int c_idx[MAX_CAND];
     __shared__ float red[4];
+    __shared__ int w_gt[4], w_eq[4];
     __shared__ float s_part[256];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const T* row = logits + (int64_t)blockIdx.x * ld;
@@ -125,39 +126,67 @@ __global__ __launch_bounds__(256) void topk_sample_kernel(const T* __restrict__ 
             }
             __syncthreads();
         }
-        // HF TopKLogitsWarper keeps every score >= the k-th largest (ties included)
+        // HF TopKLogitsWarper keeps every score >= the k-th largest (ties included).  Candidates are compacted in
+        // VOCABULARY ORDER (wave w owns a contiguous quarter of the row; ballot prefix inside the wave, per-wave bases from
+        // a counting pass), so the kept set and the draw are deterministic for a given (seed, step, row).  At most
+        // MAX_CAND candidates: every score strictly above the threshold (fewer than top_k <= MAX_CAND of them) and the
+        // lowest-index ties at the threshold up to the capacity.
         const uint32_t thr = s_prefix;
-        if (tid == 0) s_ncand = 0;
+        const int per_wave = (V_ + 3) / 4;
+        const int c_lo = wave * per_wave, c_hi = min(V_, c_lo + per_wave);
+        int n_gt = 0, n_eq = 0;
+        for (int c0 = c_lo; c0 < c_hi; c0 += 64) {
+            const int c = c0 + lane;
+            const uint32_t key = c < c_hi ? float_key(Elem<T>::load(row + c) * inv_temp) : 0u;
+            n_gt += __popcll(__ballot(c < c_hi && key > thr));
+            n_eq += __popcll(__ballot(c < c_hi && key == thr));
+        }
+        if (lane == 0) { w_gt[wave] = n_gt; w_eq[wave] = n_eq; }
         __syncthreads();
-        for (int c = tid; c < V_; c += 256) {
-            const float v = Elem<T>::load(row + c) * inv_temp;
-            if (float_key(v) >= thr) {
-                const int slot = atomicAdd(&s_ncand, 1);
-                if (slot < MAX_CAND) { c_val[slot] = v; c_idx[slot] = c; }
-            }
+        int tot_gt = 0, tot_eq = 0, gt_before = 0, eq_before = 0;
+        for (int w = 0; w < 4; ++w) {
+            if (w < wave) { gt_before += w_gt[w]; eq_before += w_eq[w]; }
+            tot_gt += w_gt[w];
+            tot_eq += w_eq[w];
+        }
+        const int eq_allow = MAX_CAND - tot_gt;   // >= 1: tot_gt < top_k <= MAX_CAND (checked on the host)
+        const uint64_t below = (1ull << lane) - 1ull;
+        for (int c0 = c_lo; c0 < c_hi; c0 += 64) {
+            const int c = c0 + lane;
+            const float v = c < c_hi ? Elem<T>::load(row + c) * inv_temp : 0.f;
+            const uint32_t key = c < c_hi ? float_key(v) : 0u;
+            const bool gt = c < c_hi && key > thr, eq = c < c_hi && key == thr;
+            const uint64_t bg = __ballot(gt), be = __ballot(eq);
+            const int my_gt = gt_before + __popcll(bg & below), my_eq = eq_before + __popcll(be & below);
+            int slot = -1;
+            if (gt) slot = my_gt + min(my_eq, eq_allow);
+            else if (eq && my_eq < eq_allow) slot = my_gt + my_eq;
+            if (slot >= 0) { c_val[slot] = v; c_idx[slot] = c; }
+            gt_before += __popcll(bg);
+            eq_before += __popcll(be);
         }
         __syncthreads();
-        const int n = min(s_ncand, MAX_CAND);
-        // softmax over the candidates + inverse-CDF draw in index order (deterministic for a given (seed, step, row))
+        const int n = tot_gt + min(tot_eq, eq_allow);
+        // softmax over the candidates (block-parallel) + inverse-CDF draw in vocabulary order
+        float mx = -INFINITY;
+        for (int i = tid; i < n; i += 256) mx = fmaxf(mx, c_val[i]);
+        mx = wave_max(mx);
+        if (lane == 0) red[wave] = mx;
+        __syncthreads();
+        mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        for (int i = tid; i < n; i += 256) c_val[i] = expf(c_val[i] - mx);
+        __syncthreads();
         if (tid == 0) {
-            float mx = -INFINITY;
-            for (int i = 0; i < n; ++i) mx = fmaxf(mx, c_val[i]);
             float tot = 0.f;
-            for (int i = 0; i < n; ++i) tot += expf(c_val[i] - mx);
+            for (int i = 0; i < n; ++i) tot += c_val[i];
             const float target = u01 * tot;
-            // walk candidates in increasing vocabulary index
             float cum = 0.f;
-            int chosen = -1, last = -1;
-            for (int step = 0; step < n; ++step) {
-                int best = -1;
-                for (int i = 0; i < n; ++i)
-                    if (c_idx[i] > last && (best < 0 || c_idx[i] < c_idx[best])) best = i;
-                last = c_idx[best];
-                cum += expf(c_val[best] - mx);
-                chosen = c_idx[best];
-                if (cum > target) break;
+            int chosen = n > 0 ? c_idx[n - 1] : 0;
+            for (int i = 0; i < n; ++i) {
+                cum += c_val[i];
+                if (cum > target) { chosen = c_idx[i]; break; }
             }
-            ids_out[(int64_t)blockIdx.x * ids_stride] = chosen < 0 ? 0 : chosen;
+            ids_out[(int64_t)blockIdx.x * ids_stride] = chosen;
         }
         return;
     }
@@ -249,6 +278,7 @@ __global__ __launch_bounds__(1024) void finish_block_kernel(int64_t B, int L, in
 
 __global__ void bump_kernel(int32_t* c, int32_t d) { *c += d; }
 
+#ifdef BT_DEBUG_HOOKS
 // debug probe of ds_read_b64_tr_b16: lds[i] = in[i] (4096 shorts); lane l reads at element offset addr[l]; out[l*4 + j]
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 __global__ void tr_probe_kernel(const short* in, const int* addr, short* out) {
@@ -259,6 +289,7 @@ __global__ void tr_probe_kernel(const short* in, const int* addr, short* out) {
         (__attribute__((address_space(3))) s16x4_t*)(lds + addr[threadIdx.x]));
     for (int j = 0; j < 4; ++j) out[threadIdx.x * 4 + j] = v[j];
 }
+#endif  // BT_DEBUG_HOOKS
 
 template <typename T>
 static int launch_embed(int64_t rows, int64_t width, const int64_t* ids, int64_t ids_stride, int64_t vocab,
@@ -328,6 +359,11 @@ extern "C" int bt_topk_sample(int dtype, int64_t M, int64_t V, const void* logit
     BT_CHECK_ARG(M >= 0 && V > 0 && V < (1ll << 31) && ld >= V && M < (1ll << 31), "bt_topk_sample: bad shape");
     BT_CHECK_ARG(logits && ids_out, "bt_topk_sample: null pointer");
     BT_CHECK_ARG(temperature > 0.f, "bt_topk_sample: temperature must be > 0");
+    if (top_k > MAX_CAND && top_k < V) {   // the candidate buffer holds MAX_CAND scores: refuse rather than drop candidates
+        set_error("bt_topk_sample: top_k = %d exceeds the %d-candidate capacity (use top_k <= %d, or 0 / >= vocab for no filter)",
+                  top_k, MAX_CAND, MAX_CAND);
+        return BT_ERR_UNSUPPORTED;
+    }
     if (M == 0) return BT_OK;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(BT_PROF_SAMPLE, s);
@@ -363,9 +399,11 @@ extern "C" int bt_bump(int32_t* counter, int32_t delta, bt_stream stream) {
     return BT_OK;
 }
 
+#ifdef BT_DEBUG_HOOKS
 extern "C" int bt_debug_tr_probe(const void* in, const void* addr, void* out, bt_stream stream) {
     hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const short*)in, (const int*)addr,
                        (short*)out);
     BT_LAUNCH_CHECK("tr_probe launch");
     return BT_OK;
 }
+#endif

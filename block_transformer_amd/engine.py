@@ -1,38 +1,49 @@
 """The two-level decode engine behind ``BlockTransformer.generate`` (reference model/block_transformer.py:279-449).
 
-State lives in preallocated HBM buffers with fixed addresses so that one *block step* is a fixed launch sequence:
+State lives in preallocated HBM buffers with fixed addresses, described once to the C library by a ``bt_engine_desc``
+(include/bt_hip.h); one *block step* is then a fixed launch sequence issued by C entry points:
 
-    graph A "token block":   expand ctx -> token decoder step 0 (q = E) -> logits -> argmax/sample -> embed_in ->
+    bt_token_block_enqueue:  expand ctx -> token decoder step 0 (q = E) -> logits -> argmax/sample -> embed_in ->
                              ... L tokens -> finish_block (EOS/pad rules, write ids, append block-mask column)
-    graph B "roll-over":     embedder lookup+concat of the new block -> block decoder step (RoPE + append global KV at
+    bt_roll_over_enqueue:    embedder lookup+concat of the new block -> block decoder step (RoPE + append global KV at
                              row n, attention over n+1 block positions) -> ctx ; n += 1
 
-Both are captured once into hipGraphs and replayed per block; everything that changes between replays (the number of
-cached block positions n) is a device scalar read by the kernels.  Finished sequences are masked, not compacted
-(reference compacts with boolean indexing + host syncs, C13/C14): fixed batch => static shapes => graph replay.
+The Python side only captures those calls into hipGraphs once and replays them per block; everything that changes between
+replays (the number of cached block positions n, finished flags, the sampler's draw counter) is a device scalar read by
+the kernels.  Finished sequences are masked, not compacted (the reference compacts with boolean indexing + host syncs,
+C13/C14): fixed batch => static shapes => graph replay.  Local-KV "reset" costs nothing: every token block starts
+writing the local cache at row 0 again.
 
-Local-KV "reset" costs nothing: every token block starts writing the local cache at row 0 again.
+Large batches are run as TWO half-batch shards on two HIP streams, one token block apart (``PipelinedEngine``): while
+shard A streams its global KV cache (block-decoder step, HBM-bound, matrix cores idle) shard B runs its token-decoder
+GEMMs (MFMA-bound, HBM idle) — the "two roofs" of SURVEY.md section 7 overlapped instead of added.
 """
 from __future__ import annotations
 
-import math
-from typing import Optional
-
+import ctypes
 import os
+from typing import List, Optional
 
 import torch
 
 from . import _lib, ops
-from ._lib import check, current_stream, lib, ptr
+from ._lib import bt_engine_desc, check, current_stream, dtype_code, lib, ptr
 from .runtime import DecoderRuntime, Graph, KVCache
+
+DEFAULT_ROPE_POLICY = "hf439_generate"
 
 
 def td_position_table(policy: str, n_exp: int, block_length: int):
     """RoPE positions of the adapted token-decoder sequence [BE_1..BE_E, t_0..t_{L-2}].
 
-    ``train`` = HF default arange (the no-cache forward the model was trained with; golden-pinned).
-    ``hf439_generate`` = what transformers 4.39.3 ``prepare_inputs_for_generation`` feeds through the reference's
-    **kwargs during cached generation: prefix rows all at 0, token t at t+1 (unverifiable here).
+    ``hf439_generate`` (default of generate()) = what the reference's *cached* generation computes: transformers 4.39.3
+    ``GPTNeoXForCausalLM.prepare_inputs_for_generation`` derives ``position_ids = cumsum(attention_mask) - 1`` from the
+    un-adapted mask and the reference forwards it through **kwargs into ``gpt_neox`` (model/token_decoder/gpt_neo_x.py:76-90
+    -> base.py:158,301-303 -> gpt_neo_x.py:59-71): the E prefix rows all rotate at position 0 (a [B,1] position id
+    broadcast over the q = E rows), token t at t+1.  Pinned by golden G9 (the reference's own classes evaluated at
+    exactly these position ids).
+    ``train`` = HF default arange over the adapted sequence: what a direct (no ``position_ids``) forward — teacher forcing,
+    ``BlockTransformer.forward`` — computes; pinned by goldens G5/G6/G7.
     """
     if policy == "train":
         return list(range(n_exp + block_length - 1))
@@ -41,10 +52,26 @@ def td_position_table(policy: str, n_exp: int, block_length: int):
     raise ValueError(f"unknown RoPE position policy {policy!r}")
 
 
-class TokenBlockState:
-    """Buffers + launch sequence for decoding one block of <= L tokens from a context embedding."""
+def _gen_fields(gen, cfg_pad: int):
+    """(gen_eos, gen_pad, do_sample, temperature, top_k, seed) from a GenerationConfig-like object."""
+    gen_eos = -1 if gen is None or gen.eos_token_id is None else int(gen.eos_token_id)
+    gen_pad = cfg_pad
+    if gen is not None and gen.pad_token_id is not None:
+        gen_pad = int(gen.pad_token_id)
+    elif gen_eos >= 0:
+        gen_pad = gen_eos
+    do_sample = bool(gen is not None and gen.do_sample)
+    temperature = float((gen.temperature if gen is not None else None) or 1.0)
+    top_k = int((gen.top_k if gen is not None else None) or 0)
+    seed = int((getattr(gen, "seed", 0) if gen is not None else 0) or 0)
+    return gen_eos, gen_pad, do_sample, temperature, top_k, seed
 
-    def __init__(self, token_decoder, batch: int, device, rope_policy: str = "train"):
+
+class TokenBlockState:
+    """Token-decoder side of a block step: buffers + the token half of the descriptor.  Also serves
+    ``GPTNeoXTokenDecoder.generate`` (reference model/token_decoder/base.py:399-453) on its own."""
+
+    def __init__(self, token_decoder, batch: int, device, rope_policy: str = DEFAULT_ROPE_POLICY):
         td = token_decoder
         self.td = td
         self.B = batch
@@ -64,9 +91,9 @@ class TokenBlockState:
         self.hid = torch.empty(batch, self.H, dtype=dt, device=device)
         self.logits = torch.empty(batch, self.V, dtype=dt, device=device)
         self.raw = torch.zeros(batch, self.L, dtype=torch.int64, device=device)
-        self.pos_table = torch.tensor(td_position_table(rope_policy, self.E, self.L), dtype=torch.int32, device=device)
-        self.rope = ops.rope_tables(max(self.pos_table.tolist()) + 1, self.rt.dims.rot,
-                                    float(getattr(cfg, "rotary_emb_base", 10000.0)), device)
+        table = td_position_table(rope_policy, self.E, self.L)
+        self.pos_table = torch.tensor(table, dtype=torch.int32, device=device)
+        self.rope = ops.rope_tables(max(table) + 1, self.rt.dims.rot, float(getattr(cfg, "rotary_emb_base", 10000.0)), device)
         # step 0 runs B*E prefix rows, steps 1.. run B rows (which may want split-K scratch when B <= 256): size for both
         self.ws = torch.empty(max(self.rt.workspace_bytes(batch * self.E), self.rt.workspace_bytes(batch)), dtype=torch.uint8,
                               device=device)
@@ -74,41 +101,77 @@ class TokenBlockState:
         # split-K scratch for the skinny expansion GEMM (small batches stream the weights with every CU)
         self.scratch = (torch.empty(16 * batch * self.E * self.H, dtype=torch.float32, device=device)
                         if batch <= 256 else None)
+        self._desc: Optional[bt_engine_desc] = None   # stand-alone descriptor (token_decoder.generate)
 
-    def _pick(self, t: int, gen):
-        if gen is not None and gen.do_sample:
-            ops.topk_sample(self.logits, temperature=float(gen.temperature or 1.0), top_k=int(gen.top_k or 0),
-                            seed=int(getattr(gen, "seed", 0) or 0), step=self.sample_step, out=self.raw[:, t])
-            check(lib().bt_bump(ptr(self.sample_step), 1, current_stream()), "bt_bump")
-        else:
-            ops.argmax(self.logits, out=self.raw[:, t])
+    def weight_key(self):
+        td = self.td
+        return (self.rt.weight_key(), td.expansion_layer.weight.data_ptr(),
+                0 if td.expansion_layer.bias is None else td.expansion_layer.bias.data_ptr(),
+                td.gpt_neox.embed_in.weight.data_ptr(), td.embed_out.weight.data_ptr())
+
+    def fill_desc(self, d: bt_engine_desc) -> None:
+        td = self.td
+        for p in (td.expansion_layer.weight, td.gpt_neox.embed_in.weight, td.embed_out.weight):
+            if p.dtype != self.dtype or not p.is_contiguous() or not p.is_cuda:
+                raise _lib.BtError("token-decoder parameters must be contiguous, on the GPU and share the stack's dtype")
+        d.dtype = dtype_code(self.dtype)
+        d.L, d.E, d.vocab, d.B = self.L, self.E, self.V, self.B
+        d.td_dims = self.rt.dims
+        d.td_w = self.rt.weights()
+        d.exp_w = td.expansion_layer.weight.data_ptr()
+        d.exp_b = ptr(td.expansion_layer.bias)
+        d.embed_in = td.gpt_neox.embed_in.weight.data_ptr()
+        d.embed_out = td.embed_out.weight.data_ptr()
+        d.lk, d.lv = self.local.k.data_ptr(), self.local.v.data_ptr()
+        d.l_layer_stride, d.l_nmax = self.local.layer_stride, self.local.n_max
+        d.l_cos, d.l_sin = self.rope[0].data_ptr(), self.rope[1].data_ptr()
+        d.l_pos_table = self.pos_table.data_ptr()
+        d.x_pre, d.x_tok, d.hid, d.logits = (self.x_pre.data_ptr(), self.x_tok.data_ptr(), self.hid.data_ptr(),
+                                             self.logits.data_ptr())
+        d.raw = self.raw.data_ptr()
+        d.ws_tok, d.ws_tok_bytes = self.ws.data_ptr(), self.ws.numel()
+        d.exp_scratch = ptr(self.scratch)
+        d.exp_scratch_bytes = 0 if self.scratch is None else self.scratch.numel() * 4
+        d.sample_step = self.sample_step.data_ptr()
+
+    @staticmethod
+    def set_gen(d: bt_engine_desc, gen, cfg_pad: int):
+        gen_eos, gen_pad, do_sample, temperature, top_k, seed = _gen_fields(gen, cfg_pad)
+        d.do_sample, d.temperature, d.top_k, d.seed = int(do_sample), temperature, top_k, seed
+        d.config_pad, d.gen_eos, d.gen_pad = int(cfg_pad), gen_eos, int(gen_pad)
+        return gen_eos, gen_pad, do_sample, temperature, top_k, seed
 
     def run(self, ctx: torch.Tensor, count: int, gen=None, on_token=None):
-        """ctx [B, H_bd] -> raw[:, :count] token ids.  Pure launch sequence (capturable when on_token is None)."""
-        td, rt = self.td, self.rt
-        # expansion_layer: Conv1d(k=1) == Linear; [B, H_bd] -> [B, E*H] == E prefix rows per sequence
-        ops.linear(ctx, td.expansion_layer.weight, td.expansion_layer.bias, out=self.x_pre.view(self.B, self.E * self.H),
-                   scratch=self.scratch)
-        rt.forward(self.x_pre, self.E, self.local, pos0=0, pos_table=self.pos_table, first_out_row=self.E - 1,
-                   out=self.hid, ws=self.ws, rope=self.rope)
-        for t in range(count):
-            if t > 0:
-                ops.embed_rows(self.raw[:, t - 1], td.gpt_neox.embed_in.weight, out=self.x_tok)
-                rt.forward(self.x_tok, 1, self.local, pos0=self.E + t - 1, pos_table=self.pos_table, out=self.hid,
-                           ws=self.ws, rope=self.rope)
-            ops.linear(self.hid, td.embed_out.weight, None, out=self.logits)
-            self._pick(t, gen)
-            if on_token is not None:
+        """ctx [B, H_bd] -> raw[:, :count] token ids (stand-alone use: no finish step, no global state)."""
+        key = self.weight_key()
+        if self._desc is None or self._desc_key != key:
+            self._desc = bt_engine_desc()
+            self.fill_desc(self._desc)
+            self._desc_key = key
+        d = self._desc
+        if ctx.dtype != self.dtype or not ctx.is_contiguous():
+            raise _lib.BtError(f"block embeddings must be contiguous {self.dtype}")
+        d.ctx = ptr(ctx)
+        d.bd_dims.hidden = ctx.shape[-1]
+        self.set_gen(d, gen, int(self.td.config.pad_token_id or 0))
+        if on_token is None:
+            check(lib().bt_token_block_enqueue(ctypes.byref(d), 0, count, 0, current_stream()), "bt_token_block_enqueue")
+        else:
+            for t in range(count):
+                check(lib().bt_token_block_enqueue(ctypes.byref(d), t, t + 1, 0, current_stream()), "bt_token_block_enqueue")
                 on_token(self.raw[:, t])
         return self.raw
 
 
 class DecodeEngine:
-    """Everything ``BlockTransformer.generate`` needs for one (batch, max_blocks) problem size."""
+    """Everything ``BlockTransformer.generate`` needs for one (batch, max_blocks) problem size on ONE stream."""
 
-    def __init__(self, model, batch: int, max_blocks: int, rope_policy: str = "train", prefill_rows: Optional[int] = None):
+    pipelined = False
+
+    def __init__(self, model, batch: int, max_blocks: int, rope_policy: str = DEFAULT_ROPE_POLICY,
+                 prefill_rows: Optional[int] = None, stream: Optional[torch.cuda.Stream] = None):
         self.model = model
-        bd, td, emb = model.block_decoder, model.token_decoder, model.embedder
+        bd, td = model.block_decoder, model.token_decoder
         self.bd_rt: DecoderRuntime = bd._rt
         dev = self.bd_rt.device
         dt = self.bd_rt.dtype
@@ -128,124 +191,290 @@ class DecodeEngine:
         self.mask = torch.ones(batch, self.n_max + 1, dtype=torch.uint8, device=dev)
         self.finished = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.finished_prev = torch.zeros(batch, dtype=torch.int32, device=dev)
-        self.stream = torch.cuda.Stream(device=dev)                       # graphs cannot be captured on the null stream
+        # graphs cannot be captured on the null stream
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=dev)
         self.n_cur = torch.zeros(1, dtype=torch.int32, device=dev)       # cached block positions == index of next block
         # prefill is chunked over sequences so the activation workspace stays bounded
         self.prefill_rows = int(prefill_rows or os.environ.get("BT_PREFILL_ROWS", 32768))
         self.ws_step = torch.empty(self.bd_rt.workspace_bytes(batch), dtype=torch.uint8, device=dev)
         self.ws_prefill: Optional[torch.Tensor] = None
-        # split-N ("flash-decoding") for the global step when B*heads is too small to fill 256 CUs
-        self.n_split = 1
+        self.x_prefill: Optional[torch.Tensor] = None
+        # split-N ("flash-decoding") for the global step when B*heads is too small to fill 256 CUs; the library raises the
+        # factor on its own once a split's score row would not fit in LDS (very long contexts) -> same rule, same size here
+        hint = 1
         work = batch * heads
         if work < 512 and self.n_max >= 256:
-            self.n_split = int(min(16, max(1, 1024 // max(work, 1)), max(1, self.n_max // 64)))
+            hint = int(min(16, max(1, 1024 // max(work, 1)), max(1, self.n_max // 64)))
+        self.n_split = int(lib().bt_attention_split_count(self.H // heads, self.n_max, hint))
         self.split_ws = None
         if self.n_split > 1:
             self.split_ws = torch.empty(batch * heads * self.n_split * (self.H // heads + 2), dtype=torch.float32,
                                         device=dev)
-        self.graph_tok: Optional[Graph] = None
-        self.graph_roll: Optional[Graph] = None
+        self.desc = bt_engine_desc()
+        self._desc_key = None
+        self.graphs = {}
         self._graph_key = None
 
+    # ---- descriptor ----------------------------------------------------------------------------------------------------------
+    def weight_key(self):
+        emb = self.model.embedder.embeddings.weight
+        return (self.bd_rt.weight_key(), self.tok.weight_key(), emb.data_ptr())
+
+    def refresh_desc(self) -> None:
+        """(Re)fill the C descriptor when parameters moved (``.to()``, dtype cast, checkpoint load with assign=True)."""
+        key = self.weight_key()
+        if key == self._desc_key:
+            return
+        d = self.desc
+        self.tok.fill_desc(d)
+        emb = self.model.embedder.embeddings.weight
+        if emb.dtype != self.dtype or not emb.is_contiguous() or not emb.is_cuda:
+            raise _lib.BtError("embedder table must be contiguous, on the GPU and share the decoders' dtype")
+        d.bd_dims = self.bd_rt.dims
+        d.bd_w = self.bd_rt.weights()
+        d.emb_table, d.emb_width = emb.data_ptr(), emb.shape[1]
+        d.gk, d.gv = self.glob.k.data_ptr(), self.glob.v.data_ptr()
+        d.g_layer_stride, d.g_nmax = self.glob.layer_stride, self.glob.n_max
+        d.g_cos, d.g_sin = self.rope[0].data_ptr(), self.rope[1].data_ptr()
+        d.x_blk, d.ctx = self.x_blk.data_ptr(), self.ctx.data_ptr()
+        d.out_ids, d.nb_max = self.out_ids.data_ptr(), self.NB
+        d.n_cur, d.finished, d.finished_prev = self.n_cur.data_ptr(), self.finished.data_ptr(), self.finished_prev.data_ptr()
+        d.mask_ld = self.mask.stride(0)
+        d.ws_step, d.ws_step_bytes = self.ws_step.data_ptr(), self.ws_step.numel()
+        d.n_split = self.n_split
+        d.split_ws = ptr(self.split_ws)
+        d.split_ws_bytes = 0 if self.split_ws is None else self.split_ws.numel() * 4
+        self._desc_key = key
+        self.graphs = {}          # captured graphs bake in the old parameter pointers
+
+    def configure(self, gen, cfg_pad: int, use_mask: bool):
+        """Per-generate() settings: sampler / EOS fields of the descriptor; invalidates the graphs when they change (the
+        captured launches hold them by value)."""
+        self.refresh_desc()
+        fields = TokenBlockState.set_gen(self.desc, gen, cfg_pad)
+        self.desc.mask = self.mask.data_ptr() if use_mask else None
+        key = (use_mask, int(cfg_pad)) + fields
+        if key != self._graph_key:
+            self.graphs = {}
+            self._graph_key = key
+        return fields[0]   # gen_eos
+
     # ---- phases ------------------------------------------------------------------------------------------------------------
-    def prefill(self, block_ids: torch.Tensor, block_mask: torch.Tensor, use_mask: bool):
-        """Embed all prompt blocks and run the block decoder over them (causal, q_len = nb); ctx <- last hidden row."""
+    def prefill(self, block_ids: torch.Tensor, block_mask: torch.Tensor, scratch=None):
+        """Embed all prompt blocks and run the block decoder over them (causal, q_len = nb); ctx <- last hidden row.
+        ``scratch`` = (x, ws) tensors shared between the shards of a pipelined engine."""
         B, nb, L = block_ids.shape
         self.out_ids[:, :nb].copy_(block_ids)
         self.mask.fill_(1)
         self.mask[:, :nb].copy_(block_mask.to(torch.uint8))
         self.finished.zero_()
+        self.finished_prev.zero_()
         self.n_cur.fill_(nb)
-        emb_w = self.model.embedder.embeddings.weight
         bc = max(1, min(B, self.prefill_rows // max(nb, 1)))
-        need = self.bd_rt.workspace_bytes(bc * nb)
-        if self.ws_prefill is None or self.ws_prefill.numel() < need:
-            self.ws_prefill = None
-            self.ws_prefill = torch.empty(need, dtype=torch.uint8, device=self.device)
-        x = torch.empty(bc * nb, self.H, dtype=self.dtype, device=self.device)
-        mode = _lib.ATTN_FLASH if (self.dtype == torch.bfloat16 and nb > 1) else _lib.ATTN_ROWS
+        if scratch is None:
+            need = self.bd_rt.workspace_bytes(bc * nb)
+            if self.ws_prefill is None or self.ws_prefill.numel() < need:
+                self.ws_prefill = None
+                self.ws_prefill = torch.empty(need, dtype=torch.uint8, device=self.device)
+            if self.x_prefill is None or self.x_prefill.numel() < bc * nb * self.H:
+                self.x_prefill = None
+                self.x_prefill = torch.empty(bc * nb, self.H, dtype=self.dtype, device=self.device)
+            scratch = (self.x_prefill, self.ws_prefill)
+        x, ws = scratch
+        ids = block_ids.contiguous()
         for b0 in range(0, B, bc):
-            b1 = min(B, b0 + bc)
-            n = b1 - b0
-            xs = x[:n * nb]
-            ops.embed_rows(block_ids[b0:b1].reshape(-1), emb_w, out=xs.view(n * nb * L, -1))
-            self.bd_rt.forward(xs, nb, self.glob, b0=b0, pos0=0, mask=self.mask[b0:b1] if use_mask else None,
-                               mode=mode, first_out_row=nb - 1, out=self.ctx[b0:b1], ws=self.ws_prefill,
-                               rope=self.rope)
+            n = min(B, b0 + bc) - b0
+            check(lib().bt_prefill_enqueue(ctypes.byref(self.desc), ptr(ids), nb, b0, n, ptr(x), ptr(ws), ws.numel(),
+                                           current_stream()), "bt_prefill_enqueue")
 
-    def token_block(self, count: int, gen, cfg_pad: int, gen_eos: int, gen_pad: int, use_mask: bool, on_token=None):
-        """Decode <= L tokens from ctx, then finish the block on device (EOS/pad rules, ids, finished flags, mask)."""
-        self.tok.run(self.ctx, count, gen, on_token)
-        check(lib().bt_finish_block(self.B, self.L, count, ptr(self.tok.raw), ptr(self.out_ids), self.NB,
-                                    ptr(self.n_cur), ptr(self.finished), ptr(self.finished_prev),
-                                    ptr(self.mask) if use_mask else None, self.mask.stride(0), int(cfg_pad),
-                                    int(gen_eos), int(gen_pad), current_stream()), "bt_finish_block")
+    def prefill_scratch_shape(self, nb: int):
+        bc = max(1, min(self.B, self.prefill_rows // max(nb, 1)))
+        return bc * nb, self.bd_rt.workspace_bytes(bc * nb)
 
-    def roll_over(self, use_mask: bool):
-        """Embed the block just finished (zero rows for sequences that were already finished before it,
-        block_transformer.py:419-421), run the block-decoder step at cache row n, then n += 1."""
-        ops.embed_rows(self.tok.raw.view(-1), self.model.embedder.embeddings.weight,
-                       out=self.x_blk.view(self.B * self.L, -1), row_zero=self.finished_prev, rows_per_seq=self.L)
-        self.bd_rt.forward(self.x_blk, 1, self.glob, pos0_dev=self.n_cur, mask=self.mask if use_mask else None,
-                           mode=_lib.ATTN_ROWS, n_split=self.n_split, split_ws=self.split_ws, out=self.ctx,
-                           ws=self.ws_step, rope=self.rope)
-        check(lib().bt_bump(ptr(self.n_cur), 1, current_stream()), "bt_bump")
+    def _enqueue(self, what: str, count: int = 0):
+        d = ctypes.byref(self.desc)
+        if what == "tok":
+            check(lib().bt_token_block_enqueue(d, 0, count, count, current_stream()), "bt_token_block_enqueue")
+        elif what == "roll":
+            check(lib().bt_roll_over_enqueue(d, current_stream()), "bt_roll_over_enqueue")
+        else:   # "step": a full token block and the roll-over behind it
+            check(lib().bt_block_step_enqueue(d, count, 1, current_stream()), "bt_block_step_enqueue")
+
+    def launch(self, what: str, count: int, use_graphs: bool):
+        """Run one unit ("tok" / "roll" / "step") on torch's current stream, through its captured graph when allowed."""
+        if not use_graphs or (what != "roll" and count != self.L):
+            return self._enqueue(what, count)
+        g = self.graphs.get(what)
+        if g is None:
+            with Graph() as g:
+                self._enqueue(what, count)
+            self.graphs[what] = g
+        g.launch()
+
+    def token_block_streamed(self, count: int, streamer):
+        """Eager token block with one host callback per token (HF streamer protocol, inference_demo.py:69-83)."""
+        d = ctypes.byref(self.desc)
+        streamer.block_start()
+        for t in range(count):
+            fin = count if t == count - 1 else 0
+            check(lib().bt_token_block_enqueue(d, t, t + 1, fin, current_stream()), "bt_token_block_enqueue")
+            streamer.put(self.tok.raw[:, t])
+        streamer.block_end()
 
     # ---- the generate loop -------------------------------------------------------------------------------------------------
     def generate(self, block_ids: torch.Tensor, block_mask: torch.Tensor, max_length: int, added_pad: int, gen,
                  cfg_pad: int, use_graphs: bool = True, streamer=None, timers=None):
         """Runs prefill + block iterations; returns (out_ids[B, n_blocks, L], next_token_count of the last block)."""
         B, nb, L = block_ids.shape
-        gen_eos = -1 if gen.eos_token_id is None else int(gen.eos_token_id)
-        gen_pad = gen.pad_token_id if gen.pad_token_id is not None else (gen_eos if gen_eos >= 0 else cfg_pad)
-        use_mask = gen_eos >= 0 or not bool(block_mask.all())
-        on_token = None
-        if streamer is not None:
-            use_graphs = False
-            on_token = streamer.put  # one [B] tensor per token, like HF generate's streamer
-        key = (use_mask, gen_eos, gen_pad, cfg_pad, bool(gen.do_sample), float(gen.temperature or 1.0),
-               int(gen.top_k or 0))
-        if self._graph_key != key:
-            self.graph_tok = self.graph_roll = None
-            self._graph_key = key
-
+        use_mask = (gen is not None and gen.eos_token_id is not None) or not bool(block_mask.all())
+        gen_eos = self.configure(gen, cfg_pad, use_mask)
+        per_iter = timers is not None and timers.per_iteration
         side = self.stream
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             if timers is not None:
                 timers.mark("prefill_start")
-            self.prefill(block_ids, block_mask, use_mask)
+            self.prefill(block_ids, block_mask)
             if timers is not None:
                 timers.mark("decode_start")
             n_blocks = nb
+            # EOS handling needs a host look at finished[] between the token block and the roll-over (like the
+            # reference, :415); without it a block step is ONE graph (token block + roll-over)
+            fused_step = use_graphs and gen_eos < 0 and streamer is None and not per_iter
             while True:
                 count = min(max_length - (n_blocks * L - added_pad), L)
-                if use_graphs and count == L:
-                    if self.graph_tok is None:
-                        with Graph() as g:
-                            self.token_block(L, gen, cfg_pad, gen_eos, gen_pad, use_mask)
-                        self.graph_tok = g
-                    self.graph_tok.launch()
+                last = (n_blocks + 1) * L >= max_length
+                if per_iter:
+                    timers.mark_iter("token_decoder_start")
+                if streamer is not None:
+                    self.token_block_streamed(count, streamer)
+                elif fused_step and not last and count == L:
+                    self.launch("step", L, True)
+                    n_blocks += 1
+                    continue
                 else:
-                    if streamer is not None:
-                        streamer.block_start()
-                    self.token_block(count, gen, cfg_pad, gen_eos, gen_pad, use_mask, on_token)
-                    if streamer is not None:
-                        streamer.block_end()
+                    self.launch("tok", count, use_graphs)
+                if per_iter:
+                    timers.mark_iter("token_decoder_end")
                 n_blocks += 1
                 if n_blocks * L >= max_length:
                     break
                 if gen_eos >= 0 and bool(self.finished.all()):  # host sync per block, like the reference (:415)
                     break
-                if use_graphs:
-                    if self.graph_roll is None:
-                        with Graph() as g:
-                            self.roll_over(use_mask)
-                        self.graph_roll = g
-                    self.graph_roll.launch()
-                else:
-                    self.roll_over(use_mask)
+                if per_iter:
+                    timers.mark_iter("block_decoder_start")
+                self.launch("roll", 0, use_graphs and streamer is None)
+                if per_iter:
+                    timers.mark_iter("block_decoder_end")
             if timers is not None:
                 timers.mark("decode_end")
         torch.cuda.current_stream().wait_stream(side)
         return self.out_ids[:, :n_blocks], count
+
+
+class PipelinedEngine:
+    """Two half-batch ``DecodeEngine`` shards on two streams, offset by one token block, so that one shard's HBM-bound
+    global-attention step overlaps the other's MFMA-bound token-decoder GEMMs.  Sequences are independent (SURVEY.md
+    section 8e), so the result equals the single-engine result row for row."""
+
+    pipelined = True
+
+    def __init__(self, model, batch: int, max_blocks: int, rope_policy: str = DEFAULT_ROPE_POLICY, n_shards: int = 2):
+        self.model = model
+        self.B, self.NB = batch, max_blocks
+        bounds = [(batch * i) // n_shards for i in range(n_shards + 1)]
+        self.bounds = bounds
+        self.shards: List[DecodeEngine] = [DecodeEngine(model, bounds[i + 1] - bounds[i], max_blocks, rope_policy)
+                                           for i in range(n_shards)]
+        s0 = self.shards[0]
+        self.device, self.dtype, self.L = s0.device, s0.dtype, s0.L
+        self.tok = s0.tok             # policy / dims probe used by BlockTransformer._get_engine
+        self.stream = s0.stream
+        self.sync_phases = os.environ.get("BT_PIPELINE_SYNC", "0") == "1"
+        self._scratch = None
+
+    @property
+    def ctx(self) -> torch.Tensor:
+        return torch.cat([s.ctx for s in self.shards], dim=0)
+
+    @property
+    def finished(self) -> torch.Tensor:
+        return torch.cat([s.finished for s in self.shards], dim=0)
+
+    def _prefill_scratch(self, nb: int):
+        rows, nbytes = max(s.prefill_scratch_shape(nb) for s in self.shards)
+        sc = self._scratch
+        if sc is None or sc[0].shape[0] < rows or sc[1].numel() < nbytes:
+            self._scratch = None
+            s0 = self.shards[0]
+            self._scratch = (torch.empty(rows, s0.H, dtype=self.dtype, device=self.device),
+                             torch.empty(nbytes, dtype=torch.uint8, device=self.device))
+        return self._scratch
+
+    def generate(self, block_ids: torch.Tensor, block_mask: torch.Tensor, max_length: int, added_pad: int, gen,
+                 cfg_pad: int, use_graphs: bool = True, streamer=None, timers=None):
+        if streamer is not None:
+            raise _lib.BtError("streaming runs on the single-stream engine (BlockTransformer picks it when a streamer is given)")
+        B, nb, L = block_ids.shape
+        use_mask = (gen is not None and gen.eos_token_id is not None) or not bool(block_mask.all())
+        gen_eos = -1
+        for s in self.shards:
+            gen_eos = s.configure(gen, cfg_pad, use_mask)
+        per_iter = timers is not None and timers.per_iteration
+        main = self.stream
+        main.wait_stream(torch.cuda.current_stream())
+        scratch = self._prefill_scratch(nb)
+        with torch.cuda.stream(main):
+            if timers is not None:
+                timers.mark("prefill_start")
+            for i, s in enumerate(self.shards):   # prefill is MFMA-bound end to end: shards run back to back
+                lo, hi = self.bounds[i], self.bounds[i + 1]
+                s.prefill(block_ids[lo:hi], block_mask[lo:hi], scratch)
+            if timers is not None:
+                timers.mark("decode_start")
+        # decode: shard i runs on its own stream, one token block behind shard i-1
+        streams = [main] + [s.stream for s in self.shards[1:]]
+        for st in streams[1:]:
+            st.wait_stream(main)
+        n_blocks = nb
+        gate = None
+        first = True
+        while True:
+            count = min(max_length - (n_blocks * L - added_pad), L)
+            for i, s in enumerate(self.shards):
+                with torch.cuda.stream(streams[i]):
+                    # first block: every shard starts one token block behind the previous one, then they free-run (roll-over
+                    # of one shard beside the token block of the other).  BT_PIPELINE_SYNC=1 keeps passing the baton for
+                    # the whole decode: at most one shard is inside a token block (the MFMA-bound phase) at any time.
+                    gated = first or self.sync_phases
+                    if gated and gate is not None:
+                        streams[i].wait_event(gate)
+                    if per_iter and i == 0:
+                        timers.mark_iter("token_decoder_start")
+                    s.launch("tok", count, use_graphs)
+                    if per_iter and i == 0:
+                        timers.mark_iter("token_decoder_end")
+                    if gated:
+                        gate = torch.cuda.Event()
+                        gate.record(streams[i])
+            first = False
+            n_blocks += 1
+            if n_blocks * L >= max_length:
+                break
+            if gen_eos >= 0 and all(bool(s.finished.all()) for s in self.shards):   # host sync per block (reference :415)
+                break
+            for i, s in enumerate(self.shards):
+                with torch.cuda.stream(streams[i]):
+                    if per_iter and i == 0:
+                        timers.mark_iter("block_decoder_start")
+                    s.launch("roll", 0, use_graphs)
+                    if per_iter and i == 0:
+                        timers.mark_iter("block_decoder_end")
+        for st in streams[1:]:
+            main.wait_stream(st)
+        with torch.cuda.stream(main):
+            if timers is not None:
+                timers.mark("decode_end")
+        torch.cuda.current_stream().wait_stream(main)
+        out = torch.cat([s.out_ids[:, :n_blocks] for s in self.shards], dim=0)
+        return out, count

@@ -14,23 +14,40 @@ from typing import Optional
 import torch
 from torch import nn
 
-from ..engine import DecodeEngine
+from ..engine import DEFAULT_ROPE_POLICY, DecodeEngine, PipelinedEngine
 
 
 class _Timers:
-    """hipEvent phase marks for generate(benchmark=True) and bench.py (prefill vs decode split)."""
+    """hipEvent phase marks for generate(benchmark=True) and bench.py (prefill vs decode split); with
+    ``per_iteration`` also one start/end pair per block-decoder step and per token block, like the reference's
+    ``block_decoder_starts/ends`` and ``token_decoder_starts/ends`` lists (model/block_transformer.py:347-353,428-444)."""
 
-    def __init__(self):
+    def __init__(self, per_iteration: bool = False):
         self.events = {}
+        self.per_iteration = per_iteration
+        self.iter_events = {}
 
     def mark(self, name: str):
         ev = torch.cuda.Event(enable_timing=True)
         ev.record(torch.cuda.current_stream())
         self.events[name] = ev
 
+    def mark_iter(self, name: str):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record(torch.cuda.current_stream())
+        self.iter_events.setdefault(name, []).append(ev)
+
     def ms(self, a: str, b: str) -> float:
         self.events[b].synchronize()
         return self.events[a].elapsed_time(self.events[b])
+
+    def iter_ms(self, kind: str):
+        starts, ends = self.iter_events.get(kind + "_start", []), self.iter_events.get(kind + "_end", [])
+        out = []
+        for a, b in zip(starts, ends):
+            b.synchronize()
+            out.append(a.elapsed_time(b))
+        return out
 
 
 class BlockTransformer(nn.Module):
@@ -58,6 +75,7 @@ class BlockTransformer(nn.Module):
         self.decoding_strategy = decoding_strategy
         self.config = self.token_decoder.config  # for Evaluation (reference :48)
         self.use_graphs = True
+        self.pipeline = None          # None = auto (see _want_pipeline)
         self.collect_timers = False  # bench.py: record phase events without the benchmark printout
         self._engine: Optional[DecodeEngine] = None
         self.last_timers: Optional[_Timers] = None
@@ -107,14 +125,26 @@ class BlockTransformer(nn.Module):
         return block_embeds.view((batch_size, n_blocks) + block_embeds.shape[-2:])
 
     # ---- engine management ---------------------------------------------------------------------------------------------------
-    def _get_engine(self, batch: int, max_blocks: int) -> DecodeEngine:
+    def _want_pipeline(self, batch: int) -> bool:
+        """Two half-batch shards on two streams (engine.PipelinedEngine) for large batches: ``self.pipeline`` = True /
+        False / None (auto: batch >= BT_PIPELINE_MIN_BATCH, default 1024; BT_PIPELINE=0/1 overrides)."""
+        import os
+        env = os.environ.get("BT_PIPELINE")
+        want = self.pipeline if self.pipeline is not None else (None if env is None else env == "1")
+        if want is None:
+            want = batch >= int(os.environ.get("BT_PIPELINE_MIN_BATCH", 1024))
+        return bool(want) and batch >= 2
+
+    def _get_engine(self, batch: int, max_blocks: int, streaming: bool = False):
         e = self._engine
         rt = self.block_decoder._rt
-        policy = getattr(self.token_decoder, "rope_policy", "train")
+        policy = getattr(self.token_decoder, "rope_policy", DEFAULT_ROPE_POLICY)
+        pipelined = self._want_pipeline(batch) and not streaming
         if (e is None or e.B != batch or e.NB < max_blocks or e.dtype != rt.dtype or e.device != rt.device
-                or e.tok.policy != policy):
+                or e.tok.policy != policy or e.pipelined != pipelined):
             self._engine = None  # free the old buffers before allocating the new ones
-            e = self._engine = DecodeEngine(self, batch, max_blocks, rope_policy=policy)
+            cls = PipelinedEngine if pipelined else DecodeEngine
+            e = self._engine = cls(self, batch, max_blocks, rope_policy=policy)
         return e
 
     def release_buffers(self):
@@ -170,8 +200,8 @@ class BlockTransformer(nn.Module):
             total_blocks += 1
             if total_blocks * block_length >= max_length:
                 break
-        engine = self._get_engine(batch_size, total_blocks)
-        timers = _Timers() if (benchmark or self.collect_timers) else None
+        engine = self._get_engine(batch_size, total_blocks, streaming=streamer is not None)
+        timers = _Timers(per_iteration=bool(benchmark)) if (benchmark or self.collect_timers) else None
         if benchmark:
             print(f"Benchmarking generation... (benchmark={benchmark})")
         gen = self.token_decoder.generation_config
@@ -184,10 +214,18 @@ class BlockTransformer(nn.Module):
         out = out.clone()
         self.last_timers = timers
         if benchmark:
+            # same report as the reference (:428-444): the first block-decoder time is the prefill, the others the
+            # per-block global steps; one token-decoder time per generated block (L cached forwards each)
+            bd = [timers.ms("prefill_start", "decode_start")] + timers.iter_ms("block_decoder")
+            td = timers.iter_ms("token_decoder")
             print(" Generation time (ms) ".center(100, "-"))
+            if engine.pipelined:
+                print("(two half-batch shards on two streams: per-iteration times are shard 0's and overlap shard 1's work)")
             print("Total time: ", timers.ms("prefill_start", "decode_end"))
-            print("Block decoder prefill time: ", timers.ms("prefill_start", "decode_start"))
-            print("Decode loop time (token decoder + block decoder steps): ", timers.ms("decode_start", "decode_end"))
+            print("Block decoder times: ", bd)
+            print("Token decoder times: ", td)
+            print("Block decoder total time: ", sum(bd))
+            print("Token decoder total time: ", sum(td))
         if vanilla_mode:
             out = self.revert_block_input_ids_to_vanilla(out, added_initial_block_padding,
                                                          last_block_unfilled_length=block_length - next_token_count)

@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from ... import _lib, ops
-from ...engine import TokenBlockState, td_position_table
+from ...engine import DEFAULT_ROPE_POLICY, TokenBlockState, td_position_table
 from ...runtime import DecoderRuntime, KVCache
 from ..neox import CausalLMOutputWithPast, GenerationConfig, GPTNeoXModel, init_neox_weights
 from .base import BaseTokenDecoder
@@ -35,9 +35,13 @@ class GPTNeoXTokenDecoder(nn.Module, BaseTokenDecoder):
         # HF GenerationConfig.from_model_config: eos/bos/pad copied from the model config at construction
         self.generation_config = GenerationConfig(eos_token_id=config.eos_token_id, bos_token_id=config.bos_token_id,
                                                   pad_token_id=pad_at_init)
-        self.rope_policy = "train"  # see engine.td_position_table
+        # RoPE positions used by generate() (engine.td_position_table): the reference's cached generation rotates the E
+        # prefix rows at position 0 and token t at t + 1 (transformers 4.39.3 position_ids routed through **kwargs);
+        # "train" = plain arange.  A direct forward() without ``position_ids`` always uses arange, like the reference.
+        self.rope_policy = DEFAULT_ROPE_POLICY
         self._rt = DecoderRuntime(self.gpt_neox, config)
         self._tok_state: Optional[TokenBlockState] = None
+        self._pos_tables = {}
 
     # ---- reference adapter surface (model/token_decoder/gpt_neo_x.py:52-74) ------------------------------------------
     @torch.no_grad()
@@ -54,6 +58,16 @@ class GPTNeoXTokenDecoder(nn.Module, BaseTokenDecoder):
         B = block_embeddings.shape[0]
         y = ops.linear(block_embeddings.reshape(B, -1), self.expansion_layer.weight, self.expansion_layer.bias)
         return y.view(B, self.n_expanded_emb, self.hidden_size)
+
+    def _pos_table_cached(self, table, device) -> torch.Tensor:
+        """int32 device copy of a RoPE position table, built once per distinct table (no per-call H2D copy / sync)."""
+        key = (table, str(device))
+        t = self._pos_tables.get(key)
+        if t is None:
+            if len(self._pos_tables) > 64:
+                self._pos_tables.clear()
+            t = self._pos_tables[key] = torch.tensor(list(table), dtype=torch.int32, device=device)
+        return t
 
     # ---- forward ----------------------------------------------------------------------------------------------------------
     @torch.no_grad()
@@ -126,10 +140,24 @@ class GPTNeoXTokenDecoder(nn.Module, BaseTokenDecoder):
                             x.dtype, x.device)
         elif n_total > cache.n_max:
             cache = cache.grown(n_total + self.block_length)
-        table = td_position_table(self.rope_policy, E, max(self.block_length, cache.n_max - E + 1))
-        pos_table = torch.tensor(table[:cache.n_max], dtype=torch.int32, device=x.device)
+        # RoPE positions of the adapted rows: HF default arange(past, past + q) unless the caller passes ``position_ids``
+        # (the reference forwards **kwargs to gpt_neox, base.py:301-303; HF broadcasts a [B, 1] id over the q rows)
+        position_ids = kwargs.get("position_ids")
+        table = list(range(cache.n_max))
+        if position_ids is not None:
+            pid = torch.as_tensor(position_ids).reshape(-1, torch.as_tensor(position_ids).shape[-1]).cpu()
+            if not bool((pid == pid[:1]).all()):
+                raise NotImplementedError("per-sequence position_ids are not supported: all rows must share one position row")
+            row = [int(v) for v in pid[0]]
+            if len(row) == 1:
+                row = row * q
+            if len(row) != q:
+                raise ValueError(f"position_ids has {len(row)} columns, expected 1 or the {q} adapted rows")
+            table[past_len:past_len + q] = row
+        pos_table = self._pos_table_cached(tuple(table), x.device)
         hidden = self._rt.forward(x.view(bs * q, H), q, cache, pos0=past_len, pos_table=pos_table,
-                                  mask=key_mask.contiguous(), first_out_row=first_out)
+                                  mask=key_mask.contiguous(), first_out_row=first_out,
+                                  rope=self._rt.rope(max(table) + 1))
         cache.length = n_total
         n_out = q - first_out
         logits = self.compute_logits(hidden).view(bs, n_out, cfg.vocab_size)

@@ -113,7 +113,15 @@ def load_token_decoder_from_config(cfg, block_decoder) -> GPTNeoXTokenDecoder:
         kwargs["init_expansion"] = _get(cfg, "token_decoder.init_expansion")
     dt = get_torch_dtype(cfg)
     print("Initializing token decoder from scratch...")
-    return cls(_neox_config(_get(cfg, "token_decoder"), dt), **kwargs).to(dt)
+    model = cls(_neox_config(_get(cfg, "token_decoder"), dt), **kwargs).to(dt)
+    # build-specific knob (not in the reference YAMLs): RoPE positions of cached generation, see engine.td_position_table.
+    # Default "hf439_generate" = the reference's generate(); ``++token_decoder.rope_policy=train`` = plain arange.
+    policy = _get(cfg, "token_decoder.rope_policy")
+    if policy is not None:
+        from ..engine import td_position_table
+        td_position_table(policy, 1, 1)   # validates the name
+        model.rope_policy = policy
+    return model
 
 
 def _load_tokenizer(cfg):

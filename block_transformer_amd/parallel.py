@@ -77,16 +77,24 @@ def sum_over_ranks(value: float) -> float:
     return float(t.item())
 
 
-def gather_ids(local_ids: torch.Tensor, n_total: int) -> Optional[torch.Tensor]:
-    """Concatenate every rank's generated ids (shard order == request order); returned on every rank."""
+def gather_ids(local_ids: torch.Tensor, n_total: int, pad_token_id: int = 0) -> Optional[torch.Tensor]:
+    """Concatenate every rank's generated ids (shard order == request order); returned on every rank.
+
+    Shards may come back with different widths: with EOS handling enabled each shard's generate() stops as soon as all
+    of ITS sequences are finished, and an empty shard has no width of its own.  The common width is agreed with one
+    MAX all-reduce and narrower shards are right-padded with ``pad_token_id`` before the all-gather."""
     if not dist.is_initialized():
         return local_ids
     world = dist.get_world_size()
     dev = _device_for_collectives()
-    width = local_ids.shape[1]
+    w = torch.tensor([local_ids.shape[1] if local_ids.dim() == 2 and local_ids.shape[0] > 0 else 0], dtype=torch.int64,
+                     device=dev)
+    dist.all_reduce(w, op=dist.ReduceOp.MAX)
+    width = int(w.item())
     per = -(-n_total // world)
-    buf = torch.zeros(per, width, dtype=torch.int64, device=dev)
-    buf[: local_ids.shape[0]] = local_ids.to(dev)
+    buf = torch.full((per, width), int(pad_token_id), dtype=torch.int64, device=dev)
+    if local_ids.shape[0] > 0:
+        buf[: local_ids.shape[0], : local_ids.shape[1]] = local_ids.to(dev)
     parts: List[torch.Tensor] = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(parts, buf)
     out = []
@@ -96,9 +104,26 @@ def gather_ids(local_ids: torch.Tensor, n_total: int) -> Optional[torch.Tensor]:
     return torch.cat(out, dim=0)
 
 
-def generate_sharded(generate_fn, input_ids: torch.Tensor, **kw) -> torch.Tensor:
-    """Run ``generate_fn`` on this rank's request shard and gather the full result."""
+def generate_sharded(generate_fn, input_ids: torch.Tensor, pad_token_id: int = 0, **kw) -> torch.Tensor:
+    """Run ``generate_fn`` on this rank's request shard and gather the full result (right-padded to the widest shard)."""
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
     lo, hi = shard_bounds(input_ids.shape[0], rank, world)
-    local = generate_fn(input_ids[lo:hi], **kw) if hi > lo else input_ids.new_zeros(0, kw.get("max_length", 0))
-    return gather_ids(local, input_ids.shape[0])
+    local = generate_fn(input_ids[lo:hi], **kw) if hi > lo else input_ids.new_zeros(0, 0)
+    return gather_ids(local, input_ids.shape[0], pad_token_id)
+
+
+def launch_self_under_torchrun(n_procs: int, script: str, argv: List[str]) -> None:
+    """Re-exec ``script argv`` as ``n_procs`` ranks of one node under ``torch.distributed.run`` (rendezvous on 127.0.0.1, a
+    free port) when this process is not already one of them.  Does not return on success (os.execv)."""
+    import socket
+    import sys
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 or n_procs <= 1:
+        return
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_procs}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)

@@ -98,6 +98,13 @@ class DecoderRuntime:
         out += [self.module.final_layer_norm.weight, self.module.final_layer_norm.bias]
         return out
 
+    def weight_key(self):
+        """Identity of the parameter storage (device pointers + dtype): engines key their C descriptor and their captured
+        hipGraphs on it, so re-materialised parameters (``.to()``, ``load_state_dict(assign=True)``) are never replayed
+        through stale pointers."""
+        params = self._params()
+        return tuple(p.data_ptr() for p in params) + (params[0].dtype,)
+
     def weights(self) -> bt_decoder_weights:
         """(Re)build the pointer table when parameters moved (``.to(device)``, dtype cast, checkpoint load)."""
         params = self._params()

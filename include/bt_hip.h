@@ -10,7 +10,10 @@
  * Contract (every entry point):
  *   - plain pointers and sizes only; all pointers are DEVICE pointers unless the name ends in `_host`;
  *   - never allocates or frees device memory (the caller passes workspaces), never synchronises the stream,
- *     no internal threads; re-entrant per (device, stream);
+ *     no internal threads, no process-global mutable dispatch state (kernel selection is a pure function of the
+ *     arguments; the A/B and ablation hooks `bt_debug_*` exist only in the separate test build libbt_hip_dbg.so,
+ *     compiled with -DBT_DEBUG_HOOKS); re-entrant per (device, stream).  The one opt-in exception is the bench-only
+ *     kernel-family timer `bt_prof_enable` (off by default; not thread-safe while enabled);
  *   - enqueues its kernels on `stream` (a hipStream_t passed as void*; NULL = the null stream) and returns
  *     BT_OK (0) or a negative bt_status; `bt_last_error()` returns a thread-local message;
  *   - safe inside hipStreamBeginCapture / hipGraph capture (no host reads of device memory): values that change
@@ -35,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BT_VERSION 100 /* 0.1.0 */
+#define BT_VERSION 200 /* 0.2.0: bt_engine_desc + bt_*_enqueue */
 
 typedef void* bt_stream; /* hipStream_t */
 
@@ -167,6 +170,9 @@ int bt_ln_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_t heads, in
  *       1 = MFMA flash kernel (bf16 prefill).  Replaces flash-attn fwd / eager baddbmm+softmax+matmul (C6).
  * `ws`/`ws_bytes`: scratch for split-N partials (may be NULL when n_split == 1).  Rows whose keys are all masked
  * produce zeros (the reference leaves them unspecified: finfo.min arithmetic). */
+/* The split-N factor bt_attention(mode 0) will actually use for a hint: raised until one split's score row fits in LDS
+ * (about 15.8k keys per split at head_dim 128).  Callers size `ws` as B*heads*q_len*n_split*(head_dim+2) floats when > 1. */
+int32_t bt_attention_split_count(int32_t head_dim, int64_t n_max, int32_t n_split_hint);
 int bt_attention(int dtype, int mode, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim, const void* qkv,
                  int64_t ld_qkv, const void* k_cache, const void* v_cache, int64_t n_max, const int32_t* pos0_dev,
                  int32_t pos0_host, const uint8_t* mask, int64_t mask_ld, void* out, int64_t ldo, int32_t n_split,
@@ -177,7 +183,9 @@ int bt_argmax(int dtype, int64_t M, int64_t V, const void* logits, int64_t ld, i
               bt_stream stream);
 
 /* HF sample(): logits/temperature -> top-k filter -> softmax -> multinomial, one draw per row with a counter-based
- * RNG keyed by (seed, *step_dev, row).  Distributional parity only (sampling).  (C12) */
+ * RNG keyed by (seed, *step_dev, row) -- deterministic for a given key: the kept set is compacted in vocabulary order
+ * (every score above the k-th largest + the lowest-index ties, at most 1024 candidates; top_k in (1024, V) is
+ * refused with BT_ERR_UNSUPPORTED; top_k <= 0 or >= V = no filter).  Distributional parity only.  (C12) */
 int bt_topk_sample(int dtype, int64_t M, int64_t V, const void* logits, int64_t ld, float temperature, int32_t top_k,
                    uint64_t seed, const int32_t* step_dev, int64_t* ids_out, int64_t ids_stride, bt_stream stream);
 
@@ -219,6 +227,82 @@ int bt_finish_block(int64_t B, int32_t L, int32_t count, int64_t* raw, int64_t* 
                     int64_t mask_ld, int64_t config_pad, int64_t gen_eos, int64_t gen_pad, bt_stream stream);
 /* *counter += delta (device scalar bump inside a captured graph). */
 int bt_bump(int32_t* counter, int32_t delta, bt_stream stream);
+
+/* ---- the two-level block step as C entry points (BlockTransformer.generate loop body, model/block_transformer.py:370-426) ----
+ * Everything one (batch, max_blocks) problem needs, as raw device pointers: a binder in any language fills this once,
+ * then runs   bt_prefill_enqueue (per chunk of sequences)  ->  { bt_block_step_enqueue } x n_blocks   on a stream,
+ * or captures bt_block_step_enqueue into a hipGraph (bt_graph_*) and replays it: every value that changes between
+ * replays lives in device memory (n_cur, finished[], mask, sample_step).  No entry point allocates, synchronises or
+ * reads device memory on the host.  All activation buffers are dtype `dtype`, row-major, contiguous. */
+typedef struct bt_engine_desc {
+    int32_t dtype;           /* bt_dtype of weights, activations and KV caches */
+    int32_t L;               /* block_length */
+    int32_t E;               /* token_decoder.n_expanded_emb (prefix rows per block) */
+    int32_t vocab;
+    int64_t B;               /* sequences in this engine */
+    bt_decoder_dims bd_dims; /* block decoder (global) stack */
+    bt_decoder_weights bd_w;
+    bt_decoder_dims td_dims; /* token decoder (local) stack */
+    bt_decoder_weights td_w;
+    const void* emb_table;   /* embedder.embeddings.weight [vocab, emb_width], emb_width * L == bd_dims.hidden */
+    int32_t emb_width;
+    int32_t do_sample;       /* 0 greedy (bt_argmax), 1 temperature + top-k multinomial (bt_topk_sample) */
+    const void* exp_w;       /* token_decoder.expansion_layer.weight [E * H_td, H_bd] (Conv1d k=1 == Linear) */
+    const void* exp_b;       /* [E * H_td] or NULL */
+    const void* embed_in;    /* token_decoder.gpt_neox.embed_in.weight [vocab, H_td] */
+    const void* embed_out;   /* token_decoder.embed_out.weight [vocab, H_td] */
+    /* global KV cache K,V[layers][B][heads][g_nmax][d] + block-decoder RoPE tables */
+    void* gk; void* gv; int64_t g_layer_stride; int64_t g_nmax; const float* g_cos; const float* g_sin;
+    /* local KV cache K,V[layers][B][heads][l_nmax = E+L-1][d] + token-decoder RoPE tables and position policy table */
+    void* lk; void* lv; int64_t l_layer_stride; int64_t l_nmax; const float* l_cos; const float* l_sin;
+    const int32_t* l_pos_table;
+    /* activations */
+    void* x_blk;             /* [B, H_bd]  embedded block (block-decoder step input; overwritten) */
+    void* ctx;               /* [B, H_bd]  context embedding = block-decoder output of the newest block */
+    void* x_pre;             /* [B*E, H_td] expanded prefix rows */
+    void* x_tok;             /* [B, H_td]  embed_in(previous token) */
+    void* hid;               /* [B, H_td]  token-decoder output row */
+    void* logits;            /* [B, vocab] */
+    int64_t* raw;            /* [B, L] tokens of the block being decoded */
+    int64_t* out_ids;        /* [B, nb_max, L] all blocks (prompt + generated) */
+    int64_t nb_max;
+    int32_t* n_cur;          /* device scalar: cached global positions == index of the block being decoded */
+    int32_t* finished;       /* [B] */
+    int32_t* finished_prev;  /* [B] */
+    uint8_t* mask;           /* [B, mask_ld] block attention mask, or NULL when no key is ever masked (EOS disabled, no padding) */
+    int64_t mask_ld;
+    void* ws_tok; int64_t ws_tok_bytes;     /* >= bt_decoder_workspace_bytes(td_dims, dtype, B*E) */
+    void* ws_step; int64_t ws_step_bytes;   /* >= bt_decoder_workspace_bytes(bd_dims, dtype, B) */
+    void* exp_scratch; int64_t exp_scratch_bytes; /* optional split-K scratch of the expansion GEMM (may be NULL) */
+    int32_t n_split;         /* split-N factor of the global attention step (1 = off) */
+    int32_t top_k;
+    void* split_ws; int64_t split_ws_bytes;
+    float temperature;
+    int32_t reserved0;
+    uint64_t seed;
+    int32_t* sample_step;    /* device counter of sampling draws (RNG stream position); required when do_sample */
+    int64_t config_pad;      /* token_decoder.config.pad_token_id (fills the unfilled tail of a partial block) */
+    int64_t gen_eos;         /* generation_config.eos_token_id, < 0 = EOS handling disabled */
+    int64_t gen_pad;         /* pad written after EOS */
+} bt_engine_desc;
+
+/* Prefill of sequences [b0, b0+nseq): embed their nb prompt blocks (block_ids [B, nb, L] int64 on device), run the block
+ * decoder over them (causal, mode 1 = MFMA flash for bf16 when nb > 1) writing global KV rows 0..nb-1, and leave the last
+ * hidden row of each sequence in ctx[b0 ..].  x: scratch [nseq*nb, H_bd]; ws: >= bt_decoder_workspace_bytes(bd, nseq*nb).
+ * The caller sets *n_cur = nb, out_ids[:, :nb] = block_ids and the mask columns.  (block_transformer.py:355-380, first iteration) */
+int bt_prefill_enqueue(const bt_engine_desc* e, const int64_t* block_ids, int32_t nb, int64_t b0, int64_t nseq, void* x,
+                       void* ws, int64_t ws_bytes, bt_stream stream);
+/* Token steps t in [t_begin, t_end) of the block being decoded (t_begin == 0 also runs the expansion and the E prefix
+ * rows): token_decoder.generate (model/token_decoder/base.py:399-453 = L cached forwards + greedy/sample).  When
+ * finish_count > 0 the block is closed afterwards with bt_finish_block(count = finish_count). */
+int bt_token_block_enqueue(const bt_engine_desc* e, int32_t t_begin, int32_t t_end, int32_t finish_count, bt_stream stream);
+/* Roll-over: embedder lookup+concat of the block just finished (zero rows for sequences finished before it), block-decoder
+ * step at global cache row *n_cur (RoPE + append + attention over *n_cur + 1 positions) -> ctx, then *n_cur += 1.
+ * (block_transformer.py:370-380,419-426) */
+int bt_roll_over_enqueue(const bt_engine_desc* e, bt_stream stream);
+/* One full block step = bt_token_block_enqueue(e, 0, count, count) followed, when roll != 0, by bt_roll_over_enqueue:
+ * the unit that is hipGraph-captured. */
+int bt_block_step_enqueue(const bt_engine_desc* e, int32_t count, int32_t roll, bt_stream stream);
 
 /* ---- hipGraph helpers (capture the block step once, replay per block) ------------------------------------------ */
 typedef struct bt_graph bt_graph;

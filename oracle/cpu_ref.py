@@ -4,13 +4,16 @@ A pure-PyTorch (CPU, eager) restatement of the reference's Block Transformer dec
 ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this module; the product package
 (``block_transformer_amd``) never does, and fails loudly when its HIP extension is missing.
 
-Parity status: PINNED for the no-cache paths against outputs of the reference's own classes imported in the build
-container (``oracle/make_golden.py`` -> ``tests/golden/*.npz``: G1 embedder, G2 block-decoder prefill, G4 expansion,
-G5 token-decoder teacher-forced logits, G6 greedy tokens assembled from the reference classes, G7
-``BlockTransformer.forward`` logits, G8 preprocess/revert integer cases).  The cached ``generate()`` of the
-reference cannot run on the installed transformers (5.15.0 vs the pinned 4.39.3); its
-token-decoder RoPE position policy under 4.39.3 (``hf439_generate`` below) is therefore restated from the published
-4.39.3 source and is UNPINNED.  The default policy ``train`` is pinned by G5/G6/G7.
+Parity status: PINNED against outputs of the reference's own classes imported in the build container
+(``oracle/make_golden.py`` -> ``tests/golden/*.npz``: G1 embedder, G2 block-decoder prefill, G4 expansion, G5
+token-decoder teacher-forced logits, G6 greedy tokens assembled from the reference classes (arange positions), G7
+``BlockTransformer.forward`` logits, G8 preprocess/revert integer cases, G9 greedy tokens from the reference classes
+evaluated at the position ids of cached generation).  The reference's cached ``generate()`` itself cannot run on the
+installed transformers (5.15.0 vs the pinned 4.39.3): the position ids it would feed
+(``hf439_generate`` below: prefix rows at 0, token t at t+1) are restated from the published 4.39.3
+``GPTNeoXForCausalLM.prepare_inputs_for_generation`` (position_ids = cumsum(attention_mask) - 1, last column once a cache
+exists) and the reference's **kwargs routing (model/token_decoder/gpt_neo_x.py:76-90, base.py:158,301-303); what IS
+pinned is the arithmetic of the reference's modules AT those position ids (G9) and that cached == no-cache (G3 property).
 
 Each function cites the reference file:line it follows (paths relative to /root/reference).
 The arithmetic lives in third-party ``transformers==4.39.3`` (requirements.txt:3) GPT-NeoX; it is restated from the
@@ -33,12 +36,12 @@ KV = List[Tuple[Tensor, Tensor]]
 def td_position_table(policy: str, n_exp: int, block_length: int) -> List[int]:
     """RoPE positions of the adapted token-decoder sequence [BE_1..BE_E, t_0, .., t_{L-2}].
 
-    ``train``: HF default ``arange`` over the adapted sequence (no-cache forward; reference
+    ``train``: HF default ``arange`` over the adapted sequence (a direct forward without position_ids; reference
     model/token_decoder/base.py:461-502 builds inputs_embeds=[BE.., A, B, C]).
-    ``hf439_generate``: transformers 4.39.3 ``GPTNeoXForCausalLM.prepare_inputs_for_generation`` derives
-    position_ids from the *un-adapted* attention mask (cumsum-1) and the reference forwards it through **kwargs
-    (model/token_decoder/base.py:158,301-303 -> gpt_neo_x.py:59-71): the E prefix rows all get position 0
-    (broadcast), token t gets position t+1.  Unverifiable here (risk #1).
+    ``hf439_generate`` (what the reference's generate() computes, the default of ``OracleBlockTransformer.generate``):
+    transformers 4.39.3 ``GPTNeoXForCausalLM.prepare_inputs_for_generation`` derives position_ids from the *un-adapted*
+    attention mask (cumsum-1) and the reference forwards it through **kwargs (model/token_decoder/base.py:158,301-303 ->
+    gpt_neo_x.py:59-71): the E prefix rows all get position 0 (a [B,1] id broadcast over q = E rows), token t gets t+1.
     """
     n = n_exp + block_length - 1
     if policy == "train":
@@ -156,7 +159,7 @@ class OracleBlockTransformer:
                  expansion_ratio: int = 2, rotary_pct: float = 0.25, rope_base: float = 10000.0, eps: float = 1e-5,
                  eos_token_id: int = 0, pad_token_id: Optional[int] = None, gen_eos_token_id: Optional[int] = None,
                  gen_pad_token_id: Optional[int] = None, embedder_pad_token_id: Optional[int] = None,
-                 rope_policy: str = "train"):
+                 rope_policy: str = "hf439_generate"):
         self.sd = state_dict
         self.L, self.E = block_length, expansion_ratio
         self.bd = OracleDecoder(state_dict, "block_decoder.", bd_heads, rotary_pct, rope_base, eps)
@@ -173,7 +176,8 @@ class OracleBlockTransformer:
         self.gen_pad_token_id = gen_pad_token_id if gen_pad_token_id is not None else (
             gen_eos_token_id if gen_eos_token_id is not None else self.pad_token_id)
         self.embedder_pad_token_id = embedder_pad_token_id  # LookupConfig.pad_token_id (None, Q4)
-        self.td_pos = td_position_table(rope_policy, self.E, self.L)
+        self.rope_policy = rope_policy
+        self.td_pos = td_position_table(rope_policy, self.E, self.L)   # cached generation (token_decoder_generate)
 
     # ---- embedder -------------------------------------------------------------------------------------------
     def embed(self, ids: Tensor) -> Tensor:
@@ -204,15 +208,16 @@ class OracleBlockTransformer:
     def logits(self, h: Tensor) -> Tensor:
         return F.linear(h, self.sd["token_decoder.embed_out.weight"])
 
-    def token_decoder_teacher_forced(self, ctx: Tensor, tokens: Tensor,
-                                     token_mask: Optional[Tensor] = None) -> Tensor:
+    def token_decoder_teacher_forced(self, ctx: Tensor, tokens: Tensor, token_mask: Optional[Tensor] = None,
+                                     positions=None) -> Tensor:
         """BaseTokenDecoder.forward(past=None) with input_ids=[BOS, tokens...] (base.py:141-397, prefix adaptation
         :461-502, redundant-prefix drop :321-329): returns logits [B, 1+len(tokens), V] (one per input position)."""
         B = ctx.shape[0]
         emb_in = self.sd["token_decoder.gpt_neox.embed_in.weight"]
         x = torch.cat([self.expand(ctx), emb_in[tokens]], dim=1)
         n = x.shape[1]
-        positions = torch.tensor(self.td_pos[:n]) if n <= len(self.td_pos) else torch.arange(n)
+        # a direct forward carries no position_ids: HF default arange (the reference's training / scoring path)
+        positions = torch.arange(n) if positions is None else torch.as_tensor(positions)[:n]
         key_mask = None
         if token_mask is not None:
             key_mask = torch.cat([torch.ones(B, self.E, dtype=token_mask.dtype), token_mask], dim=1)

@@ -11,7 +11,10 @@ paths and writes inputs + expected outputs as small ``tests/golden/<config>.npz`
 Vectors: G1 embedder, G2 block-decoder prefill hidden states (with and without a key mask),
 G4 expansion, G5 token-decoder teacher-forced logits, G6 greedy token ids assembled from the reference classes
 through the no-cache path (incl. P % L != 0 and D % L != 0), G7 BlockTransformer.forward logits, G8
-preprocess/revert integer cases.  (G3, incremental == prefill row, is a property test in tests/, not a fixture.)
+preprocess/revert integer cases, G9 = G6 with the token decoder evaluated at the position ids of the reference's cached
+generation (prefix rows at 0, token t at t+1: what transformers 4.39.3 ``prepare_inputs_for_generation`` feeds through the
+reference's **kwargs; passed here explicitly as ``position_ids=`` to the reference's own ``GPTNeoXTokenDecoder.forward``).
+(G3, incremental == prefill row, is a property test in tests/, not a fixture.)
 """
 from __future__ import annotations
 
@@ -28,7 +31,7 @@ sys.path.insert(0, ROOT)
 REF = "/root/reference"
 
 from block_transformer_amd.config import named_dims  # noqa: E402
-from oracle.cpu_ref import oracle_from_dims, random_state_dict  # noqa: E402
+from oracle.cpu_ref import oracle_from_dims, random_state_dict, td_position_table  # noqa: E402
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
@@ -86,7 +89,7 @@ def build_reference_model(dims, sd):
 
 
 @torch.no_grad()
-def reference_greedy(model, dims, input_ids, attention_mask, max_length):
+def reference_greedy(model, dims, input_ids, attention_mask, max_length, td_positions=None):
     """Greedy tokens from the reference's own classes through the NO-CACHE path:
     loop {embed all blocks -> block decoder -> last hidden -> L x (token decoder on [BOS, tokens...], argmax)}.
     End test and partial-final-block handling follow model/block_transformer.py:387-388,415."""
@@ -104,7 +107,12 @@ def reference_greedy(model, dims, input_ids, attention_mask, max_length):
         count = min(max_length - (nb * L - pad), L)
         toks = torch.zeros(B, 1, dtype=torch.long)  # BOS/EOS placeholder = 0
         for _ in range(count):
-            lg = model.token_decoder(input_ids=toks, block_embeddings=ctx, use_cache=False, return_dict=True).logits
+            kw = {}
+            if td_positions is not None:   # adapted length = E prefix rows + (len(toks) - 1) tokens
+                n_adapted = dims.E + toks.shape[1] - 1
+                kw["position_ids"] = torch.tensor(td_positions[:n_adapted])[None, :]
+            lg = model.token_decoder(input_ids=toks, block_embeddings=ctx, use_cache=False, return_dict=True,
+                                     **kw).logits
             toks = torch.cat([toks, lg[:, -1].argmax(-1, keepdim=True)], dim=1)
         new = torch.full((B, L), model.token_decoder.config.pad_token_id, dtype=torch.long)
         new[:, :count] = toks[:, 1:]
@@ -154,6 +162,12 @@ def make_fixture(name, seed, store_weights, B=2, nb=5, gen_cases=((10, 23), (8, 
     tin = torch.cat([torch.zeros(B, 1, dtype=torch.long), toks], dim=1)
     lg = model.token_decoder(input_ids=tin, block_embeddings=ctx, use_cache=False, return_dict=True).logits
     fx["g5_tokens"], fx["g5_logits"] = toks.numpy(), lg.numpy()
+    # G9 logits: the same teacher-forced call at the cached-generation position ids (prefix rows 0, token t at t+1)
+    pos9 = torch.tensor(td_position_table("hf439_generate", dims.E, L))[None, :]
+    lg9 = model.token_decoder(input_ids=tin, block_embeddings=ctx, use_cache=False, return_dict=True,
+                              position_ids=pos9).logits
+    fx["g9_logits"] = lg9.numpy()
+    assert (lg9 - lg).abs().max() > 1e-4, "position ids did not reach the reference's attention layers"
 
     # G7 BlockTransformer.forward logits [B, nb-1, L, V]
     out = model(input_ids=ids, attention_mask=mask, block_attention_mask=bm)
@@ -165,6 +179,10 @@ def make_fixture(name, seed, store_weights, B=2, nb=5, gen_cases=((10, 23), (8, 
         toks_out, ctx_trace = reference_greedy(model, dims, pid, None, max_length)
         fx[f"g6_{ci}_prompt"], fx[f"g6_{ci}_max_length"] = pid.numpy(), np.int64(max_length)
         fx[f"g6_{ci}_tokens"], fx[f"g6_{ci}_ctx"] = toks_out.numpy(), ctx_trace.numpy()
+        # G9: same prompts, token decoder at the cached-generation position ids
+        toks9, ctx9 = reference_greedy(model, dims, pid, None, max_length,
+                                       td_positions=td_position_table("hf439_generate", dims.E, L))
+        fx[f"g9_{ci}_tokens"], fx[f"g9_{ci}_ctx"] = toks9.numpy(), ctx9.numpy()
 
     # G8 preprocess / revert integer cases
     for ci, P in enumerate((L * 2, L * 2 + 1, L * 3 - 1)):
@@ -178,7 +196,7 @@ def make_fixture(name, seed, store_weights, B=2, nb=5, gen_cases=((10, 23), (8, 
 
     # slim down big-vocab logits: keep strided slices + argmax
     if V > 1024:
-        for k in ("g5_logits", "g7_logits"):
+        for k in ("g5_logits", "g7_logits", "g9_logits"):
             full = fx.pop(k)
             fx[k + "_argmax"] = full.argmax(-1)
             fx[k + "_slice"] = full[..., ::97].copy()
@@ -190,7 +208,8 @@ def make_fixture(name, seed, store_weights, B=2, nb=5, gen_cases=((10, 23), (8, 
 
 def check_oracle(dims, sd, fx, tol=2e-5):
     """The restatement must reproduce every vector (fp32, tolerance 2e-5 abs on O(1) activations/logits)."""
-    o = oracle_from_dims(dims, sd)
+    o = oracle_from_dims(dims, sd, rope_policy="train")
+    o9 = oracle_from_dims(dims, sd, rope_policy="hf439_generate")
     t = lambda k: torch.from_numpy(np.asarray(fx[k]))
     B, nb, L = t("g1_ids").shape
     H = dims.bd.hidden
@@ -207,6 +226,13 @@ def check_oracle(dims, sd, fx, tol=2e-5):
     errs["g4"] = (o.expand(t("g4_ctx")) - t("g4_expanded")).abs().max().item()
     lg = o.token_decoder_teacher_forced(t("g4_ctx"), t("g5_tokens"))
     f7 = o.forward_logits(t("g1_ids"), torch.ones_like(t("g1_ids")), torch.ones(B, nb, dtype=torch.long))
+    lg9 = o.token_decoder_teacher_forced(t("g4_ctx"), t("g5_tokens"),
+                                         positions=td_position_table("hf439_generate", dims.E, L))
+    if "g9_logits" in fx:
+        errs["g9_logits"] = (lg9 - t("g9_logits")).abs().max().item()
+    else:
+        errs["g9_logits"] = (lg9[..., ::97] - t("g9_logits_slice")).abs().max().item()
+        assert (lg9.argmax(-1) == t("g9_logits_argmax")).all()
     if "g5_logits" in fx:
         errs["g5"] = (lg - t("g5_logits")).abs().max().item()
         errs["g7"] = (f7 - t("g7_logits")).abs().max().item()
@@ -220,6 +246,9 @@ def check_oracle(dims, sd, fx, tol=2e-5):
         assert out.shape == t(f"g6_{ci}_tokens").shape, (out.shape, t(f"g6_{ci}_tokens").shape)
         assert (out == t(f"g6_{ci}_tokens")).all(), f"G6 case {ci}: greedy tokens differ"
         errs[f"g6_{ci}_ctx"] = (torch.stack(trace["ctx"], 0) - t(f"g6_{ci}_ctx")).abs().max().item()
+        out9, trace9 = o9.generate(t(f"g6_{ci}_prompt"), max_length=int(fx[f"g6_{ci}_max_length"]), return_trace=True)
+        assert (out9 == t(f"g9_{ci}_tokens")).all(), f"G9 case {ci}: greedy tokens differ (cached-generation positions)"
+        errs[f"g9_{ci}_ctx"] = (torch.stack(trace9["ctx"], 0) - t(f"g9_{ci}_ctx")).abs().max().item()
         ci += 1
     ci = 0
     while f"g8_{ci}_in" in fx:

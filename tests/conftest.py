@@ -38,6 +38,18 @@ def golden():
     return get
 
 
+@pytest.fixture
+def dbg_lib():
+    """Route the ops through libbt_hip_dbg.so (same kernels + bt_debug_* hooks) for one test; the product library
+    libbt_hip.so is what every other test — and the product — runs."""
+    from block_transformer_amd import _lib
+    prev = _lib.use_debug_library(True)
+    try:
+        yield _lib.lib()
+    finally:
+        _lib.use_debug_library(prev)
+
+
 def t(fx, key):
     return torch.from_numpy(np.asarray(fx[key]))
 

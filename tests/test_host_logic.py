@@ -56,9 +56,9 @@ def test_overrides():
 def test_library_exports_every_declared_symbol():
     """The C-ABI library loads and exports exactly what include/bt_hip.h declares (no compute without a GPU)."""
     lib = _lib.lib()
-    assert lib.bt_version() == 100
+    assert lib.bt_version() == 200
     header = open(os.path.join(ROOT, "include", "bt_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|int64_t|const char\*)\s+(bt_\w+)\(", header, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int32_t|int64_t|const char\*)\s+(bt_\w+)\(", header, flags=re.M))
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name), name
@@ -67,10 +67,62 @@ def test_library_exports_every_declared_symbol():
     assert rc == -1 and b"dtype" in lib.bt_last_error()
     rc = lib.bt_attention(1, 0, 1, 1, 1, 48, 1, 48, 1, 1, 8, None, 0, None, 0, 1, 48, 1, None, 0, None)
     assert rc == -1 and b"head_dim" in lib.bt_last_error()
+    rc = lib.bt_block_step_enqueue(None, 4, 1, None)
+    assert rc == -1 and b"descriptor" in lib.bt_last_error()
+    rc = lib.bt_topk_sample(1, 1, 50304, 1, 50304, 1.0, 2000, 0, None, 1, 1, None)   # top_k beyond the candidate buffer
+    assert rc == -2 and b"top_k" in lib.bt_last_error()
+    # split-N rule shared by the library and the engine's workspace sizing
+    assert lib.bt_attention_split_count(128, 544, 1) == 1 and lib.bt_attention_split_count(128, 544, 4) == 4
+    assert lib.bt_attention_split_count(128, 40000, 1) == 3   # 40000 keys do not fit one 64 KiB score row
+
+
+def test_product_library_has_no_debug_hooks():
+    """libbt_hip.so (the product) exports no bt_debug_* setter and contains none of the A/B or timing-ablation kernels; the
+    hooks live in the separate test build libbt_hip_dbg.so (-DBT_DEBUG_HOOKS)."""
+    import subprocess
+    prod = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "bt_linear" in prod and "bt_debug" not in prod
+    blob = open(_lib.LIB_PATH, "rb").read()
+    for kern in (b"gemm_bf16_mfma256_kernelILb", b"flash_prefill_kernelILi", b"tr_probe_kernel", b"Mma32"):
+        assert kern not in blob, kern
+    dbg = subprocess.run(["nm", "-D", "--defined-only", _lib.DEBUG_LIB_PATH], capture_output=True, text=True).stdout
+    for name in _lib._DEBUG_SIGS:
+        assert name in dbg, name
+    prev = _lib.use_debug_library(True)
+    try:
+        assert _lib.lib().bt_version() == 200 and hasattr(_lib.lib(), "bt_debug_gemm_variant")
+    finally:
+        _lib.use_debug_library(prev)
+    assert not hasattr(_lib.lib(), "bt_debug_gemm_variant_missing")
+
+
+def test_engine_desc_layout_matches_header(tmp_path):
+    """ctypes bt_engine_desc / bt_attn_args == the C structs of include/bt_hip.h (size and every field offset), checked
+    against a probe compiled from the header with gcc."""
+    import ctypes
+    import subprocess
+    structs = {"bt_engine_desc": _lib.bt_engine_desc, "bt_attn_args": _lib.bt_attn_args,
+               "bt_decoder_dims": _lib.bt_decoder_dims, "bt_layer_weights": _lib.bt_layer_weights,
+               "bt_decoder_weights": _lib.bt_decoder_weights}
+    lines = ['#include "bt_hip.h"', "#include <stdio.h>", "#include <stddef.h>", "int main(void) {"]
+    for name, cls in structs.items():
+        lines.append(f'printf("{name} %zu\\n", sizeof({name}));')
+        for f, _ in cls._fields_:
+            lines.append(f'printf("{name}.{f} %zu\\n", offsetof({name}, {f}));')
+    lines += ["return 0; }"]
+    src = tmp_path / "probe.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for name, cls in structs.items():
+        assert int(out[name]) == ctypes.sizeof(cls), name
+        for f, _ in cls._fields_:
+            assert int(out[f"{name}.{f}"]) == getattr(cls, f).offset, f"{name}.{f}"
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
-    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "_handles", {})
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(ImportError, match="no fallback"):
         _lib.lib()

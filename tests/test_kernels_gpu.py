@@ -54,7 +54,7 @@ def test_linear(M, N, K, dtype, variant):
     assert rel_err(out, ref) <= tol, (rel_err(out, ref), tol)
 
 
-def test_linear_mfma_equals_generic_bf16():
+def test_linear_mfma_equals_generic_bf16(dbg_lib):
     """A/B of the MFMA kernel against the simple tiled kernel on identical bf16 inputs (same fp32 accumulate)."""
     x = rnd(200, 512, seed=5).bfloat16().to(DEV)
     w = rnd(384, 512, seed=6, scale=0.05).bfloat16().to(DEV)
@@ -74,7 +74,7 @@ def test_linear_mfma_equals_generic_bf16():
 @pytest.mark.parametrize("M,N,K", [(256, 256, 64), (300, 520, 128), (512, 768, 2048), (1000, 260, 448), (64, 1024, 192)])
 @pytest.mark.parametrize("variant", ["plain", "bias_gelu", "bias_res"])
 @pytest.mark.parametrize("kernel", [2, 3, 9, 10])
-def test_linear_256_tile_kernel(M, N, K, variant, kernel):
+def test_linear_256_tile_kernel(M, N, K, variant, kernel, dbg_lib):
     """The deep-pipelined 256x256 kernel (forced) against fp64, incl. M/N tails and every pipeline length nk = K/64
     (nk = 1..7 exercise the prologue/epilogue wait counts of the half-tile ring)."""
     x = rnd(M, K, seed=1).bfloat16()
@@ -99,7 +99,7 @@ def test_linear_256_tile_kernel(M, N, K, variant, kernel):
 
 
 @pytest.mark.parametrize("kernel", [0, 9, 12, 14])
-def test_gelu_epilogue_accuracy(kernel):
+def test_gelu_epilogue_accuracy(kernel, dbg_lib):
     """The bf16 epilogues' GELU (scaled-normal-tail polynomial, not erff) through an identity GEMM: within one bf16 ulp of
     the exact erf GELU everywhere -- including the negative tail, where 1 + erf cancels -- and bit-equal to the correctly
     rounded value for almost every input."""
@@ -128,7 +128,7 @@ def test_gelu_epilogue_accuracy(kernel):
 @pytest.mark.parametrize("variant", ["plain", "bias", "bias_gelu", "bias_res", "res"])
 @pytest.mark.parametrize("max_wg", [0, 1, 4, 5])
 @pytest.mark.parametrize("kernel", [12, 14])
-def test_linear_persistent_kernel(M, N, K, variant, max_wg, kernel):
+def test_linear_persistent_kernel(M, N, K, variant, max_wg, kernel, dbg_lib):
     """The persistent 256x256 kernel (forced; grid capped so workgroups walk 1..many tiles incl. a partial last round)
     against fp64: bias folded into the accumulator init, per-wave LDS-patch epilogue, residual joined in fp32, M/N edge
     tiles (which take the conservative store-count waits).  kernel 12 = production (16x16x32 MFMA fragments), 14 = 32x32x16 blocks."""
@@ -160,7 +160,7 @@ def test_linear_persistent_kernel(M, N, K, variant, max_wg, kernel):
 
 
 @pytest.mark.parametrize("kernel", [12, 14])
-def test_linear_persistent_inplace_residual_and_strides(kernel):
+def test_linear_persistent_inplace_residual_and_strides(kernel, dbg_lib):
     """hidden += x @ W^T through the persistent kernels, in place (res == out), row strides > row length."""
     M, N, K = 1024, 512, 256
     x = rnd(M, K + 64, seed=1).bfloat16().to(DEV)[:, :K]
@@ -181,7 +181,7 @@ def test_linear_persistent_inplace_residual_and_strides(kernel):
     assert torch.equal(hid[:, N:], pad_before), "columns beyond N must not be written"
 
 
-def test_linear_256_tile_kernel_repeatable():
+def test_linear_256_tile_kernel_repeatable(dbg_lib):
     """Race screen: the ring schedule must give bit-identical results run to run (and equal to the 128x128 kernel)."""
     x = rnd(1024, 1024, seed=5).bfloat16().to(DEV)
     w = rnd(1536, 1024, seed=6, scale=0.03).bfloat16().to(DEV)
@@ -233,7 +233,7 @@ def test_linear_splitk_skinny(M, N, K, variant):
 @pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 8])
 @pytest.mark.parametrize("N,K", [(2048, 2048), (6144, 2048), (2048, 8192), (50, 512), (4099, 2560), (50304, 2048)])
 @pytest.mark.parametrize("variant", ["plain", "bias_gelu", "bias_res"])
-def test_linear_gemv_few_rows(M, N, K, variant):
+def test_linear_gemv_few_rows(M, N, K, variant, dbg_lib):
     """Few rows (M <= 4: the weight-streaming GEMV kernel, K % 512 == 0; 5..8: split-K / tile kernels) == fp64 reference, element-wise within bf16 rounding,
     == the MFMA path (variant 22 disables the GEMV), with strided x / out / residual rows and N not a multiple of the
     rows-per-workgroup."""
@@ -492,7 +492,7 @@ def test_rope_kv_append(dtype, d, rot, use_dev_pos, use_table):
 @pytest.mark.parametrize("use_dev_pos,use_table", [(False, False), (True, False), (False, True)])
 @pytest.mark.parametrize("fused,kernel,max_wg", [(True, 0, 0), (False, 0, 0), (True, 9, 0), (True, 12, 0), (True, 12, 2),
                                                  (True, 14, 2)])
-def test_qkv_rope_append_fused_epilogue(B, q, pos0, heads, use_dev_pos, use_table, fused, kernel, max_wg):
+def test_qkv_rope_append_fused_epilogue(B, q, pos0, heads, use_dev_pos, use_table, fused, kernel, max_wg, dbg_lib):
     """QKV projection with RoPE + KV-cache append in the GEMM epilogue (d = 128, rot = 32) == fp64 reference, and ==
     the unfused sequence bt_linear + bt_rope_kv_append within bf16 rounding."""
     run_qkv_fused(B, q, pos0, heads, 128, use_dev_pos, use_table, fused, kernel, max_wg)
@@ -500,7 +500,7 @@ def test_qkv_rope_append_fused_epilogue(B, q, pos0, heads, use_dev_pos, use_tabl
 
 @pytest.mark.parametrize("d,heads", [(32, 8), (64, 4), (96, 4)])
 @pytest.mark.parametrize("kernel,max_wg", [(0, 0), (9, 0), (12, 0), (12, 1), (14, 1)])
-def test_qkv_rope_append_fused_head_dims(d, heads, kernel, max_wg):
+def test_qkv_rope_append_fused_head_dims(d, heads, kernel, max_wg, dbg_lib):
     """Other head sizes through every MFMA kernel's fused epilogue (d = 32: two rotated column groups per 64-column wave
     slab and a divergent q / cache scatter; d = 96: heads straddle the waves' 64-column slabs)."""
     run_qkv_fused(5, 61, 2, heads, d, True, True, True, kernel, max_wg)
@@ -510,7 +510,7 @@ def test_qkv_rope_append_fused_head_dims(d, heads, kernel, max_wg):
 @pytest.mark.parametrize("use_dev_pos,use_table", [(False, False), (True, True)])
 @pytest.mark.parametrize("max_wg", [0, 2])
 @pytest.mark.parametrize("kernel", [12, 14])
-def test_qkv_rope_append_fused_persistent_full_tiles(B, q, pos0, heads, d, use_dev_pos, use_table, max_wg, kernel):
+def test_qkv_rope_append_fused_persistent_full_tiles(B, q, pos0, heads, d, use_dev_pos, use_table, max_wg, kernel, dbg_lib):
     """Fused RoPE + KV append epilogue of the persistent kernels on full 256 x 256 tiles (the fast store-count waits)."""
     run_qkv_fused(B, q, pos0, heads, d, use_dev_pos, use_table, True, kernel, max_wg)
 
@@ -625,7 +625,7 @@ def test_attention_rows_mask(dtype):
 
 
 @pytest.fixture(params=[0, 2, 1], ids=["flash_v2_4w2s", "flash_v2_8w4s", "flash_v1"])
-def flash_variant(request):
+def flash_variant(request, dbg_lib):
     """0 = LDS-DMA + ds_read_b64_tr_b16 kernel, 4 waves / 128 query rows / double buffer (default), 2 = the same kernel
     with 8 waves / 256 query rows / 4-deep K/V ring (d >= 64), 1 = first-generation kernel (kept for A/B)."""
     lib().bt_debug_flash_variant(request.param)

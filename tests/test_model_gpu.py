@@ -91,6 +91,17 @@ def test_expansion_g4_and_token_decoder_g5(gpu_model, name):
     else:
         assert maxabs(lg[..., ::97], t(fx, "g5_logits_slice")) <= TOL
         assert torch.equal(lg.argmax(-1), t(fx, "g5_logits_argmax"))
+    # G9: the same call with the position ids of the reference's cached generation routed through **kwargs
+    from block_transformer_amd.engine import td_position_table
+    pos9 = torch.tensor(td_position_table("hf439_generate", dims.E, dims.L))[None, :]
+    lg9 = model.token_decoder(input_ids=tin, block_embeddings=ctx[:, None, :], return_dict=True,
+                              position_ids=pos9).logits.cpu()
+    if "g9_logits" in fx:
+        assert maxabs(lg9, t(fx, "g9_logits")) <= TIGHT
+        assert maxabs(lg9, t(fx, "g5_logits")) > 2e-4     # the two policies are distinguishable at this tolerance
+    else:
+        assert maxabs(lg9[..., ::97], t(fx, "g9_logits_slice")) <= TOL
+        assert torch.equal(lg9.argmax(-1), t(fx, "g9_logits_argmax"))
 
 
 def test_token_decoder_cached_steps_equal_teacher_forced(gpu_model):
@@ -132,29 +143,36 @@ def test_token_decoder_generate(gpu_model):
 
 @pytest.mark.parametrize("name", GOLDEN_CONFIGS)
 @pytest.mark.parametrize("graphs", [True, False])
-def test_generate_greedy_matches_reference_g6(gpu_model, name, graphs):
-    """End-to-end greedy token ids == the reference's own classes (incl. P % L != 0 and D % L != 0)."""
+@pytest.mark.parametrize("policy,key", [("hf439_generate", "g9"), ("train", "g6")])
+def test_generate_greedy_matches_reference_g6_g9(gpu_model, name, graphs, policy, key):
+    """End-to-end greedy token ids == the reference's own classes (incl. P % L != 0 and D % L != 0): G9 = the default
+    policy (token decoder at the position ids of the reference's cached generate()), G6 = plain arange positions."""
     model, dims, sd, fx = gpu_model(name)
+    assert model.token_decoder.rope_policy == "hf439_generate"        # the default mirrors the reference's generate()
     model.use_graphs = graphs
-    ci = 0
-    while f"g6_{ci}_prompt" in fx:
-        prompt = t(fx, f"g6_{ci}_prompt").to(DEV)
-        ml = int(fx[f"g6_{ci}_max_length"])
-        out = model.generate(prompt, max_length=ml)
-        want = t(fx, f"g6_{ci}_tokens")
-        assert out.shape == want.shape, (out.shape, want.shape)
-        assert torch.equal(out.cpu(), want), f"case {ci}"
-        # context embeddings of the run (last block step) against the reference trace
-        assert maxabs(model._engine.ctx, t(fx, f"g6_{ci}_ctx")[-1]) <= TIGHT
-        ci += 1
-    model.use_graphs = True
+    model.token_decoder.rope_policy = policy
+    try:
+        ci = 0
+        while f"g6_{ci}_prompt" in fx:
+            prompt = t(fx, f"g6_{ci}_prompt").to(DEV)
+            ml = int(fx[f"g6_{ci}_max_length"])
+            out = model.generate(prompt, max_length=ml)
+            want = t(fx, f"{key}_{ci}_tokens")
+            assert out.shape == want.shape, (out.shape, want.shape)
+            assert torch.equal(out.cpu(), want), f"case {ci}"
+            # context embeddings of the run (last block step) against the reference trace
+            assert maxabs(model._engine.ctx, t(fx, f"{key}_{ci}_ctx")[-1]) <= TIGHT
+            ci += 1
+    finally:
+        model.use_graphs = True
+        model.token_decoder.rope_policy = "hf439_generate"
 
 
 def test_generate_block_format_and_shapes(gpu_model):
     model, dims, sd, fx = gpu_model("micro")
     prompt = t(fx, "g6_1_prompt")            # P = 8 = 2 blocks
     B = prompt.shape[0]
-    want = t(fx, "g6_1_tokens")
+    want = t(fx, "g9_1_tokens")
     ids = prompt.view(B, 2, 4).to(DEV)
     out = model.generate(ids, attention_mask=torch.ones_like(ids),
                          block_attention_mask=torch.ones(B, 2, dtype=torch.long, device=DEV), max_length=16)
@@ -236,19 +254,19 @@ def test_generate_eos_handling(gpu_model, cfg_pad, gen_pad):
             model.use_graphs = True
 
 
-def test_generate_rope_policy_hf439(gpu_model):
-    """The optional 4.39.3 cached-generation position policy (restatement-only, unpinned): engine == oracle."""
+def test_generate_rope_policy_train_vs_oracle(gpu_model):
+    """The non-default arange policy (config knob ``token_decoder.rope_policy=train``): engine == oracle."""
     model, dims, sd, fx = gpu_model("micro")
     prompt = t(fx, "g6_1_prompt")
-    o = oracle_from_dims(dims, sd, rope_policy="hf439_generate")
+    o = oracle_from_dims(dims, sd, rope_policy="train")
     want = o.generate(prompt, max_length=16)
-    model.token_decoder.rope_policy = "hf439_generate"
+    model.token_decoder.rope_policy = "train"
     try:
         got = model.generate(prompt.to(DEV), max_length=16)
     finally:
-        model.token_decoder.rope_policy = "train"
+        model.token_decoder.rope_policy = "hf439_generate"
     assert torch.equal(got.cpu(), want)
-    assert not torch.equal(want, t(fx, "g6_1_tokens")) or True   # policies may or may not flip a greedy token
+    assert torch.equal(want, t(fx, "g6_1_tokens"))
 
 
 def test_generate_streamer_protocol(gpu_model):
@@ -267,7 +285,7 @@ def test_generate_streamer_protocol(gpu_model):
     rec = Rec()
     prompt = t(fx, "g6_1_prompt").to(DEV)
     out = model.generate(prompt, max_length=16, streamer=rec)
-    assert torch.equal(out.cpu(), t(fx, "g6_1_tokens"))
+    assert torch.equal(out.cpu(), t(fx, "g9_1_tokens"))
     kinds = [e[0] for e in rec.events]
     assert kinds == (["put"] * 5 + ["end"]) * 2           # per block: placeholder + L tokens, then end()
     B = prompt.shape[0]
@@ -414,7 +432,7 @@ def test_checkpoint_roundtrip_safetensors(gpu_model, tmp_path):
     assert missing == ["block_decoder.gpt_neox.embed_in.weight"] and not unexpected
     fresh.token_decoder.generation_config.eos_token_id = None
     out = fresh.generate(t(fx, "g6_1_prompt").to(DEV), max_length=16)
-    assert torch.equal(out.cpu(), t(fx, "g6_1_tokens"))
+    assert torch.equal(out.cpu(), t(fx, "g9_1_tokens"))
 
 
 @pytest.mark.parametrize("name", ["block_main_b4_5", "block_main_b4_19", "block_main_b4_85", "block_main_b4_300",
@@ -481,7 +499,7 @@ def test_full_size_1p2b_generate_properties():
 
 
 @pytest.mark.parametrize("B", [1, 3, 4])
-def test_small_batch_fused_stack_matches_unfused(B):
+def test_small_batch_fused_stack_matches_unfused(B, dbg_lib):
     """1..4 sequences: the decoder stacks run LayerNorm / RoPE / KV append inside the weight-streaming GEMVs (5 launches
     per layer).  Same weights, same prompt: the fused and the unfused (bt_debug_no_few_rows_fusion) launch sequences
     produce the same greedy tokens up to rare bf16 near-ties, and the same context embedding within bf16 rounding."""
@@ -514,7 +532,7 @@ def test_small_batch_fused_stack_matches_unfused(B):
 
 
 @pytest.mark.parametrize("B", [6, 16])
-def test_mid_batch_streamer_stack_matches_unfused(B):
+def test_mid_batch_streamer_stack_matches_unfused(B, dbg_lib):
     """5..16 rows: the stacks run on the MFMA weight streamer with LayerNorm / RoPE / KV append / the second residual
     projection folded in.  Same weights and prompt through the unfused launch sequence (bt_debug_few_rows_max(4) +
     bt_debug_skinny_rows(4)): same greedy tokens up to rare bf16 near-ties."""

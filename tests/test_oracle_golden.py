@@ -48,7 +48,15 @@ def test_oracle_matches_reference_vectors(golden, name):
     d2[B - 1, 0] = 0  # that query sees no key at all: unspecified in the reference (finfo.min arithmetic)
     assert d2.max() <= TOL
     assert (o.expand(t(fx, "g4_ctx")) - t(fx, "g4_expanded")).abs().max() <= TOL      # G4
-    lg = o.token_decoder_teacher_forced(t(fx, "g4_ctx"), t(fx, "g5_tokens"))           # G5
+    lg = o.token_decoder_teacher_forced(t(fx, "g4_ctx"), t(fx, "g5_tokens"))           # G5 (a direct forward: arange)
+    lg9 = o.token_decoder_teacher_forced(t(fx, "g4_ctx"), t(fx, "g5_tokens"),          # G9 (cached-generation position ids)
+                                         positions=td_position_table("hf439_generate", dims.E, dims.L))
+    if "g9_logits" in fx:
+        assert (lg9 - t(fx, "g9_logits")).abs().max() <= TOL
+        assert (lg9 - t(fx, "g5_logits")).abs().max() > 10 * TOL, "G9 must discriminate the two position policies"
+    else:
+        assert (lg9[..., ::97] - t(fx, "g9_logits_slice")).abs().max() <= TOL
+        assert torch.equal(lg9.argmax(-1), t(fx, "g9_logits_argmax"))
     f7 = o.forward_logits(t(fx, "g1_ids"), torch.ones_like(t(fx, "g1_ids")), ones)     # G7
     if "g5_logits" in fx:
         assert (lg - t(fx, "g5_logits")).abs().max() <= TOL
@@ -61,16 +69,18 @@ def test_oracle_matches_reference_vectors(golden, name):
 
 
 @pytest.mark.parametrize("name", GOLDEN_CONFIGS)
-def test_oracle_greedy_tokens_match_reference(golden, name):                           # G6
+def test_oracle_greedy_tokens_match_reference(golden, name):                           # G6 (arange) and G9 (generate())
     dims, sd, fx = golden(name)
-    o = oracle_from_dims(dims, sd)
-    ci = 0
-    while f"g6_{ci}_prompt" in fx:
-        out, trace = o.generate(t(fx, f"g6_{ci}_prompt"), max_length=int(fx[f"g6_{ci}_max_length"]), return_trace=True)
-        assert torch.equal(out, t(fx, f"g6_{ci}_tokens")), f"case {ci}"
-        assert (torch.stack(trace["ctx"], 0) - t(fx, f"g6_{ci}_ctx")).abs().max() <= TOL
-        ci += 1
-    assert ci >= 1
+    assert oracle_from_dims(dims, sd).rope_policy == "hf439_generate", "the oracle's generate() mirrors the reference's"
+    for policy, key in (("train", "g6"), ("hf439_generate", "g9")):
+        o = oracle_from_dims(dims, sd, rope_policy=policy)
+        ci = 0
+        while f"g6_{ci}_prompt" in fx:
+            out, trace = o.generate(t(fx, f"g6_{ci}_prompt"), max_length=int(fx[f"g6_{ci}_max_length"]), return_trace=True)
+            assert torch.equal(out, t(fx, f"{key}_{ci}_tokens")), f"{key} case {ci}"
+            assert (torch.stack(trace["ctx"], 0) - t(fx, f"{key}_{ci}_ctx")).abs().max() <= TOL
+            ci += 1
+        assert ci >= 1
 
 
 @pytest.mark.parametrize("name", GOLDEN_CONFIGS)

@@ -8,7 +8,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402,F401  (libbt_hip must load after torch)
+from block_transformer_amd import _lib  # noqa: E402
 from block_transformer_amd._lib import lib  # noqa: E402
+
+_lib.use_debug_library(True)   # the bt_debug_* knobs exist only in libbt_hip_dbg.so
 
 sep = sys.argv.index("--") if "--" in sys.argv else len(sys.argv)
 for kv in sys.argv[1:sep]:

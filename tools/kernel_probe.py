@@ -21,6 +21,12 @@ sys.path.insert(0, ROOT)
 from block_transformer_amd import _lib, ops  # noqa: E402
 from block_transformer_amd._lib import check, current_stream, lib, ptr  # noqa: E402
 
+# the A/B and ablation variants (bt_debug_*) exist only in the debug build; --product times libbt_hip.so itself
+if "--product" in sys.argv:
+    sys.argv.remove("--product")
+else:
+    _lib.use_debug_library(True)
+
 DEV = "cuda"
 
 

@@ -3,7 +3,9 @@
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from block_transformer_amd import _lib
 from block_transformer_amd._lib import check, current_stream, lib, ptr
+_lib.use_debug_library(True)   # bt_debug_tr_probe exists only in libbt_hip_dbg.so
 
 def run(addr):
     src = torch.arange(4096, dtype=torch.int16, device="cuda")
