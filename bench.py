@@ -5,6 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+``--gpus N`` without a torchrun environment re-execs itself under ``torch.distributed.run`` with N ranks (one per GPU, RCCL):
+the printed line always carries the number of ranks that actually ran (``n_gpus`` == ``rccl_ranks`` == N) or the run fails.
+
 One *step* = one full ``BlockTransformer.generate`` over one batch of synthetic prompts, timed the way the reference's
 ``measure_generation_time.py:131-161`` times it: prefill + decode, random ids, random-init weights of the named
 architecture, EOS disabled, greedy.  Workload at N=1 (BASELINE.json configs[1]): block_main_b4_1.2b, bf16, prefill 2048 /
@@ -58,20 +61,48 @@ def algorithmic_counts(dims, B: int, P: int, D: int, itemsize: int = 2):
     def stack_flops(d, rows):
         return 2 * rows * d.layers * (3 * d.hidden * d.hidden + d.hidden * d.hidden + 2 * d.hidden * d.inter)
 
+    def stack_flops_tail(d, rows, seqs):
+        """What bt_decoder_forward EXECUTES when the caller consumes only the last row of each sequence (prefill -> context
+        embedding, token-decoder step 0): the last layer runs QKV on every row (the KV cache needs it) but attention
+        output / dense / MLP on one row per sequence only (engine.hip, tail_only)."""
+        per_row_rest = d.hidden * d.hidden + 2 * d.hidden * d.inter
+        return stack_flops(d, rows) - 2 * (rows - seqs) * per_row_rest
+
+    few_rows = B * E <= 16                                          # small-batch fused path runs every layer on every row
     lin = stack_flops(bd, B * nb)                                   # prefill
+    lin_exec = stack_flops_tail(bd, B * nb, B) if nb > 1 else lin
     lin += n_roll * stack_flops(bd, B)                              # block-decoder steps
+    lin_exec += n_roll * stack_flops(bd, B)
     per_block_td = stack_flops(td, B * E) + (L - 1) * stack_flops(td, B)
-    per_block_td += 2 * B * (E * td.hidden) * bd.hidden             # expansion
-    per_block_td += L * 2 * B * V * td.hidden                       # logits
-    lin += n_tok_blocks * per_block_td
+    per_block_td_exec = (stack_flops(td, B * E) if few_rows or E == 1 else stack_flops_tail(td, B * E, B)) + \
+        (L - 1) * stack_flops(td, B)
+    extra = 2 * B * (E * td.hidden) * bd.hidden                     # expansion
+    extra += L * 2 * B * V * td.hidden                              # logits
+    lin += n_tok_blocks * (per_block_td + extra)
+    lin_exec += n_tok_blocks * (per_block_td_exec + extra)
+    # decode phase alone (SURVEY.md section 8d): everything after the prefill
+    lin_decode_exec = lin_exec - (stack_flops_tail(bd, B * nb, B) if nb > 1 else stack_flops(bd, B * nb))
     # row-wise attention bytes: global steps read n_k K rows + n_k V rows per (b, head); n_k = nb+1 .. nb+n_roll
     kv_row = bd.hidden * itemsize                                   # one position, all heads, K or V
     glob = sum(2 * B * bd.layers * kv_row * (nb + 1 + i) for i in range(n_roll))
     local_keys = sum(range(1, E + 1)) + sum(E + t for t in range(1, L))   # keys read per block per (b, head)
     loc = n_tok_blocks * 2 * B * td.layers * td.hidden * itemsize * local_keys
     flash = 4 * B * bd.layers * bd.hidden * (nb * (nb + 1) // 2)
-    return {"linear_flops": float(lin), "attn_rows_bytes": float(glob + loc), "attn_rows_global_bytes": float(glob),
-            "attn_flash_flops": float(flash), "n_tok_blocks": n_tok_blocks, "n_roll": n_roll, "nb": nb}
+    # section 8d decode-phase bytes: weights streamed once per forward + KV traffic + embedding rows
+    p_layer = lambda d: 12 * d.hidden * d.hidden + 13 * d.hidden                      # noqa: E731
+    w_bd, w_td = bd.layers * p_layer(bd) * itemsize, td.layers * p_layer(td) * itemsize
+    w_out = V * td.hidden * itemsize
+    w_exp = (E * td.hidden * bd.hidden + E * td.hidden) * itemsize
+    decode_bytes = n_roll * w_bd + n_tok_blocks * (L * w_td + L * w_out + w_exp) + glob + loc
+    decode_bytes += n_roll * B * kv_row * 2 * bd.layers                                # global append
+    decode_bytes += n_tok_blocks * B * td.hidden * itemsize * 2 * td.layers * (E + L - 1)   # local writes
+    decode_bytes += (n_roll * B * bd.hidden + n_tok_blocks * B * (L - 1) * td.hidden) * itemsize   # embedding rows
+    attn_decode_flops = 4 * B * bd.hidden * bd.layers * sum(nb + 1 + i for i in range(n_roll)) + \
+        4 * B * td.hidden * td.layers * local_keys * n_tok_blocks
+    return {"linear_flops": float(lin), "linear_flops_executed": float(lin_exec),
+            "attn_rows_bytes": float(glob + loc), "attn_rows_global_bytes": float(glob),
+            "attn_flash_flops": float(flash), "n_tok_blocks": n_tok_blocks, "n_roll": n_roll, "nb": nb,
+            "decode_bytes": float(decode_bytes), "decode_flops": float(lin_decode_exec + attn_decode_flops)}
 
 
 def build_model(dims, dtype_name: str, device, seed: int):
@@ -114,6 +145,47 @@ def cpu_baseline(model, dims, sample_prefill: int, sample_decode: int):
             "seconds": dt}, out, ids
 
 
+def cpu_plumbing_config0(cores: int):
+    """BASELINE.json configs[0]: block_main_b4 smallest config (block_main_b4_5), batch 1, prefill 16 / decode 16, eager
+    PyTorch on the host (no GPU) -- the oracle on seeded random-init weights; tokens/s of the whole generate()."""
+    from oracle.cpu_ref import oracle_from_dims, random_state_dict
+    d0 = named_dims("block_main_b4_5")
+    o = oracle_from_dims(d0, random_state_dict(d0, seed=15, bias_std=0.0))
+    ids = torch.randint(1, d0.vocab, (1, 16), generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        o.generate(ids, max_length=32)   # warm-up
+        t0 = time.perf_counter()
+        reps = 5
+        for _ in range(reps):
+            o.generate(ids, max_length=32)
+        dt = (time.perf_counter() - t0) / reps
+    return {"config": "block_main_b4_5 batch 1 prefill 16 / decode 16, fp32 eager PyTorch on the host", "value": 16 / dt,
+            "unit": "tokens/s", "cores": cores, "seconds_per_generate": dt}
+
+
+def auto_batch(dims, P: int, D: int, device, itemsize: int, cap: int = 4096) -> int:
+    """Per-GPU batch sized from free HBM the way the reference's harness auto-tunes it (fill the VRAM), without the
+    search: bytes per sequence = global KV (kv_pos x block positions) + local KV + activations / logits, 8 % head-room,
+    rounded down like measure_generation_time.round_batch, capped at ``cap`` (the prefill chunking and the decode GEMM
+    tile quantisation are tuned for <= 4096 rows)."""
+    from block_transformer_amd.measure_generation_time import round_batch
+    L, E = dims.L, dims.E
+    n_max = math.ceil(get_max_length(L, P, D) / L)
+    per_seq = dims.kv_bytes_per_position(itemsize) * n_max                              # global KV
+    per_seq += dims.td.layers * 2 * dims.td.hidden * itemsize * (E + L - 1)             # local KV
+    per_seq += dims.vocab * itemsize + n_max * L * 8 + (n_max + 1)                      # logits row, ids, mask
+    per_seq += (E + 1) * (5 * dims.td.hidden + dims.td.inter) * itemsize + 6 * dims.td.hidden * itemsize   # step workspaces
+    free, _total = torch.cuda.mem_get_info(device)
+    fixed = 36 << 30                                                                   # prefill chunk workspace + slack
+    fit = int((free * 0.92 - fixed) // per_seq)
+    b = max(1, min(cap, fit))
+    r = round_batch(b)
+    while r > b:                                                                       # round_batch rounds to nearest: go down
+        b -= 1
+        r = round_batch(b)
+    return max(1, r)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,31 +194,50 @@ def main():
     ap.add_argument("--config", default="block_main_b4_1.2b")
     ap.add_argument("--prefill", type=int, default=2048)
     ap.add_argument("--decode", type=int, default=128)
-    ap.add_argument("--batch", type=int, default=4096,
-                    help="per-GPU batch (weak scaling); 4096 x 544 block positions x 98 304 B = 219 GB of global KV")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="per-GPU batch (weak scaling); 0 = auto: sized from free HBM, capped at 4096 "
+                         "(4096 x 544 block positions x 98 304 B = 219 GB of global KV for prefill 2048 / decode 128)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
+    ap.add_argument("--pipeline", choices=["auto", "on", "off"], default="auto",
+                    help="two half-batch shards on two streams (global-attention / GEMM overlap); auto = batch >= 1024")
     ap.add_argument("--cpu-sample", default="128,128", help="prefill,decode of the CPU baseline sample")
     args = ap.parse_args()
 
-    rank, world, local = parallel.init_distributed()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the decode path has no CPU fallback")
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        if torch.cuda.device_count() < args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but only {torch.cuda.device_count()} GPU(s) are visible")
+        log(f"--gpus {args.gpus} without a torchrun environment: re-launching as {args.gpus} ranks")
+        parallel.launch_self_under_torchrun(args.gpus, os.path.abspath(__file__), sys.argv[1:])   # does not return
+    rank, world, local = parallel.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but {world} rank(s) are running (WORLD_SIZE={os.environ.get('WORLD_SIZE')})")
+    if world > 1:
+        assert torch.distributed.get_world_size() == args.gpus and torch.distributed.get_backend() == "nccl"
+        if torch.cuda.device_count() < world:
+            raise SystemExit(f"{world} ranks but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     dims = named_dims(args.config)
-    B, P, D, L = args.batch, args.prefill, args.decode, dims.L
+    P, D, L = args.prefill, args.decode, dims.L
+    itemsize = 2 if args.dtype == "bf16" else 4
+    B = args.batch if args.batch > 0 else auto_batch(dims, P, D, device, itemsize)
+    if world > 1:   # weak scaling with one per-GPU batch: every rank uses the smallest rank's fit
+        bt = torch.tensor([B], dtype=torch.int64, device=device)
+        torch.distributed.all_reduce(bt, op=torch.distributed.ReduceOp.MIN)
+        B = int(bt.item())
     max_length = get_max_length(L, P, D)
 
     log(f"rank {rank}/{world}: building {args.config} ({args.dtype}) on {device}")
     model = build_model(dims, args.dtype, device, args.seed)   # same weights on every rank (replicated)
     log("model built")
     model.use_graphs = not args.no_graphs
+    model.pipeline = {"auto": None, "on": True, "off": False}[args.pipeline]
     gen = torch.Generator().manual_seed(args.seed + 1000 * rank)
     input_ids = torch.randint(0, dims.vocab, (B, P), generator=gen).to(device)
 
@@ -174,12 +265,15 @@ def main():
 
     result = {
         "metric": "decoded_tokens_per_sec_per_node", "value": value, "unit": "tokens/s", "n_gpus": world,
+        "rccl_ranks": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.config} prefill{P}/decode{D}, greedy, EOS disabled, end-to-end generate() "
                                f"(prefill + decode) as in measure_generation_time.py",
                    "batch_per_gpu": B, "global_batch": B * world, "prefill": P, "decode": D, "block_length": L,
-                   "parallelism": f"dp{world} request shards", "hipgraph": model.use_graphs},
+                   "batch_sizing": "fixed (--batch)" if args.batch > 0 else "auto: free HBM / bytes per sequence, cap 4096",
+                   "parallelism": f"dp{world} request shards", "hipgraph": model.use_graphs,
+                   "half_batch_pipeline": bool(model._engine is not None and model._engine.pipelined)},
     }
 
     if rank == 0:
@@ -198,7 +292,26 @@ def main():
     if rank == 0 and not args.no_roofline:
         # per-kernel-family GPU time of ONE generate, launched eagerly with a hipEvent pair around every kernel on the
         # launch stream (libbt_hip's built-in timer), against the algorithmic flops/bytes of the same generate
-        counts = algorithmic_counts(dims, B, P, D, 2 if args.dtype == "bf16" else 4)
+        counts = algorithmic_counts(dims, B, P, D, itemsize)
+        # section 8d decode-phase roofline of the TIMED configuration: both lower bounds against the measured decode time
+        t_dec = decode_ms / 1e3
+        hbm_lb_ms = counts["decode_bytes"] / (HBM_PEAK_GBS * 1e9) * 1e3
+        mfma_lb_ms = counts["decode_flops"] / (MFMA_BF16_PEAK_TFLOPS * 1e12) * 1e3
+        result["roofline_decode_phase"] = {
+            "decode_ms": decode_ms, "bytes": counts["decode_bytes"], "flops": counts["decode_flops"],
+            "achieved_hbm_GBs": counts["decode_bytes"] / t_dec / 1e9, "frac_hbm": counts["decode_bytes"] / t_dec / 1e9 / HBM_PEAK_GBS,
+            "achieved_mfma_TFLOPs": counts["decode_flops"] / t_dec / 1e12,
+            "frac_mfma": counts["decode_flops"] / t_dec / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+            "lower_bound_ms": {"hbm": hbm_lb_ms, "mfma": mfma_lb_ms, "serial_sum": hbm_lb_ms + mfma_lb_ms},
+            "binding": "hbm" if hbm_lb_ms >= mfma_lb_ms else "mfma",
+            "frac_of_binding_roof": max(hbm_lb_ms, mfma_lb_ms) / decode_ms,
+            "note": "SURVEY 8d formulas: weights once per forward + global/local KV reads and appends + embedding rows; "
+                    "executed GEMM flops (last-layer tail skip subtracted) + attention flops; peaks 8 TB/s and 2.5 PF"}
+        # kernels in isolation: single-stream engine (the half-batch pipeline overlaps kernels, which inflates per-kernel times)
+        was_pipeline = model.pipeline
+        if model._engine is not None and model._engine.pipelined:
+            model.pipeline = False
+            model.release_buffers()
         model.use_graphs = False
         _lib.prof_enable(True)
         model.generate(input_ids, max_length=max_length)
@@ -206,6 +319,7 @@ def main():
         fam = _lib.prof_collect()
         _lib.prof_enable(False)
         model.use_graphs = not args.no_graphs
+        model.pipeline = was_pipeline
         fam_ms = {k: round(v[0], 3) for k, v in fam.items() if v[1]}
         fam_n = {k: int(v[1]) for k, v in fam.items() if v[1]}
         result["kernel_family_ms"] = fam_ms
@@ -217,24 +331,30 @@ def main():
             pmc = json.load(open(pmc_path))
 
         def traffic(name):
-            """HBM bytes per launch from the committed rocprofv3 PMC pass (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE)
-            of tools/kernel_probe.py at the shape recorded next to it; None when no PMC pass is on file."""
+            """Fabric-side bytes per launch from the COMMITTED rocprofv3 PMC pass (FETCH_SIZE x2 gfx950 correction +
+            WRITE_SIZE) of tools/kernel_probe.py at the shape recorded next to it -- a constant read from
+            profiles/pmc_traffic.json, NOT measured in this run (PMC collection needs rocprofv3 around the process);
+            None when no PMC pass is on file."""
             rec = pmc.get(name)
             return None if not rec else rec["hbm_bytes_corrected"]
 
         def traffic_note(name):
             rec = pmc.get(name)
-            return None if not rec else (f"PMC pass on {rec['shape']}: {rec['hbm_bytes_corrected'] / 1e6:.1f} MB HBM traffic "
-                                         f"per launch vs {rec['algorithmic_bytes'] / 1e6:.1f} MB algorithmic")
+            return None if not rec else (f"from profiles/pmc_traffic.json (committed rocprofv3 --pmc pass, not this run) on "
+                                         f"{rec['shape']}: {rec['hbm_bytes_corrected'] / 1e6:.1f} MB per launch vs "
+                                         f"{rec['algorithmic_bytes'] / 1e6:.1f} MB algorithmic")
 
         def roof(name):
             ms, n = fam[name]
             if name in ("linear_mfma", "linear_generic"):
-                ach = counts["linear_flops"] / (ms / 1e3) / 1e12
+                # EXECUTED flops: the engine skips 9/12 of the last layer for rows nobody consumes (tail_only), so the
+                # nominal 2*M*N*K sum over the model would overstate the rate
+                ach = counts["linear_flops_executed"] / (ms / 1e3) / 1e12
                 return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
                         "unit": "TFLOP/s", "frac": ach / MFMA_BF16_PEAK_TFLOPS,
                         "traffic": traffic(name), "launches": int(n), "avg_launch_us": ms / n * 1e3,
-                        "algorithmic_per_launch": counts["linear_flops"] / n}
+                        "algorithmic_per_launch": counts["linear_flops_executed"] / n,
+                        "nominal_flops_incl_skipped": counts["linear_flops"]}
             if name == "attn_flash":
                 ach = counts["attn_flash_flops"] / (ms / 1e3) / 1e12
                 return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": MFMA_BF16_PEAK_TFLOPS,
@@ -263,6 +383,7 @@ def main():
         log("cpu baseline (oracle on host cores) ...")
         base, cpu_out, cpu_ids = cpu_baseline(model, dims, sp, sdn)
         log(f"cpu baseline done: {base['seconds']:.1f}s")
+        base["plumbing_config0"] = cpu_plumbing_config0(base["cores"])   # BASELINE.json configs[0]
         # parity on identical inputs, same run: GPU greedy tokens vs the CPU eager path (bf16 vs fp32: agreement rate)
         gpu_out = model.generate(cpu_ids.to(device), max_length=cpu_out.shape[1]).cpu()
         # bf16 GPU vs fp32 CPU greedy decoding on random-init weights (near-flat logits): report how far the two

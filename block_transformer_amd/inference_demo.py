@@ -57,29 +57,37 @@ def load_model(name: str, checkpoint_root: Optional[str], random_init: bool = Fa
 
 
 def set_temperature(model, temperature: float):
-    if isinstance(model, BlockTransformer):
-        model.token_decoder.generation_config.update(do_sample=True, temperature=temperature)
-    else:
-        model.generation_config.update(do_sample=True, temperature=temperature)
+    """Switch generation to sampling at ``temperature`` (HF default top_k = 50) — reference inference_demo.py:62-66."""
+    holder = model.token_decoder if hasattr(model, "token_decoder") else model
+    holder.generation_config.update(do_sample=True, temperature=float(temperature))
 
 
-class FirstSampleStreamer:
-    """Prints the tokens of the last sample as they are generated (reference :69-83)."""
+class SampleStreamer:
+    """HF-streamer-protocol sink (``put(tensor)`` per step, ``end()`` per generate call) that echoes ONE sample of the batch
+    as it is generated.  ``BlockTransformer.generate`` drives it once per block: a ``[B, 1]`` placeholder first (dropped
+    here, like the prompt in HF's TextStreamer), then one ``[B]`` tensor per token, then ``end()``."""
 
-    def __init__(self, tokenizer=None):
+    def __init__(self, tokenizer=None, sample_index: int = -1):
         self.tokenizer = tokenizer
-        self.first = True
+        self.sample_index = sample_index
+        self._drop_next = True
+
+    def _render(self, token_id: int) -> str:
+        if self.tokenizer is None:
+            return f"<{token_id}>"
+        return self.tokenizer.decode(token_id).replace("\n", "\\n")
 
     def put(self, value):
-        if self.first:  # ignore the prompt / placeholder
-            self.first = False
+        if self._drop_next:
+            self._drop_next = False
             return
-        tok = value[-1]
-        text = self.tokenizer.decode(tok).replace("\n", "\\n") if self.tokenizer is not None else f"<{int(tok)}>"
-        print(text, end="", flush=True)
+        print(self._render(int(value.reshape(-1)[self.sample_index])), end="", flush=True)
 
     def end(self):
-        self.first = True
+        self._drop_next = True
+
+
+FirstSampleStreamer = SampleStreamer   # the reference's name for it (inference_demo.py:69-83)
 
 
 def main(argv=None):
@@ -94,9 +102,13 @@ def main(argv=None):
     ap.add_argument("--prompt-length", type=int, default=64, help="random prompt length when no tokenizer is given")
     ap.add_argument("--random-init", action="store_true", help="skip the checkpoint (plumbing / speed demo)")
     ap.add_argument("--no-stream", action="store_true")
+    ap.add_argument("--rope-policy", choices=["hf439_generate", "train"], default=None,
+                    help="token-decoder RoPE positions of cached generation (default: the reference's, hf439_generate)")
     args = ap.parse_args(argv)
 
     model, tokenizer = load_model(args.model, args.checkpoint_root, args.random_init, args.tokenizer)
+    if args.rope_policy:
+        model.token_decoder.rope_policy = args.rope_policy
     if tokenizer is not None:
         inputs = tokenizer([args.prompt] * args.batch_size, return_tensors="pt")
         inputs = {k: t.cuda() for k, t in inputs.items() if k in ("input_ids", "attention_mask")}
@@ -107,20 +119,20 @@ def main(argv=None):
     prompt_length = inputs["input_ids"].shape[1]
     generation_length = args.max_length - prompt_length
     set_temperature(model, args.temperature)
-    streamer = None if args.no_stream else FirstSampleStreamer(tokenizer)
+    streamer = None if args.no_stream else SampleStreamer(tokenizer)
     torch.cuda.synchronize()
     start = time.time()
     output_ids = model.generate(**inputs, max_length=args.max_length, streamer=streamer)
     torch.cuda.synchronize()
     duration = time.time() - start
-    memory = torch.cuda.max_memory_allocated(device=None)
-    print("\n" + " End of generation ".center(60, "-"))
-    print(f"Prompt length              : {prompt_length:>8}")
-    print(f"Generation length          : {generation_length:>8}")
-    print(f"Batch size                 : {args.batch_size:>8}")
-    print(f"Max memory allocated       : {memory / 1024 ** 3:>6.2f}GB")
-    print(f"Tok/sec/sample             : {generation_length / duration:>8.2f}")
-    print(f"Tok/sec                    : {generation_length * args.batch_size / duration:>8.2f}")
+    report = [("Prompt length", f"{prompt_length}"), ("Generation length", f"{generation_length}"),
+              ("Batch size", f"{args.batch_size}"),
+              ("Max memory allocated", f"{torch.cuda.max_memory_allocated() / 2 ** 30:.2f} GiB"),
+              ("Tok/sec/sample", f"{generation_length / duration:.2f}"),
+              ("Tok/sec", f"{generation_length * args.batch_size / duration:.2f}")]
+    print("\n" + "=" * 48)
+    for label, value in report:
+        print(f"{label:<24}{value:>24}")
     return output_ids
 
 

@@ -47,6 +47,9 @@ def prepare_block_model(cfg, prefill_length: int, decode_length: int) -> BlockTr
     model.token_decoder.config.pad_token_id = 1
     model.token_decoder.config.eos_token_id = 0
     model.token_decoder.generation_config.eos_token_id = None
+    policy = (cfg.get("token_decoder") or {}).get("rope_policy")       # build-specific knob, see engine.td_position_table
+    if policy is not None:
+        model.token_decoder.rope_policy = policy
     return model.eval()
 
 
@@ -181,8 +184,16 @@ def main(argv=None):
     batch_sizes = cfg.get("benchmark_batch_sizes")
     P = cfg.get("benchmark_prefill_length", DEFAULT_PREFILL_LENGTH)
     D = cfg.get("benchmark_decode_length", DEFAULT_DECODE_LENGTH)
+    # VRAM the batch search may fill.  The reference searches toward 100 % and stops below 2 GiB free (:445-468); on a
+    # shared box the default here keeps 8 % head-room (an allocation failure inside a kernel launch or graph
+    # instantiation is not a clean torch OOM).  ++benchmark_vram_fraction=1.0 restores the reference's rule;
+    # ++benchmark_memory_limit_gib / ++benchmark_min_free_gib bound the search explicitly (tests).
     total_memory = torch.cuda.get_device_properties(DEVICE).total_memory / 1024 ** 3
-    output_path = os.path.join(SAVE_DIR, cfg.get("output_dir") or cfg["name"], "generation_time.csv")
+    total_memory *= float(cfg.get("benchmark_vram_fraction", 0.92))
+    if cfg.get("benchmark_memory_limit_gib") is not None:
+        total_memory = float(cfg["benchmark_memory_limit_gib"])
+    min_free = float(cfg.get("benchmark_min_free_gib", 2))
+    output_path = os.path.join(cfg.get("save_dir") or SAVE_DIR, cfg.get("output_dir") or cfg["name"], "generation_time.csv")
     data: List[Dict] = []
     if os.path.exists(output_path):
         print("Reading existing measurement data")
@@ -192,7 +203,7 @@ def main(argv=None):
         for b in (1, 2):
             if not measurement_exists(data, b, P, D):
                 data.append(measure_generation(model, P, D, b))
-        while total_memory - get_max_batch_size_row(data, P, D)["max_memory_allocated"] >= 2:
+        while total_memory - get_max_batch_size_row(data, P, D)["max_memory_allocated"] >= min_free:
             nxt = find_next_batch_size(data, P, D, total_memory)
             if nxt is None:
                 break

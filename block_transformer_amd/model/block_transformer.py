@@ -148,8 +148,11 @@ class BlockTransformer(nn.Module):
         return e
 
     def release_buffers(self):
-        """Drop the engine (KV caches, workspaces, captured graphs)."""
+        """Drop the engine (KV caches, workspaces, captured graphs) and return the blocks to the driver (a differently
+        shaped engine -- other batch, single-stream vs half-batch shards -- needs contiguous room for its own caches)."""
         self._engine = None
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
 
     # ---- generate ----------------------------------------------------------------------------------------------------------
     @torch.inference_mode()

@@ -560,3 +560,311 @@ def test_mid_batch_streamer_stack_matches_unfused(B, dbg_lib):
     assert torch.equal(fused[:, :32], prompt.cpu())
     assert (fused == unfused).all(dim=1).float().mean() >= 0.6, (fused == unfused).float().mean()
     assert (fused[:, 32] == unfused[:, 32]).float().mean() >= 0.8
+
+
+# ---- round 2: parity on the path that is benchmarked, long decodes, the half-batch pipeline, the harness entry points ------------
+def _oracle_first_token(o, prompt):
+    """(ctx [B, H], first-token logits [B, V]) of the fp32 oracle for a prompt batch."""
+    d = o.preprocess_inputs_for_generation(prompt, None)
+    ids, bm = d["input_ids"], d["block_attention_mask"]
+    B, nb, L = ids.shape
+    x = o.embed(ids).view(B, nb, -1)
+    hidden, _ = o.block_decoder(x, bm)
+    ctx = hidden[:, -1]
+    _, lg = o.token_decoder_generate(ctx, 1, return_logits=True)
+    return ctx, lg[:, 0]
+
+
+_FULL = {}
+
+
+def _full_1p2b():
+    """block_main_b4_1.2b at full depth, bf16, random init directly on the GPU (HF-style N(0, 0.02) + non-zero biases), and
+    the fp32 CPU oracle on exactly those bf16 weights.  Built once per test session (2.4 G parameters)."""
+    if not _FULL:
+        dims = named_dims("block_main_b4_1.2b")
+        torch.manual_seed(21)
+        with torch.device(DEV):
+            model = load_block_transformer_from_dims(dims, "bf16", keep_unused_embed_in=False)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if n.endswith(".bias"):
+                    p.normal_(0.0, 0.02)
+        model.token_decoder.generation_config.eos_token_id = None
+        sd16 = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+        _FULL["m"] = (model, dims, oracle_from_dims(dims, sd16))
+    return _FULL["m"]
+
+
+@pytest.mark.parametrize("B", [2, 64])
+def test_full_depth_1p2b_bf16_first_block_logits_vs_oracle(B):
+    """BASELINE configs[1] at FULL depth (12 + 12 layers, H = 2048, V = 50304), bf16, P = 2048, through generate():
+    B = 64 puts the prefill on the persistent 256x256 MFMA GEMM with the fused QKV/RoPE/append epilogue and the flash
+    kernel (32768 rows per chunk), the decode on the 128^2 / split-K kernels; B = 2 on the skinny streamers.  Context
+    embedding and first-token logits against the fp32 CPU oracle on the same (bf16) weights (oracle on 2 of the B
+    sequences: rows are independent).
+    bf16 budget: 24 layers of bf16-rounded activations (2^-9 relative per rounding, ~10 roundings per layer,
+    accumulating as a random walk) -> |error| <= 4 % of max|value| + 0.02 absolute; the greedy token must agree wherever
+    the oracle's top-1 margin exceeds twice that budget."""
+    model, dims, o = _full_1p2b()
+    model.pipeline = False
+    model.use_graphs = True
+    P = 2048
+    prompt = torch.randint(0, dims.vocab, (B, P), generator=torch.Generator().manual_seed(B))
+    got = model.generate(prompt.to(DEV), max_length=P + 1).cpu()       # one token: the engine keeps its logits
+    eng = model._engine
+    rows = [0, B - 1]
+    ctx = eng.ctx.float().cpu()[rows]
+    logits = eng.tok.logits.float().cpu()[rows]
+    ref_ctx, ref_lg = _oracle_first_token(o, prompt[rows])
+    budget_ctx = 4e-2 * ref_ctx.abs().max().item() + 2e-2
+    budget_lg = 4e-2 * ref_lg.abs().max().item() + 2e-2
+    e_ctx, e_lg = (ctx - ref_ctx).abs().max().item(), (logits - ref_lg).abs().max().item()
+    print(f"[full-depth bf16 B={B}] ctx err {e_ctx:.4f} (budget {budget_ctx:.4f}, max {ref_ctx.abs().max():.3f}); "
+          f"logit err {e_lg:.4f} (budget {budget_lg:.4f}, max {ref_lg.abs().max():.3f})")
+    assert e_ctx <= budget_ctx and e_lg <= budget_lg
+    top2 = ref_lg.topk(2, dim=-1).values
+    margin = top2[:, 0] - top2[:, 1]
+    for i, r in enumerate(rows):
+        if margin[i] > 2 * budget_lg:
+            assert int(got[r, P]) == int(ref_lg[i].argmax())
+        assert int(got[r, P]) == int(logits[i].argmax())               # the emitted token is the argmax of the engine's logits
+    assert torch.equal(got[:, :P], prompt)
+    model.release_buffers()
+
+
+def test_fp32_production_dims_one_layer_logits_within_1e3():
+    """north_star tolerance at PRODUCTION tensor dims: fp32 instantiation, one layer per decoder, H = 2048, d = 128,
+    rot = 32, I = 8192, V = 50304: context, first-token logits within 1e-3 of the CPU oracle, greedy tokens equal."""
+    import dataclasses
+    base = named_dims("block_main_b4_1.2b")
+    one = dataclasses.replace(base, name="b4_1.2b_1layer_fp32", bd=dataclasses.replace(base.bd, layers=1),
+                              td=dataclasses.replace(base.td, layers=1))
+    sd = random_state_dict(one, seed=4, include_unused_embed_in=False)
+    model = load_block_transformer_from_dims(one, "fp32", keep_unused_embed_in=False)
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV)
+    model.token_decoder.generation_config.eos_token_id = None
+    o = oracle_from_dims(one, sd)
+    prompt = torch.randint(0, one.vocab, (2, 64), generator=torch.Generator().manual_seed(2))
+    got1 = model.generate(prompt.to(DEV), max_length=65).cpu()
+    ref_ctx, ref_lg = _oracle_first_token(o, prompt)
+    eng = model._engine
+    assert maxabs(eng.ctx, ref_ctx) <= TOL, maxabs(eng.ctx, ref_ctx)
+    assert maxabs(eng.tok.logits, ref_lg) <= TOL, maxabs(eng.tok.logits, ref_lg)
+    assert torch.equal(got1[:, 64], ref_lg.argmax(-1))
+    want = o.generate(prompt, max_length=76)
+    got = model.generate(prompt.to(DEV), max_length=76).cpu()
+    assert torch.equal(got, want)
+    del model
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name,B,P,D", [("micro128", 2, 128, 1024), ("micro", 3, 126, 1030)])
+def test_long_decode_graph_replay_matches_oracle(gpu_model, name, B, P, D):
+    """BASELINE configs[2] shape (short prompt, LONG decode) in fp32 with graphs on: hundreds of block-step replays, n_cur
+    growing from P/L past 256 cached positions so the split-N global attention (B*heads < 512, n_max >= 256) runs under
+    replay; greedy tokens bit-exact against the CPU oracle, and graphs on == graphs off."""
+    model, dims, sd, fx = gpu_model(name)
+    o = oracle_from_dims(dims, sd)
+    prompt = torch.randint(1, dims.vocab, (B, P), generator=torch.Generator().manual_seed(P))
+    ml = -(-P // dims.L) * dims.L + D
+    want = o.generate(prompt, max_length=ml)
+    model.use_graphs = True
+    got = model.generate(prompt.to(DEV), max_length=ml).cpu()
+    eng = model._engine
+    assert eng.n_split > 1 and eng.n_max >= 256, (eng.n_split, eng.n_max)
+    assert got.shape == want.shape
+    first_bad = (got != want).any(0).nonzero()
+    assert torch.equal(got, want), f"first differing column {int(first_bad[0]) if len(first_bad) else None}"
+    model.use_graphs = False
+    try:
+        eager = model.generate(prompt.to(DEV), max_length=ml).cpu()
+    finally:
+        model.use_graphs = True
+    assert torch.equal(eager, got)
+
+
+def test_full_size_1p2b_long_decode_properties():
+    """BASELINE configs[2] at full size: block_main_b4_1.2b bf16, B = 8, P = 128, D = 2048 (512 block-step replays, the
+    5..16-row MFMA streamer stacks, split-N global attention from 256 cached positions on).  Size-independent properties:
+    prompt preserved, ids in range, replay is deterministic (second run identical: all per-run state is reset), and the
+    captured graphs launch exactly the eager sequence (graphs on == graphs off, bit for bit)."""
+    model, dims, _ = _full_1p2b()
+    model.pipeline = None
+    model.use_graphs = True
+    B, P, D = 8, 128, 2048
+    prompt = torch.randint(0, dims.vocab, (B, P), generator=torch.Generator().manual_seed(11)).to(DEV)
+    a = model.generate(prompt, max_length=P + D).cpu()
+    assert a.shape == (B, P + D) and torch.equal(a[:, :P], prompt.cpu())
+    assert int(a.min()) >= 0 and int(a.max()) < dims.vocab
+    assert model._engine.n_split > 1
+    b = model.generate(prompt, max_length=P + D).cpu()
+    assert torch.equal(a, b), "graph replay is not deterministic / state leaked between runs"
+    model.use_graphs = False
+    c = model.generate(prompt, max_length=P + D).cpu()
+    assert torch.equal(a, c), "captured graphs differ from the eager launch sequence"
+    # sequences are independent: the 8 rows do not all produce the same text
+    assert len({tuple(r.tolist()) for r in a[:, P:P + 64]}) > 1
+    model.use_graphs = True
+    model.release_buffers()
+
+
+@pytest.mark.parametrize("B", [2, 5, 64])
+@pytest.mark.parametrize("sync", ["0", "1"])
+def test_half_batch_pipeline_equals_single_engine(gpu_model, B, sync, monkeypatch):
+    """engine.PipelinedEngine (two half-batch shards on two streams, one token block apart) == the single-stream engine,
+    bit for bit in fp32 (sequences are independent), incl. odd batches, EOS handling and P % L != 0."""
+    monkeypatch.setenv("BT_PIPELINE_SYNC", sync)
+    model, dims, sd, fx = gpu_model("micro")
+    prompt = torch.randint(1, dims.vocab, (B, 10), generator=torch.Generator().manual_seed(B)).to(DEV)
+    try:
+        model.pipeline = False
+        model.release_buffers()
+        one = model.generate(prompt, max_length=39).cpu()
+        assert not model._engine.pipelined
+        model.pipeline = True
+        two = model.generate(prompt, max_length=39).cpu()
+        assert model._engine.pipelined and len(model._engine.shards) == 2
+        assert torch.equal(one, two)
+        assert torch.equal(two, model.generate(prompt, max_length=39).cpu())      # replay of the captured shard graphs
+        # EOS: pick a token the greedy run produces and make it EOS
+        gcfg = model.token_decoder.generation_config
+        eos = int(one[0, 14])
+        old = (gcfg.eos_token_id, gcfg.pad_token_id)
+        try:
+            gcfg.eos_token_id, gcfg.pad_token_id = eos, 1
+            two_e = model.generate(prompt, max_length=39).cpu()
+            model.pipeline = False
+            one_e = model.generate(prompt, max_length=39).cpu()
+            assert torch.equal(one_e, two_e)
+        finally:
+            gcfg.eos_token_id, gcfg.pad_token_id = old
+    finally:
+        model.pipeline = None
+        model.release_buffers()
+
+
+def test_half_batch_pipeline_bf16_full_width_layers():
+    """The pipeline at production tensor widths (2-layer 1.2B-shaped model, bf16, B = 512 -> two 256-row shards): same
+    greedy tokens as the single-stream engine up to bf16 near-ties (the shards run other GEMM tile shapes than the whole
+    batch), first token of every sequence identical to the argmax of its own logits."""
+    import dataclasses
+    base = named_dims("block_main_b4_1.2b")
+    dims = dataclasses.replace(base, name="b4_1.2b_2layer", bd=dataclasses.replace(base.bd, layers=2),
+                               td=dataclasses.replace(base.td, layers=2))
+    sd = random_state_dict(dims, seed=5, include_unused_embed_in=False)
+    model = load_block_transformer_from_dims(dims, "fp32", keep_unused_embed_in=False)
+    model.load_state_dict(sd, strict=True)
+    model = model.bfloat16().to(DEV)
+    model.token_decoder.generation_config.eos_token_id = None
+    prompt = torch.randint(0, dims.vocab, (512, 64), generator=torch.Generator().manual_seed(1)).to(DEV)
+    model.pipeline = False
+    one = model.generate(prompt, max_length=96).cpu()
+    model.pipeline = True
+    two = model.generate(prompt, max_length=96).cpu()
+    assert model._engine.pipelined
+    assert torch.equal(two[:, :64], prompt.cpu())
+    assert (one[:, 64] == two[:, 64]).float().mean() >= 0.97, (one[:, 64] == two[:, 64]).float().mean()
+    assert (one == two).all(dim=1).float().mean() >= 0.7, (one == two).all(dim=1).float().mean()
+    del model
+    torch.cuda.empty_cache()
+
+
+def test_graphs_follow_reloaded_weights_and_seed(gpu_model):
+    """the captured graphs bake in parameter pointers and the sampler seed.  Re-materialised parameters
+    (state_dict round trip with assign=True, .cpu().cuda()) and a changed seed must not be replayed through stale graphs."""
+    model, dims, sd, fx = gpu_model("micro")
+    prompt = t(fx, "g6_1_prompt").to(DEV)
+    base = model.generate(prompt, max_length=24).cpu()
+    try:
+        # new storage, different values: the output must follow the new weights
+        sd2 = {k: (v.clone() * (1.5 if k.endswith("embed_out.weight") else 1.0)).to(DEV) for k, v in sd.items()}
+        sd2["token_decoder.embed_out.weight"] = sd2["token_decoder.embed_out.weight"].flip(0).contiguous()
+        model.load_state_dict(sd2, strict=True, assign=True)
+        moved = model.generate(prompt, max_length=24).cpu()
+        o2 = oracle_from_dims(dims, {k: v.cpu() for k, v in sd2.items()})
+        assert torch.equal(moved, o2.generate(prompt.cpu(), max_length=24))
+        assert not torch.equal(moved, base)
+    finally:
+        model.load_state_dict({k: v.to(DEV) for k, v in sd.items()}, strict=True, assign=True)
+    assert torch.equal(model.generate(prompt, max_length=24).cpu(), base)
+    g = model.token_decoder.generation_config
+    g.update(do_sample=True, temperature=1.3)
+    try:
+        outs = []
+        for seed in (1, 2, 1):
+            g.seed = seed
+            outs.append(model.generate(prompt, max_length=40).cpu())
+        assert torch.equal(outs[0], outs[2]), "same seed, same draws"
+        assert not torch.equal(outs[0], outs[1]), "a new seed must reach the captured sampler"
+        model.use_graphs = False
+        g.seed = 1
+        assert torch.equal(model.generate(prompt, max_length=40).cpu(), outs[0]), "graphs on == graphs off under sampling"
+    finally:
+        model.use_graphs = True
+        g.update(do_sample=False, temperature=1.0)
+        g.seed = 0
+
+
+def test_topk_sampler_is_deterministic_and_bounded():
+    """candidates are compacted in vocabulary order (no atomic slot race): the same (seed, step, row) draws the
+    same token every time, also with many ties at the threshold; top_k beyond the 1024-candidate buffer is refused."""
+    from block_transformer_amd import _lib, ops
+    V = 50304
+    g = torch.Generator().manual_seed(0)
+    logits = torch.randn(64, V, generator=g).bfloat16()              # bf16: plenty of exact ties
+    logits[:8] = 0.0                                                 # every score tied: 50304 candidates at the threshold
+    logits = logits.to(DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    outs = [ops.topk_sample(logits, temperature=0.9, top_k=50, seed=7, step=step).cpu() for _ in range(5)]
+    for o_ in outs[1:]:
+        assert torch.equal(o_, outs[0])
+    assert int(outs[0].min()) >= 0 and int(outs[0].max()) < V
+    assert int(outs[0][:8].max()) < 1024, "all-tied rows keep the lowest-index ties"
+    # every draw lies in the top-k set (ties included) of its row
+    f = logits.float().cpu()
+    kth = f.topk(50, dim=-1).values[:, -1]
+    picked = f[torch.arange(64), outs[0]]
+    assert bool((picked >= kth).all())
+    with pytest.raises(_lib.BtError, match="top_k"):
+        ops.topk_sample(logits, temperature=1.0, top_k=5000, seed=1, step=step)
+
+
+def test_generate_benchmark_printout(gpu_model, capsys):
+    """generate(benchmark=True) prints the reference's per-iteration report (block_transformer.py:428-444)."""
+    model, dims, sd, fx = gpu_model("micro")
+    prompt = t(fx, "g6_1_prompt").to(DEV)
+    out = model.generate(prompt, max_length=24, benchmark=True).cpu()
+    text = capsys.readouterr().out
+    assert "Block decoder times:" in text and "Token decoder times:" in text and "Total time:" in text
+    tm = model.last_timers
+    assert len(tm.iter_ms("token_decoder")) == 4 and len(tm.iter_ms("block_decoder")) == 3   # 16 new tokens = 4 blocks
+    assert torch.equal(out, model.generate(prompt, max_length=24).cpu())
+
+
+def test_measure_generation_time_main_runs(tmp_path):
+    """The harness counterpart of measure_generation_time.py end to end on the GPU at micro size: fixed batch list, then
+    the reference's auto-tune (B = 1, 2 -> linear memory model -> bisection) under an explicit memory bound."""
+    from block_transformer_amd import measure_generation_time as mgt
+    common = ["++block_decoder.config.num_hidden_layers=1", "++token_decoder.config.num_hidden_layers=1",
+              "++benchmark_prefill_length=32", "++benchmark_decode_length=16", f"++save_dir={tmp_path}"]
+    df = mgt.main(["--config-name", "block_main_b4_5", "++benchmark_batch_sizes=[2,4]", "++output_dir=fixed"] + common)
+    assert list(df["batch_size"]) == [2, 4] and not df["oom"].any()
+    assert (df["tokens_per_s"] > 0).all() and (tmp_path / "fixed" / "generation_time.csv").exists()
+    df = mgt.main(["--config-name", "block_main_b4_5", "++output_dir=auto", "++benchmark_memory_limit_gib=0.6",
+                   "++benchmark_min_free_gib=0.2"] + common)
+    bs = sorted(df["batch_size"])
+    assert bs[:2] == [1, 2] and len(bs) >= 3 and bs[-1] > 2, bs
+    assert float(df["max_memory_allocated"].max()) <= 0.8
+
+
+def test_inference_demo_main_runs(capsys):
+    """The harness counterpart of inference_demo.py end to end (random init: no checkpoint / tokenizer on the box):
+    sampling with temperature, streamer attached, throughput report."""
+    from block_transformer_amd import inference_demo as demo
+    out = demo.main(["--model", "block_main_b4_5", "--random-init", "--batch_size", "3", "--max_length", "40",
+                     "--prompt-length", "12", "--temperature", "0.8"])
+    text = capsys.readouterr().out
+    assert out.shape == (3, 40)
+    assert "Tok/sec" in text and "<" in text          # report + streamed token ids of the last sample

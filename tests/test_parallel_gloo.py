@@ -65,3 +65,69 @@ def test_two_process_gloo_sharding(n_req):
         assert torch.equal(full, want), "sharded output must equal the single-process output, in request order"
         assert mx == 2.0 and sm == 30.0
     assert ret[0][3] + ret[1][3] == n_req
+
+
+def _ragged_generate(ids, max_length):
+    """A shard whose sequences all hit EOS early returns FEWER columns (generate() stops per shard); widths differ per rank."""
+    B, P = ids.shape
+    width = max_length if (B and int(ids[0, 0]) % 2 == 0) else max_length - 3
+    out = torch.full((B, width), 7, dtype=torch.int64)
+    out[:, :P] = ids
+    return out
+
+
+def _ragged_worker(rank, world, port, n_req, ret):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    parallel.init_distributed("gloo")
+    ids = torch.arange(n_req * 4, dtype=torch.int64).view(n_req, 4) + 2      # request 0 starts even, request 1 odd, ...
+    full = parallel.generate_sharded(_ragged_generate, ids, pad_token_id=1, max_length=12)
+    ret[rank] = full
+    parallel.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_req", [1, 2, 5])
+def test_gather_ids_ragged_widths_and_empty_shard(n_req):
+    """shards may return different widths (per-shard EOS stop) and a rank may own no request at all (n_req <
+    world): the gather agrees on the widest shard, right-pads the others with pad_token_id and neither errors nor hangs."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_ragged_worker, args=(2, port, n_req, ret), nprocs=2, join=True)
+    ids = torch.arange(n_req * 4, dtype=torch.int64).view(n_req, 4) + 2
+    shards = [_ragged_generate(ids[lo:hi], 12) for lo, hi in (parallel.shard_bounds(n_req, r, 2) for r in range(2)) if hi > lo]
+    width = max(sh.shape[1] for sh in shards)
+    want = torch.cat([torch.nn.functional.pad(sh, (0, width - sh.shape[1]), value=1) for sh in shards])
+    for r in (0, 1):
+        assert torch.equal(ret[r], want), (r, ret[r], want)
+
+
+def test_self_launch_under_torchrun(tmp_path):
+    """bench.py --gpus N without a torchrun environment re-execs itself as N ranks: the helper must produce WORLD_SIZE = N
+    processes that rendezvous on 127.0.0.1 (CPU / gloo stand-in for the RCCL launch), and be a no-op inside a rank."""
+    import subprocess
+    import sys
+    script = tmp_path / "toy.py"
+    out = tmp_path / "out"
+    out.mkdir()
+    script.write_text(f"""
+import os, sys
+sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r})
+from block_transformer_amd import parallel
+n = int(sys.argv[1])
+parallel.launch_self_under_torchrun(n, os.path.abspath(__file__), sys.argv[1:])   # re-execs when not yet a rank
+rank, world, local = parallel.init_distributed("gloo")
+assert world == n, (world, n)
+total = parallel.sum_over_ranks(rank + 1)
+parallel.barrier()
+open(os.path.join({str(out)!r}, f"rank{{rank}}"), "w").write(f"{{world}} {{total}}")
+""")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, str(script), "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = sorted(os.listdir(out))
+    assert got == ["rank0", "rank1"], got
+    assert (out / "rank0").read_text() == "2 3.0" and (out / "rank1").read_text() == "2 3.0"
