@@ -19,6 +19,8 @@
 //  attn_combine_kernel<T>     merges split-N partials (flash-decoding style) when B*heads is too small to fill 256 CUs.
 #include "bt_common.h"
 
+#include <algorithm>
+
 namespace bt {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -123,14 +125,18 @@ __device__ inline float block_sum(float v, float* red, int wave, int lane) {
     return r;
 }
 
-template <typename T, int D, int NW, bool NT = false>
+// PERSIST: a fixed grid of workgroups walks the (sequence, head, query row) items (total_items of them) instead of one
+// workgroup per item: the kernel then holds a bounded number of wave slots / registers per CU for its whole run time, so a
+// GEMM launched on another stream can stay co-resident with it (half-batch pipeline: this kernel is HBM-bound and needs
+// bytes in flight, not occupancy).
+template <typename T, int D, int NW, bool NT = false, bool PERSIST = false>
 __global__ __launch_bounds__(NW * 64) void attend_rows_kernel(const T* __restrict__ qkv, int64_t ld_qkv,
                                                              const T* __restrict__ kc, const T* __restrict__ vc,
                                                              int64_t n_max, const int32_t* __restrict__ pos0_dev,
                                                              int pos0_host, const uint8_t* __restrict__ mask,
                                                              int64_t mask_ld, T* __restrict__ out, int64_t ldo,
                                                              float* __restrict__ ws, int q_len, int heads, int n_split,
-                                                             float scale) {
+                                                             float scale, int64_t total_items = 0) {
     constexpr int V = Elem<T>::VEC;
     constexpr int LPR = D / V;     // lanes per K/V row
     constexpr int RPW = 64 / LPR;  // rows per wave-instruction
@@ -142,7 +148,8 @@ __global__ __launch_bounds__(NW * 64) void attend_rows_kernel(const T* __restric
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane % LPR, sub = lane / LPR;
-    const int64_t idx = blockIdx.x;
+    for (int64_t idx = blockIdx.x; PERSIST ? idx < total_items : idx == (int64_t)blockIdx.x; idx += gridDim.x) {
+    if (PERSIST && idx != (int64_t)blockIdx.x) __syncthreads();   // the previous item's LDS rows are free again
     const int t = (int)(idx % q_len);
     const int head = (int)((idx / q_len) % heads);
     const int64_t b = idx / ((int64_t)q_len * heads);
@@ -269,6 +276,7 @@ __global__ __launch_bounds__(NW * 64) void attend_rows_kernel(const T* __restric
             for (int i = 0; i < V; ++i) w[2 + c * V + i] = acc[i];
         }
     }
+    }   // item loop
 }
 
 template <typename T>
@@ -769,6 +777,9 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void flash_prefill_v2_ker
 // ---- host dispatch ------------------------------------------------------------------------------------------------------
 #ifdef BT_DEBUG_HOOKS
 static int g_attn_nt = 0;   // A/B hook (debug library only): non-temporal K/V loads in the global (NW = 4) streaming kernel
+static int g_attn_persist = 0;   // A/B hook: > 0 = persistent global-attention kernel with that many workgroups per CU
+#else
+static constexpr int g_attn_persist = 0;
 #endif
 
 template <typename T, int D>
@@ -790,6 +801,16 @@ static int launch_attend(int64_t B, int q_len, int heads, const void* qkv, int64
             set_error("bt_attention: %lld keys per split need %zu B of LDS; raise n_split", (long long)cap, shm);
             return BT_ERR_ARG;
         }
+        if (g_attn_persist > 0 && n_split == 1) {   // bounded-footprint variant: g_attn_persist workgroups per CU walk the items
+            const int64_t items = B * heads * q_len;
+            int dev = 0, cus = 256;
+            (void)hipGetDevice(&dev);
+            (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            const dim3 pgrid((unsigned)std::min<int64_t>(items, (int64_t)g_attn_persist * cus), 1);
+            hipLaunchKernelGGL((attend_rows_kernel<T, D, 4, false, true>), pgrid, dim3(256), shm, s, (const T*)qkv, ld_qkv,
+                               (const T*)kc, (const T*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (T*)out, ldo, ws, q_len,
+                               heads, n_split, scale, items);
+        } else
 #ifdef BT_DEBUG_HOOKS
         if (g_attn_nt)
             hipLaunchKernelGGL((attend_rows_kernel<T, D, 4, true>), grid, dim3(256), shm, s, (const T*)qkv, ld_qkv,
@@ -946,4 +967,5 @@ extern "C" int bt_attention(int dtype, int mode, int64_t B, int32_t q_len, int32
 #ifdef BT_DEBUG_HOOKS
 extern "C" void bt_debug_flash_variant(int v) { bt::g_flash_variant = v; }
 extern "C" void bt_debug_attn_nt(int v) { bt::g_attn_nt = v; }
+extern "C" void bt_debug_attn_persist(int v) { bt::g_attn_persist = v; }
 #endif

@@ -75,7 +75,7 @@ class BlockTransformer(nn.Module):
         self.decoding_strategy = decoding_strategy
         self.config = self.token_decoder.config  # for Evaluation (reference :48)
         self.use_graphs = True
-        self.pipeline = None          # None = auto (see _want_pipeline)
+        self.pipeline = None          # None = off unless BT_PIPELINE=1 (see _want_pipeline)
         self.collect_timers = False  # bench.py: record phase events without the benchmark printout
         self._engine: Optional[DecodeEngine] = None
         self.last_timers: Optional[_Timers] = None
@@ -126,19 +126,20 @@ class BlockTransformer(nn.Module):
 
     # ---- engine management ---------------------------------------------------------------------------------------------------
     def _want_pipeline(self, batch: int) -> bool:
-        """Two half-batch shards on two streams (engine.PipelinedEngine) for large batches: ``self.pipeline`` = True /
-        False / None (auto: batch >= BT_PIPELINE_MIN_BATCH, default 1024; BT_PIPELINE=0/1 overrides)."""
+        """Two half-batch shards on two streams (engine.PipelinedEngine): opt-in (``self.pipeline = True`` or BT_PIPELINE=1).
+        Measured on MI355X (profiles/r2_overlap_probe.jsonl): without a bounded-footprint attention kernel
+        nothing overlaps, with one the two phases hide <= 30 % of the shorter one because the GEMM's own operand traffic
+        already takes half of the fabric bandwidth the global attention needs -- not enough to pay for the smaller GEMMs."""
         import os
-        env = os.environ.get("BT_PIPELINE")
-        want = self.pipeline if self.pipeline is not None else (None if env is None else env == "1")
-        if want is None:
-            want = batch >= int(os.environ.get("BT_PIPELINE_MIN_BATCH", 1024))
+        want = self.pipeline if self.pipeline is not None else os.environ.get("BT_PIPELINE") == "1"
         return bool(want) and batch >= 2
 
     def _get_engine(self, batch: int, max_blocks: int, streaming: bool = False):
         e = self._engine
         rt = self.block_decoder._rt
         policy = getattr(self.token_decoder, "rope_policy", DEFAULT_ROPE_POLICY)
+        # single stream when a streamer needs per-token host callbacks, and when EOS handling is on: HF stops a block early
+        # once EVERY row of the batch has produced EOS (Q6), a whole-batch condition two independent shards cannot evaluate
         pipelined = self._want_pipeline(batch) and not streaming
         if (e is None or e.B != batch or e.NB < max_blocks or e.dtype != rt.dtype or e.device != rt.device
                 or e.tok.policy != policy or e.pipelined != pipelined):
@@ -203,11 +204,11 @@ class BlockTransformer(nn.Module):
             total_blocks += 1
             if total_blocks * block_length >= max_length:
                 break
-        engine = self._get_engine(batch_size, total_blocks, streaming=streamer is not None)
+        gen = self.token_decoder.generation_config
+        engine = self._get_engine(batch_size, total_blocks, streaming=streamer is not None or gen.eos_token_id is not None)
         timers = _Timers(per_iteration=bool(benchmark)) if (benchmark or self.collect_timers) else None
         if benchmark:
             print(f"Benchmarking generation... (benchmark={benchmark})")
-        gen = self.token_decoder.generation_config
         if streamer is not None:
             streamer = _BlockStreamer(streamer, batch_size, self.token_decoder.config.eos_token_id)
         out, next_token_count = engine.generate(input_ids.contiguous(), block_attention_mask.contiguous(), max_length,

@@ -349,7 +349,12 @@ def test_real_dims_one_layer_bf16_logits():
     # first generated block: context + first-token logits
     eng = model._engine
     ref_ctx = trace["ctx"][-1]
-    assert (eng.ctx.float().cpu() - ref_ctx).abs().max() <= 6e-2 * ref_ctx.abs().max() + 2e-2
+    # the last context embedding depends on the first generated block's tokens: compare it for the sequences whose greedy
+    # tokens of that block agree with the oracle (a bf16 near-tie may flip one on random-init weights)
+    same = (got[:, 40:44] == want[:, 40:44]).all(dim=1)
+    assert same.float().mean() >= 0.5, same
+    d_ctx = (eng.ctx.float().cpu() - ref_ctx)[same].abs().max()
+    assert d_ctx <= 6e-2 * ref_ctx.abs().max() + 2e-2, d_ctx
     _, lg = o.token_decoder_generate(trace["ctx"][0], 1, return_logits=True)
     out = model.token_decoder(input_ids=torch.zeros(3, 1, dtype=torch.long, device=DEV),
                               block_embeddings=trace["ctx"][0][:, None, :].bfloat16().to(DEV))
@@ -604,8 +609,9 @@ def test_full_depth_1p2b_bf16_first_block_logits_vs_oracle(B):
     embedding and first-token logits against the fp32 CPU oracle on the same (bf16) weights (oracle on 2 of the B
     sequences: rows are independent).
     bf16 budget: 24 layers of bf16-rounded activations (2^-9 relative per rounding, ~10 roundings per layer,
-    accumulating as a random walk) -> |error| <= 4 % of max|value| + 0.02 absolute; the greedy token must agree wherever
-    the oracle's top-1 margin exceeds twice that budget."""
+    accumulating as a random walk) -> |error| <= 3 % of max|value| + 0.01 absolute (observed on MI355X: 1.1-1.8 % of
+    max: ctx 0.041 / 0.061, logits 0.048 / 0.057 at max|value| 3.4-4.2); the greedy token must agree wherever the oracle's
+    top-1 margin exceeds twice that budget."""
     model, dims, o = _full_1p2b()
     model.pipeline = False
     model.use_graphs = True
@@ -617,8 +623,8 @@ def test_full_depth_1p2b_bf16_first_block_logits_vs_oracle(B):
     ctx = eng.ctx.float().cpu()[rows]
     logits = eng.tok.logits.float().cpu()[rows]
     ref_ctx, ref_lg = _oracle_first_token(o, prompt[rows])
-    budget_ctx = 4e-2 * ref_ctx.abs().max().item() + 2e-2
-    budget_lg = 4e-2 * ref_lg.abs().max().item() + 2e-2
+    budget_ctx = 3e-2 * ref_ctx.abs().max().item() + 1e-2
+    budget_lg = 3e-2 * ref_lg.abs().max().item() + 1e-2
     e_ctx, e_lg = (ctx - ref_ctx).abs().max().item(), (logits - ref_lg).abs().max().item()
     print(f"[full-depth bf16 B={B}] ctx err {e_ctx:.4f} (budget {budget_ctx:.4f}, max {ref_ctx.abs().max():.3f}); "
           f"logit err {e_lg:.4f} (budget {budget_lg:.4f}, max {ref_lg.abs().max():.3f})")
@@ -733,11 +739,16 @@ def test_half_batch_pipeline_equals_single_engine(gpu_model, B, sync, monkeypatc
         eos = int(one[0, 14])
         old = (gcfg.eos_token_id, gcfg.pad_token_id)
         try:
+            # with EOS handling on, HF's "stop the block once EVERY row has produced EOS" (Q6) is a whole-batch condition:
+            # generate() falls back to the single-stream engine, so the result cannot depend on the sharding
             gcfg.eos_token_id, gcfg.pad_token_id = eos, 1
             two_e = model.generate(prompt, max_length=39).cpu()
+            assert not model._engine.pipelined
             model.pipeline = False
             one_e = model.generate(prompt, max_length=39).cpu()
             assert torch.equal(one_e, two_e)
+            o = oracle_from_dims(dims, sd, gen_eos_token_id=eos, gen_pad_token_id=1)
+            assert torch.equal(one_e, o.generate(prompt.cpu(), max_length=39))
         finally:
             gcfg.eos_token_id, gcfg.pad_token_id = old
     finally:

@@ -78,6 +78,25 @@ def probe_attn(B, n, iters, heads=16, d=128, n_split=1, dtype=torch.bfloat16):
             "algorithmic_MB": round(nbytes / 1e6, 1), "GBps": round(gbs, 1), "frac_hbm_peak": round(gbs / 8000.0, 3)}
 
 
+def probe_local(B, q_len, pos0, iters, heads=16, d=128, window=5):
+    """Token-decoder local attention (attend_rows_kernel<..., NW = 1>): q_len new rows at cache rows pos0.., window of E+L-1."""
+    H = heads * d
+    qkv = torch.randn(B * q_len, 3 * H, device=DEV).bfloat16()
+    kc = torch.randn(B, heads, window, d, device=DEV).bfloat16()
+    vc = torch.randn(B, heads, window, d, device=DEV).bfloat16()
+    out = torch.empty(B * q_len, H, device=DEV, dtype=torch.bfloat16)
+
+    def run():
+        check(lib().bt_attention(_lib.BT_BF16, 0, B, q_len, heads, d, ptr(qkv), 3 * H, ptr(kc), ptr(vc), window, None, pos0,
+                                 None, 0, ptr(out), H, 1, None, 0, current_stream()))
+
+    ms = timed(run, iters)
+    keys = sum(pos0 + t + 1 for t in range(q_len))
+    nbytes = 2.0 * B * heads * keys * d * 2 + 2.0 * B * q_len * H * 2     # K,V rows read + q read + out written
+    return {"op": "attn_rows_local", "B": B, "q_len": q_len, "pos0": pos0, "ms": round(ms, 4), "algorithmic_MB": round(nbytes / 1e6, 1),
+            "GBps": round(nbytes / (ms * 1e-3) / 1e9, 1)}
+
+
 def probe_flash(B, n, iters, heads=16, d=128):
     H = heads * d
     qkv = torch.randn(B * n, 3 * H, device=DEV).bfloat16()
@@ -105,7 +124,8 @@ def probe_copy(nbytes, iters):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("what", choices=["gemm", "attn", "flash", "suite", "copy", "ab", "abl", "skinny", "decode", "vendor", "pitch"])
+    ap.add_argument("what", choices=["gemm", "attn", "flash", "suite", "copy", "ab", "abl", "skinny", "decode", "vendor", "pitch",
+                                     "local"])
     ap.add_argument("--m", type=int, default=32768)
     ap.add_argument("--n", type=int, default=6144)
     ap.add_argument("--k", type=int, default=2048)
@@ -120,6 +140,10 @@ def main():
     lib().bt_debug_gemm_variant(args.variant)
     if args.what == "gemm":
         res.append(probe_gemm(args.m, args.n, args.k, args.iters))
+    elif args.what == "local":   # the four local steps of a token block at batch --batch: step 0 (q = E = 2), then rows 2, 3, 4
+        res.append(probe_local(args.batch, 2, 0, args.iters))
+        for pos0 in (2, 3, 4):
+            res.append(probe_local(args.batch, 1, pos0, args.iters))
     elif args.what == "attn":
         for nt in (0, 1, 0, 1):
             lib().bt_debug_attn_nt(nt)
