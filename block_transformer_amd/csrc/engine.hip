@@ -79,7 +79,36 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
     const bool few_rows = dtype == BT_BF16 && M <= g_few_rows_max && (M > 4 ? (H % 32 == 0 && I % 32 == 0) : (H % 512 == 0 && H <= 2048)) &&
                           dims->rot == 32 &&
                           dims->head_dim % 32 == 0 && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) && !g_no_few_rows_fusion;
-    for (int l = 0; l < dims->layers; ++l) {
+    // 17 .. 256 rows (mid-batch decode): split-K slabs + fused reduce kernels -- 7 launches per layer instead of 11, no
+    // separate LayerNorm / RoPE / KV-append launch (the step is bound by its count of dependent launches).  Like the few-rows
+    // path it runs every layer on every row (the tail-only shortcut is not worth a second launch sequence here).
+    const bool mid_rows = dtype == BT_BF16 && !few_rows && mid_rows_ok(M, H, I, dims->head_dim, dims->rot) && scratch &&
+                          mid_slab_bytes(M, H, I) >= 0 && mid_slab_bytes(M, H, I) <= sk_bytes &&
+                          ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+    if (mid_rows) {
+        hipStream_t hs = (hipStream_t)stream;
+        const bt_layer_weights& l0 = w->layers_host[0];
+        BT_TRY(bt_layernorm(dtype, M, H, x, H, l0.ln1_w, l0.ln1_b, ln1, H, l0.ln2_w, l0.ln2_b, ln2, H, dims->ln_eps, stream));
+        for (int l = 0; l < dims->layers; ++l) {
+            const bt_layer_weights& lw = w->layers_host[l];
+            char* kc = reinterpret_cast<char*>(attn->k_cache) + (int64_t)l * attn->layer_stride * es;
+            char* vc = reinterpret_cast<char*>(attn->v_cache) + (int64_t)l * attn->layer_stride * es;
+            BT_TRY(mid_qkv(hs, B, q_len, dims->heads, dims->head_dim, ln1, H, lw.qkv_w, lw.qkv_b, qkv, 3 * H, kc, vc, attn->n_max,
+                           attn->pos0_dev, attn->pos0_host, attn->pos_table, attn->cos_tab, attn->sin_tab, scratch, sk_bytes));
+            // the attention output overwrites ln1 (its only reader, the QKV GEMM, is done); ln2 stays until the MLP has read it
+            BT_TRY(bt_attention(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc, attn->n_max,
+                                attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H, attn->n_split,
+                                attn->split_ws, attn->split_ws_bytes, stream));
+            BT_TRY(mid_gelu(hs, M, I, H, ln2, H, lw.h4_w, lw.h4_b, h4, I, scratch, sk_bytes));
+            const bool more = l + 1 < dims->layers;
+            const bt_layer_weights& nx = w->layers_host[more ? l + 1 : l];
+            // x += h4 W2^T + b2 + att Wd^T + bd, then LN1 / LN2 of the NEXT layer (att == ln1 is free again after this GEMM)
+            BT_TRY(mid_res_ln(hs, M, H, I, h4, I, lw.h_w, lw.h_b, H, att, H, lw.dense_w, lw.dense_b, x, H,
+                              more ? nx.ln1_w : nullptr, more ? nx.ln1_b : nullptr, ln1, more ? nx.ln2_w : nullptr,
+                              more ? nx.ln2_b : nullptr, ln2, H, dims->ln_eps, scratch, sk_bytes));
+        }
+    }
+    for (int l = 0; l < dims->layers && !mid_rows; ++l) {
         const bt_layer_weights& lw = w->layers_host[l];
         char* kc = reinterpret_cast<char*>(attn->k_cache) + (int64_t)l * attn->layer_stride * es;
         char* vc = reinterpret_cast<char*>(attn->v_cache) + (int64_t)l * attn->layer_stride * es;
@@ -242,7 +271,7 @@ extern "C" int bt_token_block_enqueue(const bt_engine_desc* e, int32_t t_begin, 
                          BT_ACT_NONE, stream));
         if (e->do_sample) {
             BT_TRY(bt_topk_sample(e->dtype, B, e->vocab, e->logits, e->vocab, e->temperature, e->top_k, e->seed,
-                                  e->sample_step, e->raw + t, e->L, stream));
+                                  e->sample_step, e->sample_row0, e->raw + t, e->L, stream));
             BT_TRY(bt_bump(e->sample_step, 1, stream));
         } else {
             BT_TRY(bt_argmax(e->dtype, B, e->vocab, e->logits, e->vocab, e->raw + t, e->L, stream));

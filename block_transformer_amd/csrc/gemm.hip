@@ -288,6 +288,22 @@ __device__ inline void store_tile_from_lds(const EpiArgs& e, const char* ctile, 
     }
 }
 
+struct LnPro {
+    const bf16* w;
+    const bf16* b;
+    float eps;
+};
+
+// optional second (x2, W2) operand pair accumulated onto the same outputs: out = x . W^T + x2 . W2^T + bias + bias2 [+ res]
+// (the two residual-stream projections of a parallel-residual layer -- attention output and MLP down -- in one launch)
+struct Seg2 {
+    const bf16* x;
+    const bf16* w;
+    const bf16* bias;
+    int64_t ldx, ldw;
+    int K;
+};
+
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int GROUP_M = 8;
 
@@ -334,23 +350,67 @@ __device__ inline bf16x8_t read_frag(const char* lds_tile, int row_base, int kk,
 // SPLITK: blockIdx.y selects a K slice; the fp32 partial tile goes to `partial[slice][M][N]` and splitk_reduce_kernel
 // applies the epilogue.  This is the weight-streaming ("skinny") regime: M <= ~256 rows, where one pass over W is the cost
 // and a tile-per-CU grid would leave most CUs idle (M=1, N=2048, K=8192: 32 tiles -> 256 workgroups with 8 slices).
-template <int TBM, int TBN, bool SPLITK = false>
+__device__ inline void cbarrier() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// NS: depth of the LDS ring.  NS == 2 is the classic double buffer (load t+1 while computing t, drain every step); NS >= 3
+// keeps NS - 2 further K-tiles of LDS-DMA in flight ACROSS the per-step barrier (counted s_waitcnt vmcnt, raw s_barrier), which
+// is what a latency-bound small grid needs: with one or two workgroups per CU nothing else hides the ~1-2 us L2/HBM round trip.
+//   RAW: before a wave reads tile t it has waited for its own DMA share of tile t (in-order vmcnt: at most the DMAs of the
+//        younger tiles stay outstanding) and passed the barrier every other wave reaches after doing the same;
+//   WAR: tile t + NS - 1 goes into the buffer tile t - 1 was read from, and is issued after that barrier, i.e. after every
+//        wave has issued all MFMAs of step t - 1 (which consumed its ds_reads of that buffer).
+template <int N>
+__device__ inline void wait_vmcnt_n() {
+    static_assert(N >= 0 && N <= 48 && N % 2 == 0, "unsupported vmcnt immediate");
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if constexpr (N == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else if constexpr (N == 20) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+    else if constexpr (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int TBM, int TBN, bool SPLITK = false, int NS = 2>
 __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restrict__ A, int64_t lda,
                                                             const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
                                                             int K, int tiles_m, int tiles_n,
-                                                            float* __restrict__ partial = nullptr) {
+                                                            float* __restrict__ partial = nullptr, const Seg2 s2 = Seg2{},
+                                                            int slices1 = 1 << 30) {
     const int M = ep.M, N = ep.N;
     constexpr int A_BYTES = TBM * BK * 2, W_BYTES = TBN * BK * 2, STAGE = A_BYTES + W_BYTES;
     constexpr int FM = TBM / 32, FN = TBN / 32;  // 16x16 fragments per wave along m / n
-    __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+    constexpr int IPT = TBM / 32 + TBN / 32;     // LDS-DMA instructions per wave and K-tile
+    static_assert(NS >= 2 && NS <= 4, "ring depth");
+    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int tm, tn;
     tile_coords(tiles_m, tiles_n, tm, tn);
     const int m0 = tm * TBM, n0 = tn * TBN;
-    if (SPLITK) {  // this workgroup's K slice (K here is the slice length; the operands are advanced to the slice start)
-        A += (int64_t)blockIdx.y * K;
-        W += (int64_t)blockIdx.y * K;
+    if (SPLITK) {  // this workgroup's K slice (K here is the slice length; the operands are advanced to the slice start).
+        // Slices >= slices1 belong to the optional second operand pair (out = A.W^T + A2.W2^T: the two residual-stream
+        // projections of a parallel-residual layer summed by the reduce kernel); a slice never straddles the two.
+        const int sl = blockIdx.y;
+        if (sl >= slices1) {
+            A = s2.x + (int64_t)(sl - slices1) * K;
+            W = s2.w + (int64_t)(sl - slices1) * K;
+            lda = s2.ldx;
+            ldw = s2.ldw;
+        } else {
+            A += (int64_t)sl * K;
+            W += (int64_t)sl * K;
+        }
     }
 
     f32x4_t acc[FN][FM];
@@ -360,20 +420,46 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restr
         for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     const int nk = K / BK;
-    stage_tile<TBM>(A, lda, m0, M, 0, smem, wave, lane);
-    stage_tile<TBN>(W, ldw, n0, N, 0, smem + A_BYTES, wave, lane);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if constexpr (NS == 2) {
+        stage_tile<TBM>(A, lda, m0, M, 0, smem, wave, lane);
+        stage_tile<TBN>(W, ldw, n0, N, 0, smem + A_BYTES, wave, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int s0 = 0; s0 < NS - 1; ++s0)
+            if (s0 < nk) {
+                stage_tile<TBM>(A, lda, m0, M, s0 * BK, smem + s0 * STAGE, wave, lane);
+                stage_tile<TBN>(W, ldw, n0, N, s0 * BK, smem + s0 * STAGE + A_BYTES, wave, lane);
+            }
+    }
 
     for (int t = 0; t < nk; ++t) {
-        const int cur = t & 1;
-        char* a_cur = smem + cur * STAGE;
-        char* w_cur = a_cur + A_BYTES;
-        if (t + 1 < nk) {
-            char* a_nxt = smem + (cur ^ 1) * STAGE;
-            stage_tile<TBM>(A, lda, m0, M, (t + 1) * BK, a_nxt, wave, lane);
-            stage_tile<TBN>(W, ldw, n0, N, (t + 1) * BK, a_nxt + A_BYTES, wave, lane);
+        char* a_cur;
+        if constexpr (NS == 2) {
+            const int cur = t & 1;
+            a_cur = smem + cur * STAGE;
+            if (t + 1 < nk) {
+                char* a_nxt = smem + (cur ^ 1) * STAGE;
+                stage_tile<TBM>(A, lda, m0, M, (t + 1) * BK, a_nxt, wave, lane);
+                stage_tile<TBN>(W, ldw, n0, N, (t + 1) * BK, a_nxt + A_BYTES, wave, lane);
+            }
+        } else {
+            // tiles issued after tile t so far: min(nk - 1, t + NS - 2) - t  (each IPT DMA instructions of this wave)
+            const int younger = min(nk - 1, t + NS - 2) - t;
+            if (younger >= 2) wait_vmcnt_n<2 * IPT>();
+            else if (younger == 1) wait_vmcnt_n<IPT>();
+            else wait_vmcnt_n<0>();
+            cbarrier();
+            a_cur = smem + (t % NS) * STAGE;
+            const int tn_ = t + NS - 1;
+            if (tn_ < nk) {
+                char* a_nxt = smem + (tn_ % NS) * STAGE;
+                stage_tile<TBM>(A, lda, m0, M, tn_ * BK, a_nxt, wave, lane);
+                stage_tile<TBN>(W, ldw, n0, N, tn_ * BK, a_nxt + A_BYTES, wave, lane);
+            }
         }
+        char* w_cur = a_cur + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8_t wf[FN], af[FM];
@@ -387,7 +473,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restr
                 for (int j = 0; j < FM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], af[j], acc[i][j], 0, 0, 0);
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if constexpr (NS == 2) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+    if constexpr (NS > 2) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing is in flight any more (tail waits reached 0); fence for the LDS reuse
         __syncthreads();
     }
 
@@ -408,7 +500,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restr
     // epilogue: D[i = n][j = m]; lane holds column m = lane & 15 and rows n = (lane >> 4) * 4 + r
     if ((N & 7) == 0) {
         // the last K-step ended with vmcnt(0) + barrier: every DMA has landed and every ds_read is done -> LDS is free
-        static_assert(TBM * CTile<TBN>::PITCH <= 2 * STAGE, "output tile must fit in the staging LDS");
+        static_assert(TBM * CTile<TBN>::PITCH <= NS * STAGE, "output tile must fit in the staging LDS");
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
             const int ml = wm * (TBM / 2) + j * 16 + (lane & 15);
@@ -469,6 +561,166 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
         for (int i = 0; i < 8; ++i) v[i] += rv[i];
     }
     store_vec<bf16>(ep.out + (int64_t)m * ep.ldo + n, v);
+}
+
+// ---- fused reduce kernels of the mid-batch path (17 .. 256 rows, bt_decoder_forward) ----------------------------------------
+// The split-K GEMM above leaves fp32 slabs [slices][M][N]; these kernels sum them and do everything the layer needs next at
+// that point, so that no separate RoPE / KV-append / LayerNorm launch remains (a 17..256-row decode step is bound by the
+// number of dependent launches, ~5-10 us each, not by bytes or flops).
+__device__ inline void sum_slabs8(const float* __restrict__ partial, int slices, int64_t slab, int64_t off, float (&v)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = 0.f;
+    for (int s = 0; s < slices; ++s) {
+        const float* p = partial + (int64_t)s * slab + off;
+        const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
+        v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    }
+}
+
+// QKV: + bias, partial RoPE (rot == 32: pairs (e, e + 16) of the first 32 dims of q and k), q -> qkv buffer, (k_rot, v) -> cache
+// rows pos0 + t.  One thread = one row x 8 columns (one 16-byte output); a thread in a rotated zone also sums its partner's 8.
+__global__ __launch_bounds__(256) void mid_reduce_qkv_kernel(const float* __restrict__ partial, int slices, const EpiArgs ep) {
+    const int M = ep.M, N = ep.N;
+    const int cpr = N / 8;
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)M * cpr) return;
+    const int m = (int)(idx / cpr), n = (int)(idx - (int64_t)m * cpr) * 8;
+    const int64_t slab = (int64_t)M * N;
+    float v[8];
+    sum_slabs8(partial, slices, slab, (int64_t)m * N + n, v);
+    if (ep.bias) {
+        float bv[8];
+        load_vec<bf16>(ep.bias + n, bv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] += bv[i];
+    }
+    const int D = ep.q.head_dim;
+    const int head = n / (3 * D);
+    const int within = n - head * 3 * D;
+    const int part = within / D;              // 0 q, 1 k, 2 v
+    const int el = within - part * D;         // multiple of 8
+    const int64_t b = m / ep.q.q_len;
+    const int t = m - (int)b * ep.q.q_len;
+    const int pos0 = ep.q.pos0_dev ? *ep.q.pos0_dev : ep.q.pos0_host;
+    if (part < 2 && el < 32) {
+        const bool lo = el < 16;
+        const int np = lo ? n + 16 : n - 16;
+        float w[8];
+        sum_slabs8(partial, slices, slab, (int64_t)m * N + np, w);
+        if (ep.bias) {
+            float bv[8];
+            load_vec<bf16>(ep.bias + np, bv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) w[i] += bv[i];
+        }
+        const int rpos = ep.q.pos_table ? ep.q.pos_table[pos0 + t] : pos0 + t;
+        const int e0 = lo ? el : el - 16;
+        const float* ct = ep.q.cos_tab + (int64_t)rpos * 16 + e0;
+        const float* st = ep.q.sin_tab + (int64_t)rpos * 16 + e0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float c = ct[i], sn = st[i];
+            // lo: own = x1, partner = x2 -> x1 c - x2 s ; hi: own = x2, partner = x1 -> x2 c + x1 s
+            v[i] = lo ? v[i] * c - w[i] * sn : v[i] * c + w[i] * sn;
+        }
+    }
+    bf16* dst = part == 0 ? ep.out + (int64_t)m * ep.ldo + n
+                          : (part == 1 ? ep.q.kc : ep.q.vc) + ((b * ep.q.heads + head) * ep.q.n_max + pos0 + t) * D + el;
+    store_vec<bf16>(dst, v);
+}
+
+// Residual stream: x[m, :] += sum(slabs) + bias + bias2 (in place, rounded to bf16 like the unfused epilogues), then the NEXT
+// layer's two LayerNorms of the new row (ln1 / ln2; skipped when ln.w == nullptr).  One workgroup per row, 8 columns per
+// thread and 2048-column chunk, the row stays in registers (H <= 8192).
+struct Ln2Out {
+    const bf16 *w1, *b1, *w2, *b2;
+    bf16 *o1, *o2;
+    int64_t ldo1, ldo2;
+    float eps;
+};
+
+__global__ __launch_bounds__(256) void mid_reduce_res_ln_kernel(const float* __restrict__ partial, int slices, const EpiArgs ep,
+                                                               const bf16* __restrict__ bias2, const Ln2Out ln) {
+    __shared__ float red[2][4];
+    const int N = ep.N, m = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t slab = (int64_t)ep.M * N;
+    constexpr int MAXC = 4;
+    float x[MAXC][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < MAXC; ++ch) {
+        const int n = ch * 2048 + tid * 8;
+        if (n < N) {
+            float v[8];
+            sum_slabs8(partial, slices, slab, (int64_t)m * N + n, v);
+            float bv[8];
+            if (ep.bias) {
+                load_vec<bf16>(ep.bias + n, bv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += bv[i];
+            }
+            if (bias2) {
+                load_vec<bf16>(bias2 + n, bv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += bv[i];
+            }
+            if (ep.res) {
+                load_vec<bf16>(ep.res + (int64_t)m * ep.ldr + n, bv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[i] += bv[i];
+            }
+            store_vec<bf16>(ep.out + (int64_t)m * ep.ldo + n, v);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                x[ch][i] = bf16_to_f32(f32_to_bf16(v[i]));   // LayerNorm sees the stored (bf16) row, as bt_layernorm would
+                sum += x[ch][i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) x[ch][i] = 0.f;
+        }
+    }
+    if (!ln.w1) return;
+    sum = wave_sum(sum);
+    if (lane == 0) red[0][wave] = sum;
+    __syncthreads();
+    const float mean = (red[0][0] + red[0][1] + red[0][2] + red[0][3]) / (float)N;
+    float sq = 0.f;
+#pragma unroll
+    for (int ch = 0; ch < MAXC; ++ch) {
+        if (ch * 2048 + tid * 8 < N) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float d = x[ch][i] - mean;
+                sq = fmaf(d, d, sq);
+            }
+        }
+    }
+    sq = wave_sum(sq);
+    if (lane == 0) red[1][wave] = sq;
+    __syncthreads();
+    const float rstd = rsqrtf((red[1][0] + red[1][1] + red[1][2] + red[1][3]) / (float)N + ln.eps);
+#pragma unroll
+    for (int ch = 0; ch < MAXC; ++ch) {
+        const int n = ch * 2048 + tid * 8;
+        if (n < N) {
+            float g[8], bb[8], r[8];
+            load_vec<bf16>(ln.w1 + n, g);
+            load_vec<bf16>(ln.b1 + n, bb);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) r[i] = fmaf((x[ch][i] - mean) * rstd, g[i], bb[i]);
+            store_vec<bf16>(ln.o1 + (int64_t)m * ln.ldo1 + n, r);
+            if (ln.o2) {
+                load_vec<bf16>(ln.w2 + n, g);
+                load_vec<bf16>(ln.b2 + n, bb);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) r[i] = fmaf((x[ch][i] - mean) * rstd, g[i], bb[i]);
+                store_vec<bf16>(ln.o2 + (int64_t)m * ln.ldo2 + n, r);
+            }
+        }
+    }
 }
 
 // ---- 256x256 deep-pipelined kernel ---------------------------------------------------------------------------------------
@@ -538,12 +790,6 @@ __device__ inline void wait_for_phase(int g, int total) {
     else if (allow == 2) wait_vmcnt<4>();
     else if (allow == 1) wait_vmcnt<2>();
     else wait_vmcnt<0>();
-}
-
-__device__ inline void cbarrier() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
 }
 
 #ifdef BT_DEBUG_HOOKS   // four-phase ring + timing ablations: A/B probes only, not in the product library
@@ -1548,21 +1794,6 @@ __device__ inline float dot8_bf16(const uint4& w, const uint4& x, float acc) {
 // the row PAIR (n, n + 16) of a 32-column group, so the lane that finishes row m can rotate the pair (RoPE) and scatter
 // q to the qkv buffer / k, v to their KV-cache rows itself: removes the RoPE + append launch.  Small-batch decode is
 // launch-bound (~5 us per dependent launch): 7 -> 5 launches per layer.
-struct LnPro {
-    const bf16* w;
-    const bf16* b;
-    float eps;
-};
-
-// optional second (x2, W2) operand pair accumulated onto the same outputs: out = x . W^T + x2 . W2^T + bias + bias2 [+ res]
-// (the two residual-stream projections of a parallel-residual layer -- attention output and MLP down -- in one launch)
-struct Seg2 {
-    const bf16* x;
-    const bf16* w;
-    const bf16* bias;
-    int64_t ldx, ldw;
-    int K;
-};
 
 template <int MR, int RW, bool LN = false, bool QKV = false>
 __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W,
@@ -2078,6 +2309,8 @@ BT_KNOB int g_skinny_rows = 16;   // bt_linear takes the MFMA weight streamer fo
                                   // B = 8: +21 %, 16: +4 %, 32: -20 %, 64: -30 % vs split-K + reduce -> 16)
 BT_KNOB int g_max_wg = 0;         // cap the persistent kernel's grid so small problems walk several tiles per workgroup
 BT_KNOB bool g_no_qkv_fusion = false;
+BT_KNOB bool g_mid_rows = true;   // 17..256-row stacks take the slab + fused-reduce path (false: A/B against the unfused launches)
+BT_KNOB int g_small_stages = 0;   // LDS ring depth of the 128^2 / 128x64 / 64x64 kernels: 0 = per-tile default, 2..4 forced (A/B)
 BT_KNOB int g_gemm_variant = 0;   // 0 auto; 1 force 128^2; 2/3 256^2 four-phase ring (plain/staggered); 4-8 timing ablations; 9/10 256^2
 // two-phase ring, one tile per workgroup (staggered/plain); 14 persistent on 32x32x16 MFMA; default: persistent two-phase ring.
 
@@ -2224,14 +2457,22 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                    (int64_t)(slices * 2) * M * N * 4 <= scratch_bytes)
                 slices *= 2;
             if (slices > 1) {
-                hipLaunchKernelGGL((gemm_bf16_mfma_kernel<64, 64, true>), dim3(tiles_m * tiles_n, slices), dim3(256), 0, s,
-                                   (const bf16*)A, lda, (const bf16*)W, K, ep, (int)(K / slices), tiles_m, tiles_n,
-                                   (float*)scratch);
+                if (g_small_stages == 2)
+                    hipLaunchKernelGGL((gemm_bf16_mfma_kernel<64, 64, true, 2>), dim3(tiles_m * tiles_n, slices), dim3(256), 0, s,
+                                       (const bf16*)A, lda, (const bf16*)W, K, ep, (int)(K / slices), tiles_m, tiles_n,
+                                       (float*)scratch);
+                else
+                    hipLaunchKernelGGL((gemm_bf16_mfma_kernel<64, 64, true, 4>), dim3(tiles_m * tiles_n, slices), dim3(256), 0, s,
+                                       (const bf16*)A, lda, (const bf16*)W, K, ep, (int)(K / slices), tiles_m, tiles_n,
+                                       (float*)scratch);
                 BT_LAUNCH_CHECK("bt_linear split-K launch");
                 hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div(M * (N / 8), 256)), dim3(256), 0, s,
                                    (const float*)scratch, slices, ep);
+            } else if (g_small_stages == 2) {
+                hipLaunchKernelGGL((gemm_bf16_mfma_kernel<64, 64, false, 2>), dim3(tiles_m * tiles_n), dim3(256), 0, s,
+                                   (const bf16*)A, lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n, nullptr);
             } else {
-                hipLaunchKernelGGL((gemm_bf16_mfma_kernel<64, 64, false>), dim3(tiles_m * tiles_n), dim3(256), 0, s,
+                hipLaunchKernelGGL((gemm_bf16_mfma_kernel<64, 64, false, 4>), dim3(tiles_m * tiles_n), dim3(256), 0, s,
                                    (const bf16*)A, lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n, nullptr);
             }
         } else if (mfma_ok) {
@@ -2244,12 +2485,15 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
             }
             const int tiles_m = (int)ceil_div(M, tbm), tiles_n = (int)ceil_div(N, tbn);
             BT_CHECK_ARG((int64_t)tiles_m * tiles_n < (1ll << 31), "bt_linear: grid too large");
-#define BT_LAUNCH_GEMM(TM_, TN_)                                                                                        \
-    hipLaunchKernelGGL((gemm_bf16_mfma_kernel<TM_, TN_, false>), dim3(tiles_m * tiles_n), dim3(256), 0, s, (const bf16*)A, \
-                       lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n, nullptr)
-            if (tbm == 128 && tbn == 128) BT_LAUNCH_GEMM(128, 128);
-            else if (tbm == 128) BT_LAUNCH_GEMM(128, 64);
-            else BT_LAUNCH_GEMM(64, 64);
+#define BT_LAUNCH_GEMM(TM_, TN_, NS_)                                                                                   \
+    hipLaunchKernelGGL((gemm_bf16_mfma_kernel<TM_, TN_, false, NS_>), dim3(tiles_m * tiles_n), dim3(256), 0, s,             \
+                       (const bf16*)A, lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n, nullptr)
+            // ring depth per tile: 64x64 x 4 stages and 128x64 x 3 stages still fit two workgroups per CU (64 / 72 KiB);
+            // 128x128 x 3 stages = 96 KiB = one workgroup per CU
+            const int ns = g_small_stages ? g_small_stages : (tbm == 64 ? 4 : 3);
+            if (tbm == 128 && tbn == 128) { if (ns == 2) BT_LAUNCH_GEMM(128, 128, 2); else BT_LAUNCH_GEMM(128, 128, 3); }
+            else if (tbm == 128) { if (ns == 2) BT_LAUNCH_GEMM(128, 64, 2); else BT_LAUNCH_GEMM(128, 64, 3); }
+            else { if (ns == 2) BT_LAUNCH_GEMM(64, 64, 2); else BT_LAUNCH_GEMM(64, 64, 4); }
 #undef BT_LAUNCH_GEMM
         } else {
             ProfScope ps(BT_PROF_LINEAR_GENERIC, s);
@@ -2509,11 +2753,158 @@ extern "C" int bt_linear2(int dtype, int64_t M, int64_t N, int64_t K1, const voi
     return BT_OK;
 }
 
+// ---- mid-batch path (17 .. 256 rows): split-K slabs + fused reduces; called by bt_decoder_forward (engine.hip) ------------------
+namespace bt {
+
+// K-slice length: the largest of {8192 .. 256} that divides both operand pairs' K and still gives every CU a workgroup
+static int mid_slice_len(int64_t tiles, int64_t K1, int64_t K2) {
+    int best = 0;
+    for (int ks = 8192; ks >= 256; ks >>= 1) {
+        if (K1 % ks != 0 || (K2 > 0 && K2 % ks != 0)) continue;
+        if (best != 0 && ks < 512) break;   // slices shorter than 8 K-steps are all prologue: only when nothing longer divides K
+        best = ks;
+        if (tiles * (K1 / ks + (K2 > 0 ? K2 / ks : 0)) >= 256) break;   // one workgroup per CU (two fit) is enough to stream W
+    }
+    return best;
+}
+
+bool mid_rows_ok(int64_t M, int64_t H, int64_t I, int head_dim, int rot) {
+    return M >= 17 && M <= 256 && rot == 32 && head_dim % 32 == 0 && H % 256 == 0 && I % 256 == 0 && H <= 8192 &&
+           !g_force_generic && g_gemm_variant == 0 && g_mid_rows;
+}
+
+int64_t mid_slab_bytes(int64_t M, int64_t H, int64_t I) {
+    // worst case over the three GEMMs of a layer: slices x M x N fp32 (slice counts from mid_slice_len)
+    int64_t worst = 0;
+    const int64_t tm = ceil_div(M, 64);
+    const int64_t shapes[3][3] = {{3 * H, H, 0}, {I, H, 0}, {H, I, H}};
+    for (auto& sh : shapes) {
+        const int ks = mid_slice_len(tm * ceil_div(sh[0], 64), sh[1], sh[2]);
+        if (ks == 0) return -1;
+        const int64_t sl = sh[1] / ks + (sh[2] ? sh[2] / ks : 0);
+        worst = std::max(worst, sl * M * sh[0] * 4);
+    }
+    return worst;
+}
+
+// slabs[slices][M][N] = A . W^T (K1)  [+ A2 . W2^T (K2)]   -- returns the slice count through *slices
+static int mid_gemm(hipStream_t s, int64_t M, int64_t N, const void* A, int64_t lda, const void* W, int64_t K1, const void* A2,
+                    int64_t lda2, const void* W2, int64_t K2, void* slabs, int64_t slab_bytes, int* slices) {
+    const int tiles_m = (int)ceil_div(M, 64), tiles_n = (int)ceil_div(N, 64);
+    const int ks = mid_slice_len((int64_t)tiles_m * tiles_n, K1, K2);
+    BT_CHECK_ARG(ks > 0, "mid-batch GEMM: K = %lld / %lld has no common slice length", (long long)K1, (long long)K2);
+    const int sl1 = (int)(K1 / ks), sl2 = K2 > 0 ? (int)(K2 / ks) : 0;
+    if ((int64_t)(sl1 + sl2) * M * N * 4 > slab_bytes) {
+        set_error("mid-batch GEMM: slab workspace too small (%lld bytes for %d slices of %lld x %lld)", (long long)slab_bytes,
+                  sl1 + sl2, (long long)M, (long long)N);
+        return BT_ERR_WORKSPACE;
+    }
+    EpiArgs ep{};
+    ep.M = (int)M;
+    ep.N = (int)N;
+    Seg2 s2{};
+    s2.x = (const bf16*)A2;
+    s2.w = (const bf16*)W2;
+    s2.ldx = lda2;
+    s2.ldw = K2;
+    s2.K = (int)K2;
+    ProfScope ps(BT_PROF_LINEAR_MFMA, s);
+    hipLaunchKernelGGL((gemm_bf16_mfma_kernel<64, 64, true, 4>), dim3(tiles_m * tiles_n, sl1 + sl2), dim3(256), 0, s,
+                       (const bf16*)A, lda, (const bf16*)W, K1, ep, ks, tiles_m, tiles_n, (float*)slabs, s2, sl1);
+    BT_LAUNCH_CHECK("mid-batch GEMM launch");
+    *slices = sl1 + sl2;
+    return BT_OK;
+}
+
+int mid_qkv(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, const void* x, int64_t ldx, const void* w,
+            const void* bias, void* qkv, int64_t ld_qkv, void* kc, void* vc, int64_t n_max, const int32_t* pos0_dev, int pos0_host,
+            const int32_t* pos_table, const float* cos_tab, const float* sin_tab, void* slabs, int64_t slab_bytes) {
+    const int64_t H = (int64_t)heads * head_dim, M = B * q_len;
+    int slices = 0;
+    BT_TRY(mid_gemm(s, M, 3 * H, x, ldx, w, H, nullptr, 0, nullptr, 0, slabs, slab_bytes, &slices));
+    EpiArgs ep{};
+    ep.bias = (const bf16*)bias;
+    ep.out = (bf16*)qkv;
+    ep.ldo = ld_qkv;
+    ep.M = (int)M;
+    ep.N = (int)(3 * H);
+    ep.q.kc = (bf16*)kc;
+    ep.q.vc = (bf16*)vc;
+    ep.q.n_max = n_max;
+    ep.q.pos0_dev = pos0_dev;
+    ep.q.pos_table = pos_table;
+    ep.q.cos_tab = cos_tab;
+    ep.q.sin_tab = sin_tab;
+    ep.q.pos0_host = pos0_host;
+    ep.q.q_len = q_len;
+    ep.q.heads = heads;
+    ep.q.head_dim = head_dim;
+    ep.q.enabled = 1;
+    ProfScope ps(BT_PROF_ROPE, s);
+    hipLaunchKernelGGL(mid_reduce_qkv_kernel, dim3((unsigned)ceil_div(M * (3 * H / 8), 256)), dim3(256), 0, s,
+                       (const float*)slabs, slices, ep);
+    BT_LAUNCH_CHECK("mid-batch QKV reduce launch");
+    return BT_OK;
+}
+
+int mid_gelu(hipStream_t s, int64_t M, int64_t N, int64_t K, const void* x, int64_t ldx, const void* w, const void* bias, void* out,
+             int64_t ldo, void* slabs, int64_t slab_bytes) {
+    int slices = 0;
+    BT_TRY(mid_gemm(s, M, N, x, ldx, w, K, nullptr, 0, nullptr, 0, slabs, slab_bytes, &slices));
+    EpiArgs ep{};
+    ep.bias = (const bf16*)bias;
+    ep.out = (bf16*)out;
+    ep.ldo = ldo;
+    ep.M = (int)M;
+    ep.N = (int)N;
+    ep.act = BT_ACT_GELU;
+    ProfScope ps(BT_PROF_LINEAR_MFMA, s);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div(M * (N / 8), 256)), dim3(256), 0, s, (const float*)slabs,
+                       slices, ep);
+    BT_LAUNCH_CHECK("mid-batch GELU reduce launch");
+    return BT_OK;
+}
+
+// x += x1 . W1^T + b1 + x2 . W2^T + b2 ; then (optionally) the next LayerNorm pair of the new rows
+int mid_res_ln(hipStream_t s, int64_t M, int64_t N, int64_t K1, const void* x1, int64_t ldx1, const void* w1, const void* b1,
+               int64_t K2, const void* x2, int64_t ldx2, const void* w2, const void* b2, void* x, int64_t ldx, const void* ln1_w,
+               const void* ln1_b, void* ln1_out, const void* ln2_w, const void* ln2_b, void* ln2_out, int64_t ld_ln, float eps,
+               void* slabs, int64_t slab_bytes) {
+    int slices = 0;
+    BT_TRY(mid_gemm(s, M, N, x1, ldx1, w1, K1, x2, ldx2, w2, K2, slabs, slab_bytes, &slices));
+    EpiArgs ep{};
+    ep.bias = (const bf16*)b1;
+    ep.res = (const bf16*)x;
+    ep.ldr = ldx;
+    ep.out = (bf16*)x;
+    ep.ldo = ldx;
+    ep.M = (int)M;
+    ep.N = (int)N;
+    Ln2Out ln{};
+    ln.w1 = (const bf16*)ln1_w;
+    ln.b1 = (const bf16*)ln1_b;
+    ln.o1 = (bf16*)ln1_out;
+    ln.w2 = (const bf16*)ln2_w;
+    ln.b2 = (const bf16*)ln2_b;
+    ln.o2 = (bf16*)ln2_out;
+    ln.ldo1 = ln.ldo2 = ld_ln;
+    ln.eps = eps;
+    ProfScope ps(BT_PROF_LAYERNORM, s);
+    hipLaunchKernelGGL(mid_reduce_res_ln_kernel, dim3((unsigned)M), dim3(256), 0, s, (const float*)slabs, slices, ep,
+                       (const bf16*)b2, ln);
+    BT_LAUNCH_CHECK("mid-batch residual + LayerNorm reduce launch");
+    return BT_OK;
+}
+
+}  // namespace bt
+
 #ifdef BT_DEBUG_HOOKS
 // test / A-B hooks (libbt_hip_dbg.so only): force the generic kernel for bf16, pick a kernel variant, cap the persistent grid
 extern "C" void bt_debug_force_generic_gemm(int on) { g_force_generic = on != 0; }
 extern "C" void bt_debug_gemm_variant(int v) { g_gemm_variant = v; }
 extern "C" void bt_debug_gemm_max_wg(int n) { g_max_wg = n; }
 extern "C" void bt_debug_skinny_rows(int n) { g_skinny_rows = n; }
+extern "C" void bt_debug_small_stages(int n) { g_small_stages = n; }
+extern "C" void bt_debug_mid_rows(int on) { g_mid_rows = on != 0; }
 extern "C" void bt_debug_no_qkv_fusion(int on) { g_no_qkv_fusion = on != 0; }
 #endif

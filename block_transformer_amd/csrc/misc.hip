@@ -87,7 +87,7 @@ constexpr int MAX_CAND = 1024;
 template <typename T>
 __global__ __launch_bounds__(256) void topk_sample_kernel(const T* __restrict__ logits, int64_t ld, int V_, float inv_temp,
                                                          int top_k, uint64_t seed, const int32_t* __restrict__ step_dev,
-                                                         int64_t* __restrict__ ids_out, int64_t ids_stride) {
+                                                         int64_t row0, int64_t* __restrict__ ids_out, int64_t ids_stride) {
     __shared__ int hist[256];
     __shared__ uint32_t s_prefix, s_mask;
     __shared__ int s_k;
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void topk_sample_kernel(const T* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const T* row = logits + (int64_t)blockIdx.x * ld;
     const uint64_t rnd = splitmix64(splitmix64(seed ^ (uint64_t)(step_dev ? *step_dev : 0) * 0x100000001b3ull) +
-                                    (uint64_t)blockIdx.x);
+                                    (uint64_t)(row0 + blockIdx.x));
     const float u01 = (float)((rnd >> 40) & 0xffffff) * (1.0f / 16777216.0f);
 
     if (top_k > 0 && top_k < V_) {
@@ -353,7 +353,7 @@ extern "C" int bt_argmax(int dtype, int64_t M, int64_t V, const void* logits, in
 }
 
 extern "C" int bt_topk_sample(int dtype, int64_t M, int64_t V, const void* logits, int64_t ld, float temperature,
-                              int32_t top_k, uint64_t seed, const int32_t* step_dev, int64_t* ids_out,
+                              int32_t top_k, uint64_t seed, const int32_t* step_dev, int64_t row0, int64_t* ids_out,
                               int64_t ids_stride, bt_stream stream) {
     BT_CHECK_ARG(dtype == BT_F32 || dtype == BT_BF16, "bt_topk_sample: bad dtype %d", dtype);
     BT_CHECK_ARG(M >= 0 && V > 0 && V < (1ll << 31) && ld >= V && M < (1ll << 31), "bt_topk_sample: bad shape");
@@ -369,10 +369,10 @@ extern "C" int bt_topk_sample(int dtype, int64_t M, int64_t V, const void* logit
     ProfScope ps(BT_PROF_SAMPLE, s);
     if (dtype == BT_BF16)
         hipLaunchKernelGGL(topk_sample_kernel<bf16>, dim3((unsigned)M), dim3(256), 0, s, (const bf16*)logits, ld, (int)V,
-                           1.0f / temperature, top_k, seed, step_dev, ids_out, ids_stride);
+                           1.0f / temperature, top_k, seed, step_dev, row0, ids_out, ids_stride);
     else
         hipLaunchKernelGGL(topk_sample_kernel<float>, dim3((unsigned)M), dim3(256), 0, s, (const float*)logits, ld,
-                           (int)V, 1.0f / temperature, top_k, seed, step_dev, ids_out, ids_stride);
+                           (int)V, 1.0f / temperature, top_k, seed, step_dev, row0, ids_out, ids_stride);
     BT_LAUNCH_CHECK("bt_topk_sample launch");
     return BT_OK;
 }

@@ -270,6 +270,7 @@ class DecodeEngine:
         self.finished.zero_()
         self.finished_prev.zero_()
         self.n_cur.fill_(nb)
+        self.tok.sample_step.zero_()    # the sampler's draw counter restarts: a generate() call is a function of (inputs, seed)
         bc = max(1, min(B, self.prefill_rows // max(nb, 1)))
         if scratch is None:
             need = self.bd_rt.workspace_bytes(bc * nb)
@@ -386,6 +387,8 @@ class PipelinedEngine:
         self.bounds = bounds
         self.shards: List[DecodeEngine] = [DecodeEngine(model, bounds[i + 1] - bounds[i], max_blocks, rope_policy)
                                            for i in range(n_shards)]
+        for i, s in enumerate(self.shards):
+            s.desc.sample_row0 = bounds[i]     # shards draw the RNG streams the whole batch would
         s0 = self.shards[0]
         self.device, self.dtype, self.L = s0.device, s0.dtype, s0.L
         self.tok = s0.tok             # policy / dims probe used by BlockTransformer._get_engine

@@ -94,13 +94,13 @@ def argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None):
 
 
 def topk_sample(logits: torch.Tensor, temperature: float = 1.0, top_k: int = 50, seed: int = 0,
-                step: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None):
+                step: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, row0: int = 0):
     l2, ld = _rows(logits)
     M, V = l2.shape
     if out is None:
         out = torch.empty(M, dtype=torch.int64, device=logits.device)
     check(lib().bt_topk_sample(dtype_code(logits.dtype), M, V, ptr(l2), ld, float(temperature), int(top_k), int(seed),
-                               ptr(step), ptr(out), out.stride(0), current_stream()), "bt_topk_sample")
+                               ptr(step), int(row0), ptr(out), out.stride(0), current_stream()), "bt_topk_sample")
     return out
 
 

@@ -187,7 +187,9 @@ int bt_argmax(int dtype, int64_t M, int64_t V, const void* logits, int64_t ld, i
  * (every score above the k-th largest + the lowest-index ties, at most 1024 candidates; top_k in (1024, V) is
  * refused with BT_ERR_UNSUPPORTED; top_k <= 0 or >= V = no filter).  Distributional parity only.  (C12) */
 int bt_topk_sample(int dtype, int64_t M, int64_t V, const void* logits, int64_t ld, float temperature, int32_t top_k,
-                   uint64_t seed, const int32_t* step_dev, int64_t* ids_out, int64_t ids_stride, bt_stream stream);
+                   uint64_t seed, const int32_t* step_dev, int64_t row0, int64_t* ids_out, int64_t ids_stride,
+                   bt_stream stream);   /* row0: RNG row index of logits row 0 (request shards of one batch draw the same
+                                           streams as the whole batch would: key = (seed, *step_dev, row0 + r)) */
 
 /* ---- composite: one GPT-NeoX stack over M = B*q_len rows (what GPTNeoXModel.forward does for inputs_embeds) ---- */
 typedef struct bt_attn_args {
@@ -279,6 +281,7 @@ typedef struct bt_engine_desc {
     void* split_ws; int64_t split_ws_bytes;
     float temperature;
     int32_t reserved0;
+    int64_t sample_row0;     /* RNG row index of this engine's sequence 0 (shards of one batch; 0 otherwise) */
     uint64_t seed;
     int32_t* sample_step;    /* device counter of sampling draws (RNG stream position); required when do_sample */
     int64_t config_pad;      /* token_decoder.config.pad_token_id (fills the unfilled tail of a partial block) */

@@ -69,7 +69,7 @@ def test_library_exports_every_declared_symbol():
     assert rc == -1 and b"head_dim" in lib.bt_last_error()
     rc = lib.bt_block_step_enqueue(None, 4, 1, None)
     assert rc == -1 and b"descriptor" in lib.bt_last_error()
-    rc = lib.bt_topk_sample(1, 1, 50304, 1, 50304, 1.0, 2000, 0, None, 1, 1, None)   # top_k beyond the candidate buffer
+    rc = lib.bt_topk_sample(1, 1, 50304, 1, 50304, 1.0, 2000, 0, None, 0, 1, 1, None)   # top_k beyond the candidate buffer
     assert rc == -2 and b"top_k" in lib.bt_last_error()
     # split-N rule shared by the library and the engine's workspace sizing
     assert lib.bt_attention_split_count(128, 544, 1) == 1 and lib.bt_attention_split_count(128, 544, 4) == 4
