@@ -171,9 +171,10 @@ bool mid_rows_ok(int64_t M, int64_t H, int64_t I, int head_dim, int rot);
 int64_t mid_slab_bytes(int64_t M, int64_t H, int64_t I);
 int mid_qkv(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, const void* x, int64_t ldx, const void* w,
             const void* bias, void* qkv, int64_t ld_qkv, void* kc, void* vc, int64_t n_max, const int32_t* pos0_dev, int pos0_host,
-            const int32_t* pos_table, const float* cos_tab, const float* sin_tab, void* slabs, int64_t slab_bytes);
+            const int32_t* pos_table, const float* cos_tab, const float* sin_tab, void* slabs, int64_t slab_bytes, int* counters);
 int mid_gelu(hipStream_t s, int64_t M, int64_t N, int64_t K, const void* x, int64_t ldx, const void* w, const void* bias, void* out,
-             int64_t ldo, void* slabs, int64_t slab_bytes);
+             int64_t ldo, void* slabs, int64_t slab_bytes, int* counters);
+constexpr int64_t MID_COUNTER_BYTES = 4096;   // one int per 64 x 64 tile of a <= 256-row GEMM with N <= 16384
 int mid_res_ln(hipStream_t s, int64_t M, int64_t N, int64_t K1, const void* x1, int64_t ldx1, const void* w1, const void* b1,
                int64_t K2, const void* x2, int64_t ldx2, const void* w2, const void* b2, void* x, int64_t ldx, const void* ln1_w,
                const void* ln1_b, void* ln1_out, const void* ln2_w, const void* ln2_b, void* ln2_out, int64_t ld_ln, float eps,

@@ -9,6 +9,8 @@
 // Activation workspace for M rows (elements): [ln1|att: M*H][ln2: M*H][qkv: M*3H][h4: M*I].
 #include "bt_common.h"
 
+#include <algorithm>
+
 using namespace bt;
 
 // rows up to which a stack takes the fused single-launch projections (the entry points accept <= 64; beyond ~16 rows
@@ -83,10 +85,19 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
     // separate LayerNorm / RoPE / KV-append launch (the step is bound by its count of dependent launches).  Like the few-rows
     // path it runs every layer on every row (the tail-only shortcut is not worth a second launch sequence here).
     const bool mid_rows = dtype == BT_BF16 && !few_rows && mid_rows_ok(M, H, I, dims->head_dim, dims->rot) && scratch &&
-                          mid_slab_bytes(M, H, I) >= 0 && mid_slab_bytes(M, H, I) <= sk_bytes &&
+                          mid_slab_bytes(M, H, I) >= 0 && mid_slab_bytes(M, H, I) + MID_COUNTER_BYTES <= sk_bytes &&
+                          ceil_div(M, 64) * ceil_div(std::max(3 * H, I), 64) * 4 <= MID_COUNTER_BYTES &&
                           ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
     if (mid_rows) {
         hipStream_t hs = (hipStream_t)stream;
+        // tile counters of the in-launch split-K reductions: the last 4 KiB of the scratch region, cleared once per pass (each
+        // reduction leaves its counters at zero again; the clear makes a pass independent of whatever ran before it)
+        int* counters = reinterpret_cast<int*>(sk + sk_bytes - MID_COUNTER_BYTES);
+        const int64_t slab_room = sk_bytes - MID_COUNTER_BYTES;
+        {
+            hipError_t me = hipMemsetAsync(counters, 0, MID_COUNTER_BYTES, hs);
+            if (me != hipSuccess) return bt::hip_fail(me, "hipMemsetAsync(mid-batch counters)");
+        }
         const bt_layer_weights& l0 = w->layers_host[0];
         BT_TRY(bt_layernorm(dtype, M, H, x, H, l0.ln1_w, l0.ln1_b, ln1, H, l0.ln2_w, l0.ln2_b, ln2, H, dims->ln_eps, stream));
         for (int l = 0; l < dims->layers; ++l) {
@@ -94,18 +105,19 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
             char* kc = reinterpret_cast<char*>(attn->k_cache) + (int64_t)l * attn->layer_stride * es;
             char* vc = reinterpret_cast<char*>(attn->v_cache) + (int64_t)l * attn->layer_stride * es;
             BT_TRY(mid_qkv(hs, B, q_len, dims->heads, dims->head_dim, ln1, H, lw.qkv_w, lw.qkv_b, qkv, 3 * H, kc, vc, attn->n_max,
-                           attn->pos0_dev, attn->pos0_host, attn->pos_table, attn->cos_tab, attn->sin_tab, scratch, sk_bytes));
+                           attn->pos0_dev, attn->pos0_host, attn->pos_table, attn->cos_tab, attn->sin_tab, scratch, slab_room,
+                           counters));
             // the attention output overwrites ln1 (its only reader, the QKV GEMM, is done); ln2 stays until the MLP has read it
             BT_TRY(bt_attention(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc, attn->n_max,
                                 attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H, attn->n_split,
                                 attn->split_ws, attn->split_ws_bytes, stream));
-            BT_TRY(mid_gelu(hs, M, I, H, ln2, H, lw.h4_w, lw.h4_b, h4, I, scratch, sk_bytes));
+            BT_TRY(mid_gelu(hs, M, I, H, ln2, H, lw.h4_w, lw.h4_b, h4, I, scratch, slab_room, counters));
             const bool more = l + 1 < dims->layers;
             const bt_layer_weights& nx = w->layers_host[more ? l + 1 : l];
             // x += h4 W2^T + b2 + att Wd^T + bd, then LN1 / LN2 of the NEXT layer (att == ln1 is free again after this GEMM)
             BT_TRY(mid_res_ln(hs, M, H, I, h4, I, lw.h_w, lw.h_b, H, att, H, lw.dense_w, lw.dense_b, x, H,
                               more ? nx.ln1_w : nullptr, more ? nx.ln1_b : nullptr, ln1, more ? nx.ln2_w : nullptr,
-                              more ? nx.ln2_b : nullptr, ln2, H, dims->ln_eps, scratch, sk_bytes));
+                              more ? nx.ln2_b : nullptr, ln2, H, dims->ln_eps, scratch, slab_room));
         }
     }
     for (int l = 0; l < dims->layers && !mid_rows; ++l) {

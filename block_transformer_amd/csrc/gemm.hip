@@ -381,12 +381,19 @@ __device__ inline void wait_vmcnt_n() {
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int TBM, int TBN, bool SPLITK = false, int NS = 2>
+// FUSE (with SPLITK): the split-K reduction happens INSIDE the launch -- every slice publishes its fp32 slab, the slice that
+// arrives last at the tile's counter sums all slabs in slice order (bit-identical to splitk_reduce_kernel, whatever the
+// arrival order) and runs the normal fused epilogue (bias / GELU / residual / RoPE + KV append); with one slice there is no
+// slab at all.  Publication follows the agent-scope recipe of the CDNA guide (section 5, "in-launch split-K reduction"):
+// plain slab stores -> every wave s_waitcnt vmcnt(0) -> barrier -> lane 0: release fence, vmcnt(0), relaxed agent
+// fetch_add; the last arriver: lane 0 acquire fence -> barrier -> plain loads.  `counters` (one int per tile) must be zero at
+// launch; the last arriver puts its counter back to zero (agent-scope store), bt_decoder_forward also clears them per pass.
+template <int TBM, int TBN, bool SPLITK = false, int NS = 2, bool FUSE = false>
 __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restrict__ A, int64_t lda,
                                                             const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
                                                             int K, int tiles_m, int tiles_n,
                                                             float* __restrict__ partial = nullptr, const Seg2 s2 = Seg2{},
-                                                            int slices1 = 1 << 30) {
+                                                            int slices1 = 1 << 30, int* __restrict__ counters = nullptr) {
     const int M = ep.M, N = ep.N;
     constexpr int A_BYTES = TBM * BK * 2, W_BYTES = TBN * BK * 2, STAGE = A_BYTES + W_BYTES;
     constexpr int FM = TBM / 32, FN = TBN / 32;  // 16x16 fragments per wave along m / n
@@ -483,7 +490,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restr
         __syncthreads();
     }
 
-    if (SPLITK) {  // fp32 partials: lane owns 4 consecutive columns of one row -> one 16-byte store per fragment
+    if (SPLITK && !(FUSE && gridDim.y == 1)) {  // fp32 partials: lane owns 4 consecutive columns of one row -> one 16-byte store per fragment
         float* slab = partial + (int64_t)blockIdx.y * M * N;
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
@@ -495,7 +502,45 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restr
                 if (n < N) *reinterpret_cast<f32x4_t*>(slab + (int64_t)m * N + n) = acc[i][j];
             }
         }
-        return;
+        if (!FUSE) return;
+        // ---- arrive at the tile's counter; the last slice to arrive reduces ----
+        const int S = gridDim.y;
+        int* cnt = counters + (tm * tiles_n + tn);
+        int* flag = reinterpret_cast<int*>(smem);          // the ring is idle: every DMA landed, every ds_read is done
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's slab stores have left the CU
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // restated after buffer_wbl2 where the compiler cannot drop it
+            const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = (ticket == S - 1) ? 1 : 0;
+        }
+        __syncthreads();
+        const bool last = *flag != 0;
+        __syncthreads();                                    // everyone has read the flag before smem is reused below
+        if (!last) return;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+        __syncthreads();
+        // sum the slabs in slice order (own contribution from its slab too: identical values, fixed order -> deterministic)
+#pragma unroll
+        for (int j = 0; j < FM; ++j) {
+            const int m = m0 + wm * (TBM / 2) + j * 16 + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < FN; ++i) {
+                const int n = n0 + wn * (TBN / 2) + i * 16 + (lane >> 4) * 4;
+                f32x4_t sum = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                if (m < M && n < N) {
+                    for (int sl = 0; sl < S; ++sl) {
+                        const f32x4_t p = *reinterpret_cast<const f32x4_t*>(partial + ((int64_t)sl * M + m) * N + n);
+                        sum[0] += p[0]; sum[1] += p[1]; sum[2] += p[2]; sum[3] += p[3];
+                    }
+                }
+                acc[i][j] = sum;
+            }
+        }
     }
     // epilogue: D[i = n][j = m]; lane holds column m = lane & 15 and rows n = (lane >> 4) * 4 + r
     if ((N & 7) == 0) {
@@ -1777,6 +1822,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
 // pair for M <= 4 (two launches, fp32 partial round trip): B = 1 decode 700 -> 1084 tok/s end to end.
 constexpr int GV_KC = 2048;   // K chunk staged in LDS
 
+// 16-byte weight load; NT = non-temporal (streamed once per forward: do not displace reusable lines in L2 / MALL; measured on
+// this part for a decode layer: issued -> landed -18 %, guide "nt-weights")
+template <bool NT>
+__device__ inline uint4 load_w16(const bf16* p) {
+    if constexpr (NT) {
+        const u32x4_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+        return uint4{t.x, t.y, t.z, t.w};
+    } else {
+        return *reinterpret_cast<const uint4*>(p);
+    }
+}
+
 __device__ inline float dot8_bf16(const uint4& w, const uint4& x, float acc) {
     acc = fmaf(__uint_as_float(w.x << 16), __uint_as_float(x.x << 16), acc);
     acc = fmaf(__uint_as_float(w.x & 0xffff0000u), __uint_as_float(x.x & 0xffff0000u), acc);
@@ -1843,7 +1900,7 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__
             const bf16* wp = Ws + (int64_t)n * ldws + kc + lane * 8;
 #pragma unroll
             for (int j = 0; j < GV_KC / 512; ++j)
-                wv[r][j] = (j * 512 < kw) ? *reinterpret_cast<const uint4*>(wp + j * 512) : uint4{0, 0, 0, 0};
+                wv[r][j] = (j * 512 < kw) ? load_w16<(RW < 4)>(wp + j * 512) : uint4{0, 0, 0, 0};   // RW == 4: the logits matrix, re-read every token -> cacheable
         }
         __syncthreads();
         if (LN) {   // K <= GV_KC: the chunk is the whole row.  Thread t owns the 16-byte piece t of every row.
@@ -2064,7 +2121,9 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(const bf16* __restrict
             const bf16* Xs = second ? s2.x : X;
             const int64_t ldws = second ? s2.ldw : ldw, ldxs = second ? s2.ldx : ldx;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) wfr[u][t] = *reinterpret_cast<const uint4*>(Ws + (int64_t)wr[t] * ldws + k0);
+            // (a runtime non-temporal / default select here made hipcc branch around every load: B = 8 6.7k -> 5.2k tok/s; the
+            // streamer keeps default-policy loads, the GEMV picks the policy at compile time)
+            for (int t = 0; t < 2; ++t) wfr[u][t] = load_w16<false>(Ws + (int64_t)wr[t] * ldws + k0);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int m = mt * 16 + l15;
@@ -2309,6 +2368,7 @@ BT_KNOB int g_skinny_rows = 16;   // bt_linear takes the MFMA weight streamer fo
                                   // B = 8: +21 %, 16: +4 %, 32: -20 %, 64: -30 % vs split-K + reduce -> 16)
 BT_KNOB int g_max_wg = 0;         // cap the persistent kernel's grid so small problems walk several tiles per workgroup
 BT_KNOB bool g_no_qkv_fusion = false;
+BT_KNOB bool g_mid_fuse = true;   // mid-batch QKV / h->4h GEMMs reduce their split-K slabs inside the launch (false: separate reduce kernels)
 BT_KNOB bool g_mid_rows = true;   // 17..256-row stacks take the slab + fused-reduce path (false: A/B against the unfused launches)
 BT_KNOB int g_small_stages = 0;   // LDS ring depth of the 128^2 / 128x64 / 64x64 kernels: 0 = per-tile default, 2..4 forced (A/B)
 BT_KNOB int g_gemm_variant = 0;   // 0 auto; 1 force 128^2; 2/3 256^2 four-phase ring (plain/staggered); 4-8 timing ablations; 9/10 256^2
@@ -2488,9 +2548,10 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
 #define BT_LAUNCH_GEMM(TM_, TN_, NS_)                                                                                   \
     hipLaunchKernelGGL((gemm_bf16_mfma_kernel<TM_, TN_, false, NS_>), dim3(tiles_m * tiles_n), dim3(256), 0, s,             \
                        (const bf16*)A, lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n, nullptr)
-            // ring depth per tile: 64x64 x 4 stages and 128x64 x 3 stages still fit two workgroups per CU (64 / 72 KiB);
-            // 128x128 x 3 stages = 96 KiB = one workgroup per CU
-            const int ns = g_small_stages ? g_small_stages : (tbm == 64 ? 4 : 3);
+            // ring depth per tile: 64x64 x 4 stages and 128x64 x 3 stages still fit two workgroups per CU (64 / 72 KiB)
+            // measured (profiles/r2_ring_ab.jsonl): 64x64 x 4 stages 1.2-1.5x faster at K >= 2048, 128x64 x 3 stages +7 %;
+            // 128x128 x 3 stages (one workgroup per CU instead of two) 1.4x SLOWER -> the 128^2 tile keeps the double buffer
+            const int ns = g_small_stages ? g_small_stages : (tbm == 64 ? 4 : (tbn == 64 ? 3 : 2));
             if (tbm == 128 && tbn == 128) { if (ns == 2) BT_LAUNCH_GEMM(128, 128, 2); else BT_LAUNCH_GEMM(128, 128, 3); }
             else if (tbm == 128) { if (ns == 2) BT_LAUNCH_GEMM(128, 64, 2); else BT_LAUNCH_GEMM(128, 64, 3); }
             else { if (ns == 2) BT_LAUNCH_GEMM(64, 64, 2); else BT_LAUNCH_GEMM(64, 64, 4); }
@@ -2787,9 +2848,12 @@ int64_t mid_slab_bytes(int64_t M, int64_t H, int64_t I) {
     return worst;
 }
 
-// slabs[slices][M][N] = A . W^T (K1)  [+ A2 . W2^T (K2)]   -- returns the slice count through *slices
+// slabs[slices][M][N] = A . W^T (K1)  [+ A2 . W2^T (K2)]   -- returns the slice count through *slices.
+// fused_ep != nullptr: in-launch reduction + that epilogue (no slabs at all when one slice is enough); `counters` = one zeroed
+// int per 64 x 64 tile.
 static int mid_gemm(hipStream_t s, int64_t M, int64_t N, const void* A, int64_t lda, const void* W, int64_t K1, const void* A2,
-                    int64_t lda2, const void* W2, int64_t K2, void* slabs, int64_t slab_bytes, int* slices) {
+                    int64_t lda2, const void* W2, int64_t K2, void* slabs, int64_t slab_bytes, int* slices,
+                    const EpiArgs* fused_ep = nullptr, int* counters = nullptr) {
     const int tiles_m = (int)ceil_div(M, 64), tiles_n = (int)ceil_div(N, 64);
     const int ks = mid_slice_len((int64_t)tiles_m * tiles_n, K1, K2);
     BT_CHECK_ARG(ks > 0, "mid-batch GEMM: K = %lld / %lld has no common slice length", (long long)K1, (long long)K2);
@@ -2809,8 +2873,13 @@ static int mid_gemm(hipStream_t s, int64_t M, int64_t N, const void* A, int64_t 
     s2.ldw = K2;
     s2.K = (int)K2;
     ProfScope ps(BT_PROF_LINEAR_MFMA, s);
-    hipLaunchKernelGGL((gemm_bf16_mfma_kernel<64, 64, true, 4>), dim3(tiles_m * tiles_n, sl1 + sl2), dim3(256), 0, s,
-                       (const bf16*)A, lda, (const bf16*)W, K1, ep, ks, tiles_m, tiles_n, (float*)slabs, s2, sl1);
+    if (fused_ep)
+        hipLaunchKernelGGL((gemm_bf16_mfma_kernel<64, 64, true, 4, true>), dim3(tiles_m * tiles_n, sl1 + sl2), dim3(256), 0, s,
+                           (const bf16*)A, lda, (const bf16*)W, K1, *fused_ep, ks, tiles_m, tiles_n, (float*)slabs, s2, sl1,
+                           counters);
+    else
+        hipLaunchKernelGGL((gemm_bf16_mfma_kernel<64, 64, true, 4>), dim3(tiles_m * tiles_n, sl1 + sl2), dim3(256), 0, s,
+                           (const bf16*)A, lda, (const bf16*)W, K1, ep, ks, tiles_m, tiles_n, (float*)slabs, s2, sl1);
     BT_LAUNCH_CHECK("mid-batch GEMM launch");
     *slices = sl1 + sl2;
     return BT_OK;
@@ -2818,10 +2887,9 @@ static int mid_gemm(hipStream_t s, int64_t M, int64_t N, const void* A, int64_t 
 
 int mid_qkv(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, const void* x, int64_t ldx, const void* w,
             const void* bias, void* qkv, int64_t ld_qkv, void* kc, void* vc, int64_t n_max, const int32_t* pos0_dev, int pos0_host,
-            const int32_t* pos_table, const float* cos_tab, const float* sin_tab, void* slabs, int64_t slab_bytes) {
+            const int32_t* pos_table, const float* cos_tab, const float* sin_tab, void* slabs, int64_t slab_bytes, int* counters) {
     const int64_t H = (int64_t)heads * head_dim, M = B * q_len;
     int slices = 0;
-    BT_TRY(mid_gemm(s, M, 3 * H, x, ldx, w, H, nullptr, 0, nullptr, 0, slabs, slab_bytes, &slices));
     EpiArgs ep{};
     ep.bias = (const bf16*)bias;
     ep.out = (bf16*)qkv;
@@ -2840,6 +2908,9 @@ int mid_qkv(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, const 
     ep.q.heads = heads;
     ep.q.head_dim = head_dim;
     ep.q.enabled = 1;
+    if (counters && g_mid_fuse)   // reduction, bias, RoPE and the scatter all inside the GEMM launch
+        return mid_gemm(s, M, 3 * H, x, ldx, w, H, nullptr, 0, nullptr, 0, slabs, slab_bytes, &slices, &ep, counters);
+    BT_TRY(mid_gemm(s, M, 3 * H, x, ldx, w, H, nullptr, 0, nullptr, 0, slabs, slab_bytes, &slices));
     ProfScope ps(BT_PROF_ROPE, s);
     hipLaunchKernelGGL(mid_reduce_qkv_kernel, dim3((unsigned)ceil_div(M * (3 * H / 8), 256)), dim3(256), 0, s,
                        (const float*)slabs, slices, ep);
@@ -2848,9 +2919,8 @@ int mid_qkv(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, const 
 }
 
 int mid_gelu(hipStream_t s, int64_t M, int64_t N, int64_t K, const void* x, int64_t ldx, const void* w, const void* bias, void* out,
-             int64_t ldo, void* slabs, int64_t slab_bytes) {
+             int64_t ldo, void* slabs, int64_t slab_bytes, int* counters) {
     int slices = 0;
-    BT_TRY(mid_gemm(s, M, N, x, ldx, w, K, nullptr, 0, nullptr, 0, slabs, slab_bytes, &slices));
     EpiArgs ep{};
     ep.bias = (const bf16*)bias;
     ep.out = (bf16*)out;
@@ -2858,6 +2928,9 @@ int mid_gelu(hipStream_t s, int64_t M, int64_t N, int64_t K, const void* x, int6
     ep.M = (int)M;
     ep.N = (int)N;
     ep.act = BT_ACT_GELU;
+    if (counters && g_mid_fuse)
+        return mid_gemm(s, M, N, x, ldx, w, K, nullptr, 0, nullptr, 0, slabs, slab_bytes, &slices, &ep, counters);
+    BT_TRY(mid_gemm(s, M, N, x, ldx, w, K, nullptr, 0, nullptr, 0, slabs, slab_bytes, &slices));
     ProfScope ps(BT_PROF_LINEAR_MFMA, s);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)ceil_div(M * (N / 8), 256)), dim3(256), 0, s, (const float*)slabs,
                        slices, ep);
@@ -2906,5 +2979,6 @@ extern "C" void bt_debug_gemm_max_wg(int n) { g_max_wg = n; }
 extern "C" void bt_debug_skinny_rows(int n) { g_skinny_rows = n; }
 extern "C" void bt_debug_small_stages(int n) { g_small_stages = n; }
 extern "C" void bt_debug_mid_rows(int on) { g_mid_rows = on != 0; }
+extern "C" void bt_debug_mid_fuse(int on) { g_mid_fuse = on != 0; }
 extern "C" void bt_debug_no_qkv_fusion(int on) { g_no_qkv_fusion = on != 0; }
 #endif

@@ -70,6 +70,9 @@ def generate_with_block_model_and_measure_time(model: BlockTransformer, prefill_
 
 def measure_generation(model, prefill_length, decode_length, batch_size, log_path=None) -> Dict:
     print(f" ( prefill={prefill_length} decode={decode_length} / bs={batch_size} ) ".center(80, "-"))
+    # the engine of the previous batch size holds its KV caches: drop it and hand the blocks back to the driver first (the
+    # reference's model keeps no state between calls, so its empty_cache() alone does this)
+    model.release_buffers()
     torch.cuda.empty_cache()
     try:
         print("Warming up... ", end="", flush=True)

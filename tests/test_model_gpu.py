@@ -979,3 +979,38 @@ def test_mid_batch_generate_matches_unfused(B, dbg_lib):
     assert (fused[:3, 32:36] == want[:, 32:36]).float().mean() >= 0.5
     del model
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("M", [24, 64, 200])
+def test_mid_rows_in_launch_reduction_is_exact_under_load(M, dbg_lib):
+    """The in-launch split-K reduction (last-arriving slice sums the fp32 slabs; agent-scope release / acquire hand-off across
+    CUs and XCDs) against the separate reduce kernels (bt_debug_mid_fuse(0)): same slabs, same summation order -> outputs
+    agree to one bf16 ulp on EVERY element, 40 times in a row, consumer L1-warm (same addresses every pass) and while a
+    second stream keeps the memory system busy (a stale or torn slab read would be off by a whole partial sum)."""
+    model, dims, o = _mid_stack(layers=3)
+    H = dims.bd.hidden
+    g = torch.Generator().manual_seed(100 + M)
+    x = (torch.randn(M, 1, H, generator=g) * 0.5).bfloat16().to(DEV)
+    ones = torch.ones(M, 1, dtype=torch.long, device=DEV)
+    side = torch.cuda.Stream()
+    junk_a = torch.empty(64 << 20, dtype=torch.float32, device=DEV).normal_()
+    junk_b = torch.empty_like(junk_a)
+
+    def run():
+        return model.block_decoder(inputs_embeds=x, block_attention_mask=ones).hidden_states.float()
+
+    dbg_lib.bt_debug_mid_fuse(0)
+    try:
+        ref = run()
+    finally:
+        dbg_lib.bt_debug_mid_fuse(1)
+    tol = ref.abs() * 2.0 ** -7 + 1e-3
+    for it in range(40):
+        if it % 2 == 0:
+            with torch.cuda.stream(side):                      # uneven background load on every other pass
+                for _ in range(4):
+                    junk_b.copy_(junk_a)
+        got = run()
+        bad = (got - ref).abs() > tol
+        assert not bool(bad.any()), (it, int(bad.sum()), float((got - ref).abs().max()))
+    torch.cuda.synchronize()
