@@ -2368,7 +2368,11 @@ BT_KNOB int g_skinny_rows = 16;   // bt_linear takes the MFMA weight streamer fo
                                   // B = 8: +21 %, 16: +4 %, 32: -20 %, 64: -30 % vs split-K + reduce -> 16)
 BT_KNOB int g_max_wg = 0;         // cap the persistent kernel's grid so small problems walk several tiles per workgroup
 BT_KNOB bool g_no_qkv_fusion = false;
-BT_KNOB bool g_mid_fuse = true;   // mid-batch QKV / h->4h GEMMs reduce their split-K slabs inside the launch (false: separate reduce kernels)
+// mid-batch QKV / h->4h GEMMs: 0 = slabs + separate reduce kernel always; 1 (default) = when ONE K slice already gives every CU a
+// workgroup (M >~ 200) the GEMM runs its fused epilogue directly, no slab, no reduce launch; 2 = in-launch (last-arriver) reduction
+// also for several slices -- measured SLOWER (B = 64: 42.7k -> 36.5k tok/s): every slice pays an agent-scope release fence over
+// its freshly dirtied 16 KiB slab (guide: ~6.5 us) on a ~10 us GEMM; kept for A/B only
+BT_KNOB int g_mid_fuse = 1;
 BT_KNOB bool g_mid_rows = true;   // 17..256-row stacks take the slab + fused-reduce path (false: A/B against the unfused launches)
 BT_KNOB int g_small_stages = 0;   // LDS ring depth of the 128^2 / 128x64 / 64x64 kernels: 0 = per-tile default, 2..4 forced (A/B)
 BT_KNOB int g_gemm_variant = 0;   // 0 auto; 1 force 128^2; 2/3 256^2 four-phase ring (plain/staggered); 4-8 timing ablations; 9/10 256^2
@@ -2848,6 +2852,11 @@ int64_t mid_slab_bytes(int64_t M, int64_t H, int64_t I) {
     return worst;
 }
 
+static bool mid_fuse_now(int64_t M, int64_t N, int64_t K) {
+    if (g_mid_fuse == 2) return true;
+    return g_mid_fuse == 1 && mid_slice_len(ceil_div(M, 64) * ceil_div(N, 64), K, 0) == K;
+}
+
 // slabs[slices][M][N] = A . W^T (K1)  [+ A2 . W2^T (K2)]   -- returns the slice count through *slices.
 // fused_ep != nullptr: in-launch reduction + that epilogue (no slabs at all when one slice is enough); `counters` = one zeroed
 // int per 64 x 64 tile.
@@ -2908,7 +2917,7 @@ int mid_qkv(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, const 
     ep.q.heads = heads;
     ep.q.head_dim = head_dim;
     ep.q.enabled = 1;
-    if (counters && g_mid_fuse)   // reduction, bias, RoPE and the scatter all inside the GEMM launch
+    if (counters && mid_fuse_now(M, 3 * H, H))   // reduction, bias, RoPE and the scatter all inside the GEMM launch
         return mid_gemm(s, M, 3 * H, x, ldx, w, H, nullptr, 0, nullptr, 0, slabs, slab_bytes, &slices, &ep, counters);
     BT_TRY(mid_gemm(s, M, 3 * H, x, ldx, w, H, nullptr, 0, nullptr, 0, slabs, slab_bytes, &slices));
     ProfScope ps(BT_PROF_ROPE, s);
@@ -2928,7 +2937,7 @@ int mid_gelu(hipStream_t s, int64_t M, int64_t N, int64_t K, const void* x, int6
     ep.M = (int)M;
     ep.N = (int)N;
     ep.act = BT_ACT_GELU;
-    if (counters && g_mid_fuse)
+    if (counters && mid_fuse_now(M, N, K))
         return mid_gemm(s, M, N, x, ldx, w, K, nullptr, 0, nullptr, 0, slabs, slab_bytes, &slices, &ep, counters);
     BT_TRY(mid_gemm(s, M, N, x, ldx, w, K, nullptr, 0, nullptr, 0, slabs, slab_bytes, &slices));
     ProfScope ps(BT_PROF_LINEAR_MFMA, s);
@@ -2979,6 +2988,6 @@ extern "C" void bt_debug_gemm_max_wg(int n) { g_max_wg = n; }
 extern "C" void bt_debug_skinny_rows(int n) { g_skinny_rows = n; }
 extern "C" void bt_debug_small_stages(int n) { g_small_stages = n; }
 extern "C" void bt_debug_mid_rows(int on) { g_mid_rows = on != 0; }
-extern "C" void bt_debug_mid_fuse(int on) { g_mid_fuse = on != 0; }
+extern "C" void bt_debug_mid_fuse(int mode) { g_mid_fuse = mode; }
 extern "C" void bt_debug_no_qkv_fusion(int on) { g_no_qkv_fusion = on != 0; }
 #endif

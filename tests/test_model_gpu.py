@@ -1000,12 +1000,11 @@ def test_mid_rows_in_launch_reduction_is_exact_under_load(M, dbg_lib):
         return model.block_decoder(inputs_embeds=x, block_attention_mask=ones).hidden_states.float()
 
     dbg_lib.bt_debug_mid_fuse(0)
-    try:
-        ref = run()
-    finally:
-        dbg_lib.bt_debug_mid_fuse(1)
+    ref = run()
+    dbg_lib.bt_debug_mid_fuse(2)       # in-launch reduction for every slice count (A/B mode; the default fuses one-slice GEMMs only)
     tol = ref.abs() * 2.0 ** -7 + 1e-3
-    for it in range(40):
+    try:
+      for it in range(40):
         if it % 2 == 0:
             with torch.cuda.stream(side):                      # uneven background load on every other pass
                 for _ in range(4):
@@ -1013,4 +1012,6 @@ def test_mid_rows_in_launch_reduction_is_exact_under_load(M, dbg_lib):
         got = run()
         bad = (got - ref).abs() > tol
         assert not bool(bad.any()), (it, int(bad.sum()), float((got - ref).abs().max()))
+    finally:
+        dbg_lib.bt_debug_mid_fuse(1)
     torch.cuda.synchronize()
