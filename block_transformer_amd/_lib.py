@@ -125,6 +125,7 @@ _DEBUG_SIGS = {
     "bt_debug_skinny_rows": (None, [c_int]),
     "bt_debug_small_stages": (None, [c_int]),
     "bt_debug_mid_rows": (None, [c_int]),
+    "bt_debug_few_dual": (None, [c_int]),
     "bt_debug_mid_fuse": (None, [c_int]),
     "bt_debug_no_qkv_fusion": (None, [c_int]),
     "bt_debug_flash_variant": (None, [c_int]),

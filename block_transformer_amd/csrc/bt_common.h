@@ -166,6 +166,14 @@ struct ProfScope {
     }
 };
 
+// ---- <= 4 rows: QKV (LN1, RoPE, append) and h->4h (LN2, GELU) GEMVs of one layer as ONE launch (gemm.hip) ----------------------
+bool few_rows_dual_ok(int64_t M, int64_t H, int64_t I, int head_dim, int rot);
+int few_rows_qkv_h4(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, const void* x, int64_t ldx, const void* ln1_w,
+                    const void* ln1_b, const void* ln2_w, const void* ln2_b, float eps, const void* qkv_w, const void* qkv_b,
+                    void* qkv, int64_t ld_qkv, void* kc, void* vc, int64_t n_max, const int32_t* pos0_dev, int pos0_host,
+                    const int32_t* pos_table, const float* cos_tab, const float* sin_tab, const void* h4_w, const void* h4_b,
+                    void* h4, int64_t I);
+
 // ---- mid-batch (17 .. 256 rows) decoder-layer pieces (gemm.hip), used by bt_decoder_forward (engine.hip) -------------------
 bool mid_rows_ok(int64_t M, int64_t H, int64_t I, int head_dim, int rot);
 int64_t mid_slab_bytes(int64_t M, int64_t H, int64_t I);

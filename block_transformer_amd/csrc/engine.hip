@@ -129,14 +129,26 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
             // 1..4 rows (small-batch decode, launch-bound): LayerNorms, RoPE and the KV append ride inside the weight-
             // streaming GEMVs, and the two residual-stream projections share one -- 4 launches per layer instead of 7.  The MLP's first projection reads the layer INPUT
             // (parallel residual), so it runs before the attention output projection updates x in place.
-            BT_TRY(bt_ln_qkv_rope_append(dtype, B, q_len, dims->heads, dims->head_dim, dims->rot, x, H, lw.ln1_w, lw.ln1_b,
-                                         dims->ln_eps, lw.qkv_w, lw.qkv_b, qkv, 3 * H, kc, vc, attn->n_max, attn->pos0_dev,
-                                         attn->pos0_host, attn->pos_table, attn->cos_tab, attn->sin_tab, stream));
+            // <= 4 rows: both x-consuming projections (QKV with LN1 / RoPE / append, h->4h with LN2 / GELU) in ONE launch --
+            // parallel residual: neither depends on the attention -- so the layer is 3 launches
+            const bool dual = few_rows_dual_ok(M, H, I, dims->head_dim, dims->rot) && aligned16(lw.ln1_w) && aligned16(lw.ln1_b) &&
+                              aligned16(lw.ln2_w) && aligned16(lw.ln2_b) && aligned16(lw.qkv_w) && aligned16(lw.h4_w);
+            if (dual) {
+                BT_TRY(few_rows_qkv_h4((hipStream_t)stream, B, q_len, dims->heads, dims->head_dim, x, H, lw.ln1_w, lw.ln1_b,
+                                       lw.ln2_w, lw.ln2_b, dims->ln_eps, lw.qkv_w, lw.qkv_b, qkv, 3 * H, kc, vc, attn->n_max,
+                                       attn->pos0_dev, attn->pos0_host, attn->pos_table, attn->cos_tab, attn->sin_tab, lw.h4_w,
+                                       lw.h4_b, h4, I));
+            } else {
+                BT_TRY(bt_ln_qkv_rope_append(dtype, B, q_len, dims->heads, dims->head_dim, dims->rot, x, H, lw.ln1_w, lw.ln1_b,
+                                             dims->ln_eps, lw.qkv_w, lw.qkv_b, qkv, 3 * H, kc, vc, attn->n_max, attn->pos0_dev,
+                                             attn->pos0_host, attn->pos_table, attn->cos_tab, attn->sin_tab, stream));
+            }
             BT_TRY(bt_attention(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc, attn->n_max,
                                 attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H, attn->n_split,
                                 attn->split_ws, attn->split_ws_bytes, stream));
-            BT_TRY(bt_ln_linear(dtype, M, I, H, x, H, lw.ln2_w, lw.ln2_b, dims->ln_eps, lw.h4_w, lw.h4_b, nullptr, 0, h4, I,
-                                BT_ACT_GELU, stream));
+            if (!dual)
+                BT_TRY(bt_ln_linear(dtype, M, I, H, x, H, lw.ln2_w, lw.ln2_b, dims->ln_eps, lw.h4_w, lw.h4_b, nullptr, 0, h4, I,
+                                    BT_ACT_GELU, stream));
             // x += mlp_down(h4) + attn_dense(att): both residual-stream projections in one launch (K = I, then K = H)
             if (M > 4 || I % 2048 == 0) {
                 BT_TRY(bt_linear2(dtype, M, H, I, h4, I, lw.h_w, lw.h_b, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, stream));

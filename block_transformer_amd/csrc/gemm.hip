@@ -1852,10 +1852,11 @@ __device__ inline float dot8_bf16(const uint4& w, const uint4& x, float acc) {
 // q to the qkv buffer / k, v to their KV-cache rows itself: removes the RoPE + append launch.  Small-batch decode is
 // launch-bound (~5 us per dependent launch): 7 -> 5 launches per layer.
 
+// The body is a device function of the workgroup index so that two GEMVs reading the same x can share ONE launch
+// (gemv_qkv_h4_kernel below): workgroups [0, nq) run one instantiation, the rest the other.
 template <int MR, int RW, bool LN = false, bool QKV = false>
-__global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W,
-                                                       int64_t ldw, const EpiArgs ep, int K, const LnPro ln,
-                                                       const Seg2 s2 = Seg2{}) {
+__device__ __forceinline__ void gemv_body(const int bid, const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W,
+                                          int64_t ldw, const EpiArgs& ep, int K, const LnPro& ln, const Seg2& s2) {
     static_assert(!QKV || RW == 2, "QKV mode works on row pairs");
     __shared__ __attribute__((aligned(16))) char xs[MR * GV_KC * 2];
     __shared__ float red[2][4][MR];
@@ -1863,11 +1864,11 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__
     const int M = ep.M, N = ep.N;
     int rows[RW];
     if (QKV) {   // pair p = (32-column group p >> 4, column p & 15 of it) and its rotate-half partner 16 columns further
-        const int p = blockIdx.x * 4 + wave;
+        const int p = bid * 4 + wave;
         rows[0] = (p >> 4) * 32 + (p & 15);
         rows[RW - 1] = rows[0] + 16;
     } else {
-        const int n_blk = blockIdx.x * (4 * RW);
+        const int n_blk = bid * (4 * RW);
 #pragma unroll
         for (int r = 0; r < RW; ++r) rows[r] = n_blk + wave + 4 * r;   // consecutive rows go to different waves
     }
@@ -2033,6 +2034,25 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__
             ep.out[(int64_t)my_m * ep.ldo + n].x = f32_to_bf16(v);
         }
     }
+}
+
+template <int MR, int RW, bool LN = false, bool QKV = false>
+__global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W,
+                                                       int64_t ldw, const EpiArgs ep, int K, const LnPro ln,
+                                                       const Seg2 s2 = Seg2{}) {
+    gemv_body<MR, RW, LN, QKV>(blockIdx.x, X, ldx, W, ldw, ep, K, ln, s2);
+}
+
+// Parallel residual: the layer's QKV projection (LN1 prologue, RoPE + KV append) and its MLP up-projection (LN2 prologue, GELU)
+// both read the SAME x and do not depend on each other -> one launch streams both weight matrices (58 MB at 1.2B dims)
+// instead of two dependent ~9 us launches; the decoder layer is then 3 launches for <= 4 rows:
+// [QKV | h->4h] -> attention -> [4h->h + attention.dense + residual].
+template <int MR>
+__global__ __launch_bounds__(256) void gemv_qkv_h4_kernel(const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ Wq,
+                                                         const EpiArgs epq, const LnPro ln1, int nq, const bf16* __restrict__ Wh,
+                                                         const EpiArgs eph, const LnPro ln2, int K) {
+    if ((int)blockIdx.x < nq) gemv_body<MR, 2, true, true>(blockIdx.x, X, ldx, Wq, K, epq, K, ln1, Seg2{});
+    else gemv_body<MR, 2, true, false>(blockIdx.x - nq, X, ldx, Wh, K, eph, K, ln2, Seg2{});
 }
 
 // ---- MFMA weight streamer for 5 .. 64 rows (mid-batch decode) ----------------------------------------------------------------
@@ -2374,6 +2394,7 @@ BT_KNOB bool g_no_qkv_fusion = false;
 // its freshly dirtied 16 KiB slab (guide: ~6.5 us) on a ~10 us GEMM; kept for A/B only
 BT_KNOB int g_mid_fuse = 1;
 BT_KNOB bool g_mid_rows = true;   // 17..256-row stacks take the slab + fused-reduce path (false: A/B against the unfused launches)
+BT_KNOB bool g_few_dual = true;   // <= 4 rows: QKV and h->4h GEMVs of a layer in one launch (false: two launches, A/B)
 BT_KNOB int g_small_stages = 0;   // LDS ring depth of the 128^2 / 128x64 / 64x64 kernels: 0 = per-tile default, 2..4 forced (A/B)
 BT_KNOB int g_gemm_variant = 0;   // 0 auto; 1 force 128^2; 2/3 256^2 four-phase ring (plain/staggered); 4-8 timing ablations; 9/10 256^2
 // two-phase ring, one tile per workgroup (staggered/plain); 14 persistent on 32x32x16 MFMA; default: persistent two-phase ring.
@@ -2818,6 +2839,62 @@ extern "C" int bt_linear2(int dtype, int64_t M, int64_t N, int64_t K1, const voi
     return BT_OK;
 }
 
+// ---- <= 4 rows: the layer's two x-consuming projections as one launch (gemv_qkv_h4_kernel); called by bt_decoder_forward -----
+namespace bt {
+
+bool few_rows_dual_ok(int64_t M, int64_t H, int64_t I, int head_dim, int rot) {
+    return M >= 1 && M <= 4 && rot == 32 && head_dim % 32 == 0 && H % 512 == 0 && H <= GV_KC && I % 8 == 0 && !g_force_generic &&
+           g_gemm_variant != 22 && g_few_dual;
+}
+
+int few_rows_qkv_h4(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, const void* x, int64_t ldx, const void* ln1_w,
+                    const void* ln1_b, const void* ln2_w, const void* ln2_b, float eps, const void* qkv_w, const void* qkv_b,
+                    void* qkv, int64_t ld_qkv, void* kc, void* vc, int64_t n_max, const int32_t* pos0_dev, int pos0_host,
+                    const int32_t* pos_table, const float* cos_tab, const float* sin_tab, const void* h4_w, const void* h4_b,
+                    void* h4, int64_t I) {
+    const int64_t H = (int64_t)heads * head_dim, M = B * q_len;
+    EpiArgs epq{};
+    epq.bias = (const bf16*)qkv_b;
+    epq.out = (bf16*)qkv;
+    epq.ldo = ld_qkv;
+    epq.M = (int)M;
+    epq.N = (int)(3 * H);
+    epq.q.kc = (bf16*)kc;
+    epq.q.vc = (bf16*)vc;
+    epq.q.n_max = n_max;
+    epq.q.pos0_dev = pos0_dev;
+    epq.q.pos_table = pos_table;
+    epq.q.cos_tab = cos_tab;
+    epq.q.sin_tab = sin_tab;
+    epq.q.pos0_host = pos0_host;
+    epq.q.q_len = q_len;
+    epq.q.heads = heads;
+    epq.q.head_dim = head_dim;
+    epq.q.enabled = 1;
+    EpiArgs eph{};
+    eph.bias = (const bf16*)h4_b;
+    eph.out = (bf16*)h4;
+    eph.ldo = I;
+    eph.M = (int)M;
+    eph.N = (int)I;
+    eph.act = BT_ACT_GELU;
+    const LnPro l1{(const bf16*)ln1_w, (const bf16*)ln1_b, eps}, l2{(const bf16*)ln2_w, (const bf16*)ln2_b, eps};
+    const int nq = (int)ceil_div(3 * H / 2, 4);        // one wave per (n, n + 16) pair, 4 pairs per workgroup
+    const int nh = (int)ceil_div(I, 4 * 2);            // RW = 2 rows per wave, 4 waves
+    ProfScope ps(BT_PROF_LINEAR_MFMA, s);
+#define BT_LAUNCH_DUAL(MR_)                                                                                                  \
+    hipLaunchKernelGGL((gemv_qkv_h4_kernel<MR_>), dim3(nq + nh), dim3(256), 0, s, (const bf16*)x, ldx, (const bf16*)qkv_w, epq, \
+                       l1, nq, (const bf16*)h4_w, eph, l2, (int)H)
+    if (M <= 1) BT_LAUNCH_DUAL(1);
+    else if (M <= 2) BT_LAUNCH_DUAL(2);
+    else BT_LAUNCH_DUAL(4);
+#undef BT_LAUNCH_DUAL
+    BT_LAUNCH_CHECK("fused QKV + h->4h GEMV launch");
+    return BT_OK;
+}
+
+}  // namespace bt
+
 // ---- mid-batch path (17 .. 256 rows): split-K slabs + fused reduces; called by bt_decoder_forward (engine.hip) ------------------
 namespace bt {
 
@@ -2988,6 +3065,7 @@ extern "C" void bt_debug_gemm_max_wg(int n) { g_max_wg = n; }
 extern "C" void bt_debug_skinny_rows(int n) { g_skinny_rows = n; }
 extern "C" void bt_debug_small_stages(int n) { g_small_stages = n; }
 extern "C" void bt_debug_mid_rows(int on) { g_mid_rows = on != 0; }
+extern "C" void bt_debug_few_dual(int on) { g_few_dual = on != 0; }
 extern "C" void bt_debug_mid_fuse(int mode) { g_mid_fuse = mode; }
 extern "C" void bt_debug_no_qkv_fusion(int on) { g_no_qkv_fusion = on != 0; }
 #endif

@@ -1015,3 +1015,33 @@ def test_mid_rows_in_launch_reduction_is_exact_under_load(M, dbg_lib):
     finally:
         dbg_lib.bt_debug_mid_fuse(1)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("B", [1, 2, 4])
+def test_few_rows_dual_launch_is_bit_identical(B, dbg_lib):
+    """<= 4 rows: QKV (LN1 / RoPE / append) and h->4h (LN2 / GELU) of a layer in ONE launch (gemv_qkv_h4_kernel) == the two separate
+    GEMV launches, bit for bit (same per-row arithmetic, only the launch grouping changes): tokens and last context equal."""
+    import dataclasses
+    base = named_dims("block_main_b4_1.2b")
+    dims = dataclasses.replace(base, name="b4_1.2b_2layer", bd=dataclasses.replace(base.bd, layers=2),
+                               td=dataclasses.replace(base.td, layers=2))
+    sd = random_state_dict(dims, seed=5, include_unused_embed_in=False)
+    model = load_block_transformer_from_dims(dims, "fp32", keep_unused_embed_in=False)
+    model.load_state_dict(sd, strict=True)
+    model = model.bfloat16().to(DEV)
+    model.token_decoder.generation_config.eos_token_id = None
+    prompt = torch.randint(0, dims.vocab, (B, 64), generator=torch.Generator().manual_seed(B)).to(DEV)
+    dbg_lib.bt_debug_few_dual(1)
+    a = model.generate(prompt, max_length=96).cpu()
+    ctx_a = model._engine.ctx.float().cpu().clone()
+    dbg_lib.bt_debug_few_dual(0)
+    try:
+        model._engine = None
+        b = model.generate(prompt, max_length=96).cpu()
+        ctx_b = model._engine.ctx.float().cpu().clone()
+    finally:
+        dbg_lib.bt_debug_few_dual(1)
+        model._engine = None
+    assert torch.equal(a, b) and torch.equal(ctx_a, ctx_b)
+    del model
+    torch.cuda.empty_cache()
