@@ -2066,14 +2066,21 @@ __global__ __launch_bounds__(256) void gemv_qkv_h4_kernel(const bf16* __restrict
 // are computed first (wave per row), x fragments are normalised in registers as they arrive.
 constexpr int SK_ROWS = 32;
 
+template <int MT>
+struct SkinnyLds {
+    float red[8][2][MT][64][4];
+    float stats[MT * 16][2];
+};
+
 template <int MT, bool LN, bool QKV>
-__global__ __launch_bounds__(512) void skinny_mfma_kernel(const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W,
-                                                         int64_t ldw, const EpiArgs ep, int K, const LnPro ln, const Seg2 s2) {
-    __shared__ __attribute__((aligned(16))) float red[8][2][MT][64][4];
-    __shared__ float stats[MT * 16][2];
+__device__ __forceinline__ void skinny_body(const int bid, SkinnyLds<MT>& lds, const bf16* __restrict__ X, int64_t ldx,
+                                            const bf16* __restrict__ W, int64_t ldw, const EpiArgs& ep, int K, const LnPro& ln,
+                                            const Seg2& s2) {
+    auto& red = lds.red;
+    auto& stats = lds.stats;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int M = ep.M, N = ep.N;
-    const int n0 = blockIdx.x * SK_ROWS;
+    const int n0 = bid * SK_ROWS;
     const int l15 = lane & 15, g = lane >> 4;
 
     if (LN) {   // a wave per row: two passes over the row (K * 2 bytes, L2-resident)
@@ -2279,6 +2286,23 @@ __global__ __launch_bounds__(512) void skinny_mfma_kernel(const bf16* __restrict
         pk.y = pack_bf16x2(o[t][2], o[t][3]);
         *reinterpret_cast<uint2*>(ep.out + (int64_t)m * ep.ldo + n) = pk;
     }
+}
+
+template <int MT, bool LN, bool QKV>
+__global__ __launch_bounds__(512) void skinny_mfma_kernel(const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W,
+                                                         int64_t ldw, const EpiArgs ep, int K, const LnPro ln, const Seg2 s2) {
+    __shared__ __attribute__((aligned(16))) SkinnyLds<MT> lds;
+    skinny_body<MT, LN, QKV>(blockIdx.x, lds, X, ldx, W, ldw, ep, K, ln, s2);
+}
+
+// 5 .. 16 rows: the layer's QKV (LN1, RoPE, append) and h->4h (LN2, GELU) projections as ONE launch, like gemv_qkv_h4_kernel
+template <int MT>
+__global__ __launch_bounds__(512) void skinny_qkv_h4_kernel(const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ Wq,
+                                                           const EpiArgs epq, const LnPro ln1, int nq,
+                                                           const bf16* __restrict__ Wh, const EpiArgs eph, const LnPro ln2, int K) {
+    __shared__ __attribute__((aligned(16))) SkinnyLds<MT> lds;
+    if ((int)blockIdx.x < nq) skinny_body<MT, true, true>(blockIdx.x, lds, X, ldx, Wq, K, epq, K, ln1, Seg2{});
+    else skinny_body<MT, true, false>(blockIdx.x - nq, lds, X, ldx, Wh, K, eph, K, ln2, Seg2{});
 }
 
 // launch helper: MT = ceil(M / 16) in 1..4
@@ -2843,8 +2867,9 @@ extern "C" int bt_linear2(int dtype, int64_t M, int64_t N, int64_t K1, const voi
 namespace bt {
 
 bool few_rows_dual_ok(int64_t M, int64_t H, int64_t I, int head_dim, int rot) {
-    return M >= 1 && M <= 4 && rot == 32 && head_dim % 32 == 0 && H % 512 == 0 && H <= GV_KC && I % 8 == 0 && !g_force_generic &&
-           g_gemm_variant != 22 && g_few_dual;
+    if (rot != 32 || head_dim % 32 != 0 || g_force_generic || g_gemm_variant == 22 || !g_few_dual) return false;
+    if (M >= 1 && M <= 4) return H % 512 == 0 && H <= GV_KC && I % 8 == 0;
+    return M >= 5 && M <= 64 && H % 32 == 0 && I % 32 == 0;     // MFMA weight streamer (bt_decoder_forward uses it up to 16 rows)
 }
 
 int few_rows_qkv_h4(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, const void* x, int64_t ldx, const void* ln1_w,
@@ -2879,9 +2904,23 @@ int few_rows_qkv_h4(hipStream_t s, int64_t B, int q_len, int heads, int head_dim
     eph.N = (int)I;
     eph.act = BT_ACT_GELU;
     const LnPro l1{(const bf16*)ln1_w, (const bf16*)ln1_b, eps}, l2{(const bf16*)ln2_w, (const bf16*)ln2_b, eps};
+    ProfScope ps(BT_PROF_LINEAR_MFMA, s);
+    if (M > 4) {   // 5 .. 64 rows: MFMA weight streamer, 32 weight rows per workgroup
+        const int nq = (int)ceil_div(3 * H, SK_ROWS), nh = (int)ceil_div(I, SK_ROWS);
+        const int mt = (int)ceil_div(M, 16);
+#define BT_LAUNCH_SDUAL(MT_)                                                                                                  \
+    hipLaunchKernelGGL((skinny_qkv_h4_kernel<MT_>), dim3(nq + nh), dim3(512), 0, s, (const bf16*)x, ldx, (const bf16*)qkv_w, epq, \
+                       l1, nq, (const bf16*)h4_w, eph, l2, (int)H)
+        if (mt <= 1) BT_LAUNCH_SDUAL(1);
+        else if (mt == 2) BT_LAUNCH_SDUAL(2);
+        else if (mt == 3) BT_LAUNCH_SDUAL(3);
+        else BT_LAUNCH_SDUAL(4);
+#undef BT_LAUNCH_SDUAL
+        BT_LAUNCH_CHECK("fused QKV + h->4h streamer launch");
+        return BT_OK;
+    }
     const int nq = (int)ceil_div(3 * H / 2, 4);        // one wave per (n, n + 16) pair, 4 pairs per workgroup
     const int nh = (int)ceil_div(I, 4 * 2);            // RW = 2 rows per wave, 4 waves
-    ProfScope ps(BT_PROF_LINEAR_MFMA, s);
 #define BT_LAUNCH_DUAL(MR_)                                                                                                  \
     hipLaunchKernelGGL((gemv_qkv_h4_kernel<MR_>), dim3(nq + nh), dim3(256), 0, s, (const bf16*)x, ldx, (const bf16*)qkv_w, epq, \
                        l1, nq, (const bf16*)h4_w, eph, l2, (int)H)

@@ -1017,9 +1017,9 @@ def test_mid_rows_in_launch_reduction_is_exact_under_load(M, dbg_lib):
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("B", [1, 2, 4])
+@pytest.mark.parametrize("B", [1, 2, 4, 6, 16])
 def test_few_rows_dual_launch_is_bit_identical(B, dbg_lib):
-    """<= 4 rows: QKV (LN1 / RoPE / append) and h->4h (LN2 / GELU) of a layer in ONE launch (gemv_qkv_h4_kernel) == the two separate
+    """<= 16 rows (GEMV up to 4, MFMA weight streamer above): QKV (LN1 / RoPE / append) and h->4h (LN2 / GELU) of a layer in ONE launch (gemv_qkv_h4_kernel) == the two separate
     GEMV launches, bit for bit (same per-row arithmetic, only the launch grouping changes): tokens and last context equal."""
     import dataclasses
     base = named_dims("block_main_b4_1.2b")
