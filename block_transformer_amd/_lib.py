@@ -61,7 +61,7 @@ class bt_attn_args(Structure):
     _fields_ = [("k_cache", c_void_p), ("v_cache", c_void_p), ("layer_stride", c_int64), ("n_max", c_int64),
                 ("pos0_dev", c_void_p), ("pos0_host", c_int32), ("pos_table", c_void_p), ("mask", c_void_p),
                 ("mask_ld", c_int64), ("cos_tab", c_void_p), ("sin_tab", c_void_p), ("mode", c_int32),
-                ("n_split", c_int32), ("split_ws", c_void_p), ("split_ws_bytes", c_int64)]
+                ("n_split", c_int32), ("split_ws", c_void_p), ("split_ws_bytes", c_int64), ("seq_skip", c_void_p)]
 
 
 _SIGS = {

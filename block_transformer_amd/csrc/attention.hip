@@ -136,7 +136,8 @@ __global__ __launch_bounds__(NW * 64) void attend_rows_kernel(const T* __restric
                                                              int pos0_host, const uint8_t* __restrict__ mask,
                                                              int64_t mask_ld, T* __restrict__ out, int64_t ldo,
                                                              float* __restrict__ ws, int q_len, int heads, int n_split,
-                                                             float scale, int64_t total_items = 0) {
+                                                             float scale, int64_t total_items = 0,
+                                                             const int32_t* __restrict__ seq_skip = nullptr) {
     constexpr int V = Elem<T>::VEC;
     constexpr int LPR = D / V;     // lanes per K/V row
     constexpr int RPW = 64 / LPR;  // rows per wave-instruction
@@ -154,6 +155,27 @@ __global__ __launch_bounds__(NW * 64) void attend_rows_kernel(const T* __restric
     const int head = (int)((idx / q_len) % heads);
     const int64_t b = idx / ((int64_t)q_len * heads);
     const int split = blockIdx.y;
+    if (seq_skip && seq_skip[b] != 0) {
+        // a finished sequence (BlockTransformer.generate: its next tokens are forced to pad whatever the context is; the
+        // reference compacts such rows away, :381-398): do not stream its KV cache, leave zeros
+        if (n_split == 1) {
+            if (wave == 0 && sub == 0) {
+                float z[V];
+#pragma unroll
+                for (int i = 0; i < V; ++i) z[i] = 0.f;
+                store_vec<T>(out + (b * q_len + t) * ldo + (int64_t)head * D + c * V, z);
+            }
+        } else if (wave == 0 && sub == 0) {
+            float* w = ws + (idx * n_split + split) * (D + 2);
+            if (c == 0) {
+                w[0] = -INFINITY;
+                w[1] = 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < V; ++i) w[2 + c * V + i] = 0.f;
+        }
+        continue;
+    }
     const int pos0 = pos0_dev ? *pos0_dev : pos0_host;
     const int nk = pos0 + t + 1;
     const int per = (nk + n_split - 1) / n_split;
@@ -785,7 +807,7 @@ static constexpr int g_attn_persist = 0;
 template <typename T, int D>
 static int launch_attend(int64_t B, int q_len, int heads, const void* qkv, int64_t ld_qkv, const void* kc, const void* vc,
                          int64_t n_max, const int32_t* pos0_dev, int pos0_host, const uint8_t* mask, int64_t mask_ld,
-                         void* out, int64_t ldo, int n_split, float* ws, hipStream_t s) {
+                         void* out, int64_t ldo, int n_split, float* ws, hipStream_t s, const int32_t* seq_skip = nullptr) {
     const float scale = 1.0f / sqrtf((float)D);
     ProfScope ps(BT_PROF_ATTN_ROWS, s);
     const int64_t cap = ceil_div(n_max, n_split);
@@ -820,7 +842,7 @@ static int launch_attend(int64_t B, int q_len, int heads, const void* qkv, int64
 #endif
             hipLaunchKernelGGL((attend_rows_kernel<T, D, 4>), grid, dim3(256), shm, s, (const T*)qkv, ld_qkv, (const T*)kc,
                                (const T*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (T*)out, ldo, ws, q_len, heads,
-                               n_split, scale);
+                               n_split, scale, (int64_t)0, seq_skip);
     }
     BT_LAUNCH_CHECK("bt_attention(rows) launch");
     if (n_split > 1) {
@@ -913,10 +935,27 @@ extern "C" int32_t bt_attention_split_count(int32_t head_dim, int64_t n_max, int
     return n_split;
 }
 
+namespace bt {
+int attention_impl(int dtype, int mode, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim, const void* qkv,
+                   int64_t ld_qkv, const void* k_cache, const void* v_cache, int64_t n_max, const int32_t* pos0_dev,
+                   int32_t pos0_host, const uint8_t* mask, int64_t mask_ld, void* out, int64_t ldo, int32_t n_split, void* ws,
+                   int64_t ws_bytes, const int32_t* seq_skip, bt_stream stream);
+}
+
 extern "C" int bt_attention(int dtype, int mode, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim,
                             const void* qkv, int64_t ld_qkv, const void* k_cache, const void* v_cache, int64_t n_max,
                             const int32_t* pos0_dev, int32_t pos0_host, const uint8_t* mask, int64_t mask_ld, void* out,
                             int64_t ldo, int32_t n_split, void* ws, int64_t ws_bytes, bt_stream stream) {
+    return bt::attention_impl(dtype, mode, B, q_len, heads, head_dim, qkv, ld_qkv, k_cache, v_cache, n_max, pos0_dev, pos0_host,
+                              mask, mask_ld, out, ldo, n_split, ws, ws_bytes, nullptr, stream);
+}
+
+// seq_skip[b] != 0: sequence b is finished -- the row-wise kernel (global decode step, n_max > 64) leaves zeros for it instead of
+// streaming its cache (bt_decoder_forward passes bt_attn_args.seq_skip)
+int bt::attention_impl(int dtype, int mode, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim, const void* qkv,
+                       int64_t ld_qkv, const void* k_cache, const void* v_cache, int64_t n_max, const int32_t* pos0_dev,
+                       int32_t pos0_host, const uint8_t* mask, int64_t mask_ld, void* out, int64_t ldo, int32_t n_split,
+                       void* ws, int64_t ws_bytes, const int32_t* seq_skip, bt_stream stream) {
     BT_CHECK_ARG(dtype == BT_F32 || dtype == BT_BF16, "bt_attention: bad dtype %d", dtype);
     BT_CHECK_ARG(mode == 0 || mode == 1, "bt_attention: bad mode %d", mode);
     BT_CHECK_ARG(B >= 0 && q_len > 0 && heads > 0, "bt_attention: bad shape");
@@ -948,7 +987,7 @@ extern "C" int bt_attention(int dtype, int mode, int64_t B, int32_t q_len, int32
             return BT_ERR_WORKSPACE;
         }
     }
-#define BT_ATT(T, D_) launch_attend<T, D_>(B, q_len, heads, qkv, ld_qkv, k_cache, v_cache, n_max, pos0_dev, pos0_host, mask, mask_ld, out, ldo, n_split, (float*)ws, s)
+#define BT_ATT(T, D_) launch_attend<T, D_>(B, q_len, heads, qkv, ld_qkv, k_cache, v_cache, n_max, pos0_dev, pos0_host, mask, mask_ld, out, ldo, n_split, (float*)ws, s, seq_skip)
     if (dtype == BT_BF16) {
         switch (head_dim) {
             case 32: return BT_ATT(bf16, 32);

@@ -166,6 +166,11 @@ struct ProfScope {
     }
 };
 
+int attention_impl(int dtype, int mode, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim, const void* qkv,
+                   int64_t ld_qkv, const void* k_cache, const void* v_cache, int64_t n_max, const int32_t* pos0_dev,
+                   int32_t pos0_host, const uint8_t* mask, int64_t mask_ld, void* out, int64_t ldo, int32_t n_split, void* ws,
+                   int64_t ws_bytes, const int32_t* seq_skip, bt_stream stream);
+
 // ---- <= 4 rows: QKV (LN1, RoPE, append) and h->4h (LN2, GELU) GEMVs of one layer as ONE launch (gemm.hip) ----------------------
 bool few_rows_dual_ok(int64_t M, int64_t H, int64_t I, int head_dim, int rot);
 int few_rows_qkv_h4(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, const void* x, int64_t ldx, const void* ln1_w,

@@ -47,6 +47,8 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
     BT_CHECK_ARG(B >= 0 && q_len > 0 && first_out_row >= 0 && first_out_row < q_len, "bt_decoder_forward: bad shape");
     BT_CHECK_ARG(dims->hidden == dims->heads * dims->head_dim, "bt_decoder_forward: hidden != heads*head_dim");
     if (B == 0) return BT_OK;
+    // finished sequences: their decode-step attention (q_len = 1, row-wise kernel) is skipped, see bt_attn_args.seq_skip
+    const int32_t* skip = (q_len == 1 && attn->mode == 0) ? attn->seq_skip : nullptr;
     const int64_t M = B * q_len;
     const int64_t H = dims->hidden, I = dims->inter;
     const size_t es = dtype_size(dtype);
@@ -108,9 +110,9 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
                            attn->pos0_dev, attn->pos0_host, attn->pos_table, attn->cos_tab, attn->sin_tab, scratch, slab_room,
                            counters));
             // the attention output overwrites ln1 (its only reader, the QKV GEMM, is done); ln2 stays until the MLP has read it
-            BT_TRY(bt_attention(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc, attn->n_max,
+            BT_TRY(attention_impl(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc, attn->n_max,
                                 attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H, attn->n_split,
-                                attn->split_ws, attn->split_ws_bytes, stream));
+                                attn->split_ws, attn->split_ws_bytes, skip, stream));
             BT_TRY(mid_gelu(hs, M, I, H, ln2, H, lw.h4_w, lw.h4_b, h4, I, scratch, slab_room, counters));
             const bool more = l + 1 < dims->layers;
             const bt_layer_weights& nx = w->layers_host[more ? l + 1 : l];
@@ -143,9 +145,9 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
                                              dims->ln_eps, lw.qkv_w, lw.qkv_b, qkv, 3 * H, kc, vc, attn->n_max, attn->pos0_dev,
                                              attn->pos0_host, attn->pos_table, attn->cos_tab, attn->sin_tab, stream));
             }
-            BT_TRY(bt_attention(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc, attn->n_max,
+            BT_TRY(attention_impl(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc, attn->n_max,
                                 attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H, attn->n_split,
-                                attn->split_ws, attn->split_ws_bytes, stream));
+                                attn->split_ws, attn->split_ws_bytes, skip, stream));
             if (!dual)
                 BT_TRY(bt_ln_linear(dtype, M, I, H, x, H, lw.ln2_w, lw.ln2_b, dims->ln_eps, lw.h4_w, lw.h4_b, nullptr, 0, h4, I,
                                     BT_ACT_GELU, stream));
@@ -173,9 +175,9 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
                                   3 * H, kc, vc, attn->n_max, attn->pos0_dev, attn->pos0_host, attn->pos_table,
                                   attn->cos_tab, attn->sin_tab, scratch, sk_bytes, stream));
         if (!last) {
-            BT_TRY(bt_attention(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc,
+            BT_TRY(attention_impl(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc,
                                 attn->n_max, attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H,
-                                attn->n_split, attn->split_ws, attn->split_ws_bytes, stream));
+                                attn->n_split, attn->split_ws, attn->split_ws_bytes, skip, stream));
             BT_TRY(bt_linear_ws(dtype, M, H, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, BT_ACT_NONE, scratch, sk_bytes, stream));
             BT_TRY(bt_linear_ws(dtype, M, I, H, ln2, H, lw.h4_w, lw.h4_b, nullptr, 0, h4, I, BT_ACT_GELU, scratch, sk_bytes, stream));
             BT_TRY(bt_linear_ws(dtype, M, H, I, h4, I, lw.h_w, lw.h_b, x, H, x, H, BT_ACT_NONE, scratch, sk_bytes, stream));
@@ -187,16 +189,16 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
             // the device-side start position (if any) counts from the first new row: shift it by q_len - 1 on the host
             // side only when it is a host value; a device scalar cannot be shifted here, so fall back to the full path
             if (attn->pos0_dev != nullptr) {
-                BT_TRY(bt_attention(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc,
+                BT_TRY(attention_impl(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc,
                                     attn->n_max, attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H,
-                                    attn->n_split, attn->split_ws, attn->split_ws_bytes, stream));
+                                    attn->n_split, attn->split_ws, attn->split_ws_bytes, skip, stream));
                 const char* al = reinterpret_cast<const char*>(att) + (int64_t)(q_len - 1) * H * es;
                 BT_TRY(bt_linear_ws(dtype, B, H, H, al, (int64_t)q_len * H, lw.dense_w, lw.dense_b, xl, (int64_t)q_len * H,
                                     xl, (int64_t)q_len * H, BT_ACT_NONE, scratch, sk_bytes, stream));
             } else {
-                BT_TRY(bt_attention(dtype, 0, B, 1, dims->heads, dims->head_dim, ql, (int64_t)q_len * 3 * H, kc, vc,
+                BT_TRY(attention_impl(dtype, 0, B, 1, dims->heads, dims->head_dim, ql, (int64_t)q_len * 3 * H, kc, vc,
                                     attn->n_max, nullptr, attn->pos0_host + q_len - 1, attn->mask, attn->mask_ld, att, H,
-                                    split, attn->split_ws, attn->split_ws_bytes, stream));
+                                    split, attn->split_ws, attn->split_ws_bytes, skip, stream));
                 BT_TRY(bt_linear_ws(dtype, B, H, H, att, H, lw.dense_w, lw.dense_b, xl, (int64_t)q_len * H, xl,
                                     (int64_t)q_len * H, BT_ACT_NONE, scratch, sk_bytes, stream));
             }
@@ -333,6 +335,8 @@ extern "C" int bt_roll_over_enqueue(const bt_engine_desc* e, bt_stream stream) {
     a.n_split = e->n_split > 0 ? e->n_split : 1;
     a.split_ws = e->split_ws;
     a.split_ws_bytes = e->split_ws_bytes;
+    // with EOS handling on, finished sequences skip the KV stream of the global step (their context is never decoded)
+    a.seq_skip = (e->gen_eos >= 0 && e->finished) ? e->finished : nullptr;
     BT_TRY(bt_decoder_forward(e->dtype, &e->bd_dims, &e->bd_w, B, 1, e->x_blk, &a, 0, e->ctx, e->ws_step, e->ws_step_bytes,
                               stream));
     (void)Hbd;

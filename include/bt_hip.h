@@ -208,6 +208,9 @@ typedef struct bt_attn_args {
     int32_t n_split; /* split-N factor for mode 0 */
     void* split_ws;
     int64_t split_ws_bytes;
+    const int32_t* seq_skip; /* optional [B]: != 0 marks a finished sequence whose decode-step attention (mode 0, q_len = 1) is
+                                skipped (zeros are written; its tokens are forced to pad anyway) -- the reference compacts such
+                                rows away, model/block_transformer.py:381-398 */
 } bt_attn_args;
 
 /* x[M,H] (row stride H) -> NL x {LN1|LN2, QKV, RoPE+append, attention, dense(+x), h_to_4h+GELU, 4h_to_h(+)} ->
