@@ -301,6 +301,121 @@ __global__ __launch_bounds__(NW * 64) void attend_rows_kernel(const T* __restric
     }   // item loop
 }
 
+// ---- local-window attention (token decoder: <= E + L - 1 keys, <= 2 query rows per call) ------------------------------------
+// The north-star "local path": one WAVE per (sequence, head) covers ALL query rows of the call; the whole K/V window (<= 12 rows
+// of 256 B at d = 128) is fetched once, 16 lanes x 16 B per row, 4 rows per wave-instruction, every load of the item issued
+// before the first use (one memory round trip); the softmax row lives in registers and is reduced with wave shuffles only
+// (no LDS, no barrier): scores by a 16-lane butterfly per key, max / sum across the four 16-lane row groups by xor-16 / xor-32.
+// With <= 12 keys an LDS-resident K/V tile would be written once and read once -- registers ARE the resident tile.
+// HPW = (sequence, head) items per wave, processed back to back with all their loads in flight together: the kernel is
+// latency-bound (tens of thousands of tiny items), not bandwidth-bound.
+template <int D, int HPW>
+__global__ __launch_bounds__(256) void local_attend_kernel(const bf16* __restrict__ qkv, int64_t ld_qkv, const bf16* __restrict__ kc,
+                                                          const bf16* __restrict__ vc, int64_t n_max, int pos0,
+                                                          const uint8_t* __restrict__ mask, int64_t mask_ld,
+                                                          bf16* __restrict__ out, int64_t ldo, int q_len, int heads,
+                                                          int64_t items, float scale) {
+    static_assert(D == 128, "one 16-lane group per 256-byte row");
+    constexpr int U = 3;                       // row batches of 4 keys: window <= 12 rows
+    constexpr int QMAX = 2;                    // query rows per call (E = 2 prefix rows at step 0, 1 afterwards)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, sub = lane >> 4;
+    const int64_t first = ((int64_t)blockIdx.x * 4 + wave) * HPW;
+    const int nk_all = pos0 + q_len;           // keys visible to the last query row
+    uint4 kq[HPW][U], vq[HPW][U], qq[HPW][QMAX];
+    // ---- every load of every item first ----
+#pragma unroll
+    for (int h = 0; h < HPW; ++h) {
+        int64_t it = first + h;
+        it = it < items ? it : items - 1;
+        const int64_t b = it / heads;
+        const int head = (int)(it - b * heads);
+        const bf16* kb = kc + (b * heads + head) * n_max * D + c * 8;
+        const bf16* vb = vc + (b * heads + head) * n_max * D + c * 8;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int r = u * 4 + sub;
+            r = r < nk_all ? r : nk_all - 1;
+            kq[h][u] = *reinterpret_cast<const uint4*>(kb + (int64_t)r * D);
+            vq[h][u] = *reinterpret_cast<const uint4*>(vb + (int64_t)r * D);
+        }
+#pragma unroll
+        for (int t = 0; t < QMAX; ++t) {
+            const int tt = t < q_len ? t : q_len - 1;
+            qq[h][t] = *reinterpret_cast<const uint4*>(qkv + (b * q_len + tt) * ld_qkv + (int64_t)head * 3 * D + c * 8);
+        }
+    }
+#pragma unroll
+    for (int h = 0; h < HPW; ++h) {
+        const int64_t it = first + h;
+        if (it >= items) break;
+        const int64_t b = it / heads;
+        const int head = (int)(it - b * heads);
+        const uint8_t* mrow = mask ? mask + b * mask_ld : nullptr;
+#pragma unroll
+        for (int t = 0; t < QMAX; ++t) {
+            if (t >= q_len) break;
+            const int nk = pos0 + t + 1;
+            float q[8];
+            {
+                const uint32_t w[4] = {qq[h][t].x, qq[h][t].y, qq[h][t].z, qq[h][t].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    q[2 * i] = __uint_as_float(w[i] << 16) * scale;
+                    q[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u) * scale;
+                }
+            }
+            float sc[U];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t w[4] = {kq[h][u].x, kq[h][u].y, kq[h][u].z, kq[h][u].w};
+                float d = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    d = fmaf(q[2 * i], __uint_as_float(w[i] << 16), d);
+                    d = fmaf(q[2 * i + 1], __uint_as_float(w[i] & 0xffff0000u), d);
+                }
+                d = wave_sum<16>(d);                                   // all 16 lanes of the row group hold the score
+                const int r = u * 4 + sub;
+                const bool vis = r < nk && (mrow == nullptr || mrow[r] != 0);
+                sc[u] = vis ? d : -INFINITY;
+                mx = fmaxf(mx, sc[u]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float l = 0.f;
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float p = (mx == -INFINITY) ? 0.f : __expf(sc[u] - mx);
+                l += p;
+                const uint32_t w[4] = {vq[h][u].x, vq[h][u].y, vq[h][u].z, vq[h][u].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[2 * i] = fmaf(p, __uint_as_float(w[i] << 16), acc[2 * i]);
+                    acc[2 * i + 1] = fmaf(p, __uint_as_float(w[i] & 0xffff0000u), acc[2 * i + 1]);
+                }
+            }
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                acc[i] += __shfl_xor(acc[i], 16, 64);
+                acc[i] += __shfl_xor(acc[i], 32, 64);
+            }
+            if (sub == 0) {
+                const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] *= inv;
+                store_vec<bf16>(out + (b * q_len + t) * ldo + (int64_t)head * D + c * 8, acc);
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ void attn_combine_kernel(const float* __restrict__ ws, T* __restrict__ out, int64_t ldo, int q_len, int heads,
                                     int D, int n_split) {
@@ -800,8 +915,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void flash_prefill_v2_ker
 #ifdef BT_DEBUG_HOOKS
 static int g_attn_nt = 0;   // A/B hook (debug library only): non-temporal K/V loads in the global (NW = 4) streaming kernel
 static int g_attn_persist = 0;   // A/B hook: > 0 = persistent global-attention kernel with that many workgroups per CU
+static int g_local_kernel = 1;   // A/B hook: 0 = the token-decoder window runs on the generic row-wise kernel (NW = 1)
 #else
 static constexpr int g_attn_persist = 0;
+static constexpr int g_local_kernel = 1;
 #endif
 
 template <typename T, int D>
@@ -812,6 +929,18 @@ static int launch_attend(int64_t B, int q_len, int heads, const void* qkv, int64
     ProfScope ps(BT_PROF_ATTN_ROWS, s);
     const int64_t cap = ceil_div(n_max, n_split);
     const dim3 grid((unsigned)(B * heads * q_len), (unsigned)n_split);
+    if constexpr (D == 128 && sizeof(T) == 2) {
+        // token-decoder local window: the dedicated wave-per-(sequence, head) kernel (host-known position, <= 12 keys, <= 2 rows)
+        if (g_local_kernel && n_split == 1 && pos0_dev == nullptr && pos0_host + q_len <= 12 && q_len <= 2 && n_max <= 64) {
+            const int64_t items = B * heads;
+            constexpr int HPW = 2;
+            hipLaunchKernelGGL((local_attend_kernel<128, HPW>), dim3((unsigned)ceil_div(items, 4 * HPW)), dim3(256), 0, s,
+                               (const bf16*)qkv, ld_qkv, (const bf16*)kc, (const bf16*)vc, n_max, pos0_host, mask, mask_ld,
+                               (bf16*)out, ldo, q_len, heads, items, scale);
+            BT_LAUNCH_CHECK("bt_attention(local window) launch");
+            return BT_OK;
+        }
+    }
     if (n_max <= 64 && n_split == 1) {
         const size_t shm = (4 + 1 * D + cap) * sizeof(float);
         hipLaunchKernelGGL((attend_rows_kernel<T, D, 1>), grid, dim3(64), shm, s, (const T*)qkv, ld_qkv, (const T*)kc,
@@ -1007,4 +1136,5 @@ int bt::attention_impl(int dtype, int mode, int64_t B, int32_t q_len, int32_t he
 extern "C" void bt_debug_flash_variant(int v) { bt::g_flash_variant = v; }
 extern "C" void bt_debug_attn_nt(int v) { bt::g_attn_nt = v; }
 extern "C" void bt_debug_attn_persist(int v) { bt::g_attn_persist = v; }
+extern "C" void bt_debug_local_kernel(int v) { bt::g_local_kernel = v; }
 #endif

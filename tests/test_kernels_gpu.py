@@ -800,3 +800,22 @@ def test_small_tile_ring_depth(M, N, K, stages, dbg_lib):
             dbg_lib.bt_debug_small_stages(0)
     assert rel_err(outs[stages].double(), ref) <= 1.2e-2
     assert torch.equal(outs[stages], outs[2])
+
+
+@pytest.mark.parametrize("B,heads", [(3, 2), (5, 16), (64, 16)])
+@pytest.mark.parametrize("q,pos0,n_max", [(2, 0, 5), (1, 2, 5), (1, 4, 5), (2, 0, 9), (1, 8, 9), (1, 11, 12), (2, 9, 16)])
+def test_attention_local_window_kernel(B, heads, q, pos0, n_max, dbg_lib):
+    """The dedicated token-decoder window kernel (one wave per (sequence, head), all query rows, registers + wave shuffles only)
+    vs the fp64 reference and vs the generic row-wise kernel (bt_debug_local_kernel(0)); odd item counts exercise the tail of the
+    2-items-per-wave grid; a key mask hides one cached row."""
+    mask = torch.ones(B, n_max, dtype=torch.uint8)
+    if pos0 >= 2:
+        mask[B // 2, 1] = 0
+    out, ref = run_attention(torch.bfloat16, 0, B, q, heads, 128, pos0, n_max, mask)
+    assert rel_err(out, ref) <= 1.5e-2
+    dbg_lib.bt_debug_local_kernel(0)
+    try:
+        old, _ = run_attention(torch.bfloat16, 0, B, q, heads, 128, pos0, n_max, mask)
+    finally:
+        dbg_lib.bt_debug_local_kernel(1)
+    assert (out.float() - old.float()).abs().max() <= 2.0 ** -7 * ref.abs().max()
