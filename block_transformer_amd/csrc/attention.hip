@@ -309,14 +309,14 @@ __global__ __launch_bounds__(NW * 64) void attend_rows_kernel(const T* __restric
 // With <= 12 keys an LDS-resident K/V tile would be written once and read once -- registers ARE the resident tile.
 // HPW = (sequence, head) items per wave, processed back to back with all their loads in flight together: the kernel is
 // latency-bound (tens of thousands of tiny items), not bandwidth-bound.
-template <int D, int HPW>
+template <int D, int HPW, int U>
 __global__ __launch_bounds__(256) void local_attend_kernel(const bf16* __restrict__ qkv, int64_t ld_qkv, const bf16* __restrict__ kc,
                                                           const bf16* __restrict__ vc, int64_t n_max, int pos0,
                                                           const uint8_t* __restrict__ mask, int64_t mask_ld,
                                                           bf16* __restrict__ out, int64_t ldo, int q_len, int heads,
                                                           int64_t items, float scale) {
     static_assert(D == 128, "one 16-lane group per 256-byte row");
-    constexpr int U = 3;                       // row batches of 4 keys: window <= 12 rows
+    // U = row batches of 4 keys this instantiation fetches: 2 (window <= 8 rows: L = 4) or 3 (<= 12 rows: L = 8)
     constexpr int QMAX = 2;                    // query rows per call (E = 2 prefix rows at step 0, 1 afterwards)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, sub = lane >> 4;
@@ -934,9 +934,14 @@ static int launch_attend(int64_t B, int q_len, int heads, const void* qkv, int64
         if (g_local_kernel && n_split == 1 && pos0_dev == nullptr && pos0_host + q_len <= 12 && q_len <= 2 && n_max <= 64) {
             const int64_t items = B * heads;
             constexpr int HPW = 2;
-            hipLaunchKernelGGL((local_attend_kernel<128, HPW>), dim3((unsigned)ceil_div(items, 4 * HPW)), dim3(256), 0, s,
-                               (const bf16*)qkv, ld_qkv, (const bf16*)kc, (const bf16*)vc, n_max, pos0_host, mask, mask_ld,
-                               (bf16*)out, ldo, q_len, heads, items, scale);
+            if (pos0_host + q_len <= 8)
+                hipLaunchKernelGGL((local_attend_kernel<128, HPW, 2>), dim3((unsigned)ceil_div(items, 4 * HPW)), dim3(256), 0, s,
+                                   (const bf16*)qkv, ld_qkv, (const bf16*)kc, (const bf16*)vc, n_max, pos0_host, mask, mask_ld,
+                                   (bf16*)out, ldo, q_len, heads, items, scale);
+            else
+                hipLaunchKernelGGL((local_attend_kernel<128, HPW, 3>), dim3((unsigned)ceil_div(items, 4 * HPW)), dim3(256), 0, s,
+                                   (const bf16*)qkv, ld_qkv, (const bf16*)kc, (const bf16*)vc, n_max, pos0_host, mask, mask_ld,
+                                   (bf16*)out, ldo, q_len, heads, items, scale);
             BT_LAUNCH_CHECK("bt_attention(local window) launch");
             return BT_OK;
         }
