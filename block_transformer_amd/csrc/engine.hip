@@ -21,9 +21,16 @@ static int g_few_rows_max = 16;
 extern "C" void bt_debug_few_rows_max(int n) { g_few_rows_max = n; }
 static bool g_no_few_rows_fusion = false;   // run 1..16-row stacks through the unfused launch sequence (A/B, parity)
 extern "C" void bt_debug_no_few_rows_fusion(int on) { g_no_few_rows_fusion = on != 0; }
+// > 64 rows: attention.dense + dense_4h_to_h as ONE GEMM over K = I + H (bt_linear2).  Measured (profiles/r2_probe_lin2.jsonl,
+// r2_bench_lin2.json): the two-pair persistent kernel is 4-7 % SLOWER than the two launches at M >= 8192 (1.18 vs 1.13 ms at
+// M = 32768; the extra operand state spills scalars inside the K loop), a wash at M = 4096, and the default bench drops
+// 117.9k -> 115.9k tok/s -> off; the debug build can turn it on for the A/B test.
+static bool g_lin2_large = false;
+extern "C" void bt_debug_lin2_large(int on) { g_lin2_large = on != 0; }
 #else
 static constexpr int g_few_rows_max = 16;
 static constexpr bool g_no_few_rows_fusion = false;
+static constexpr bool g_lin2_large = false;
 #endif
 
 static int64_t ws_elems(const bt_decoder_dims* d, int64_t M) {
@@ -178,9 +185,18 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
             BT_TRY(attention_impl(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc,
                                 attn->n_max, attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H,
                                 attn->n_split, attn->split_ws, attn->split_ws_bytes, skip, stream));
-            BT_TRY(bt_linear_ws(dtype, M, H, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, BT_ACT_NONE, scratch, sk_bytes, stream));
-            BT_TRY(bt_linear_ws(dtype, M, I, H, ln2, H, lw.h4_w, lw.h4_b, nullptr, 0, h4, I, BT_ACT_GELU, scratch, sk_bytes, stream));
-            BT_TRY(bt_linear_ws(dtype, M, H, I, h4, I, lw.h_w, lw.h_b, x, H, x, H, BT_ACT_NONE, scratch, sk_bytes, stream));
+            const bool lin2_rows = g_lin2_large && dtype == BT_BF16 && M > 64 && H % 64 == 0 && I % 64 == 0 && lw.h_b &&
+                                   lw.dense_b && aligned16(lw.h_b) && aligned16(lw.dense_b) && aligned16(lw.h_w) &&
+                                   aligned16(lw.dense_w) && aligned16(x);
+            if (lin2_rows) {
+                // parallel residual: x += att Wd^T + bd + h4 W2^T + b2 as ONE GEMM over K = I + H (x read and written once)
+                BT_TRY(bt_linear_ws(dtype, M, I, H, ln2, H, lw.h4_w, lw.h4_b, nullptr, 0, h4, I, BT_ACT_GELU, scratch, sk_bytes, stream));
+                BT_TRY(bt_linear2(dtype, M, H, I, h4, I, lw.h_w, lw.h_b, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, stream));
+            } else {
+                BT_TRY(bt_linear_ws(dtype, M, H, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, BT_ACT_NONE, scratch, sk_bytes, stream));
+                BT_TRY(bt_linear_ws(dtype, M, I, H, ln2, H, lw.h4_w, lw.h4_b, nullptr, 0, h4, I, BT_ACT_GELU, scratch, sk_bytes, stream));
+                BT_TRY(bt_linear_ws(dtype, M, H, I, h4, I, lw.h_w, lw.h_b, x, H, x, H, BT_ACT_NONE, scratch, sk_bytes, stream));
+            }
         } else {
             // one query row per sequence: row (q_len - 1) at cache position pos0 + q_len - 1; row-wise kernel, q_len = 1
             const char* ql = reinterpret_cast<const char*>(qkv) + (int64_t)(q_len - 1) * 3 * H * es;

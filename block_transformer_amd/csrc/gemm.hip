@@ -88,6 +88,7 @@ struct QkvEpi {
 
 struct EpiArgs {
     const bf16* bias;
+    const bf16* bias2;   // optional second bias row (two projections summed by one GEMM); LDS-staged epilogues only
     const bf16* res;
     int64_t ldr;
     bf16* out;
@@ -198,16 +199,21 @@ __device__ inline void epi_to_lds(const EpiArgs& e, char* ctile, int ml, int nl,
                                   const f32x4_t& a_hi) {
     float lo[4] = {a_lo[0], a_lo[1], a_lo[2], a_lo[3]};
     float hi[4] = {a_hi[0], a_hi[1], a_hi[2], a_hi[3]};
-    if (BIAS && e.bias) {
-        if (n_lo < e.N) {
-            const uint2 b2 = *reinterpret_cast<const uint2*>(e.bias + n_lo);
-            lo[0] += __uint_as_float(b2.x << 16); lo[1] += __uint_as_float(b2.x & 0xffff0000u);
-            lo[2] += __uint_as_float(b2.y << 16); lo[3] += __uint_as_float(b2.y & 0xffff0000u);
-        }
-        if (n_lo + 16 < e.N) {
-            const uint2 b3 = *reinterpret_cast<const uint2*>(e.bias + n_lo + 16);
-            hi[0] += __uint_as_float(b3.x << 16); hi[1] += __uint_as_float(b3.x & 0xffff0000u);
-            hi[2] += __uint_as_float(b3.y << 16); hi[3] += __uint_as_float(b3.y & 0xffff0000u);
+    if (BIAS) {
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const bf16* bp = which ? e.bias2 : e.bias;
+            if (!bp) continue;
+            if (n_lo < e.N) {
+                const uint2 b2 = *reinterpret_cast<const uint2*>(bp + n_lo);
+                lo[0] += __uint_as_float(b2.x << 16); lo[1] += __uint_as_float(b2.x & 0xffff0000u);
+                lo[2] += __uint_as_float(b2.y << 16); lo[3] += __uint_as_float(b2.y & 0xffff0000u);
+            }
+            if (n_lo + 16 < e.N) {
+                const uint2 b3 = *reinterpret_cast<const uint2*>(bp + n_lo + 16);
+                hi[0] += __uint_as_float(b3.x << 16); hi[1] += __uint_as_float(b3.x & 0xffff0000u);
+                hi[2] += __uint_as_float(b3.y << 16); hi[3] += __uint_as_float(b3.y & 0xffff0000u);
+            }
         }
     }
     if (e.act == BT_ACT_GELU) {
@@ -426,19 +432,27 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restr
 #pragma unroll
         for (int j = 0; j < FM; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
-    const int nk = K / BK;
+    // K-tiles: the first operand pair's, then (not SPLITK: one launch over both K ranges) the optional second pair's --
+    // out = A.W^T + A2.W2^T, the two residual-stream projections of a parallel-residual layer as ONE GEMM over K = K1 + K2
+    const int nk1 = K / BK;
+    const int nk = nk1 + ((!SPLITK && s2.K > 0) ? s2.K / BK : 0);
+    auto stage_pair = [&](int ti, char* dst) {
+        if (!SPLITK && ti >= nk1) {
+            stage_tile<TBM>(s2.x, s2.ldx, m0, M, (ti - nk1) * BK, dst, wave, lane);
+            stage_tile<TBN>(s2.w, s2.ldw, n0, N, (ti - nk1) * BK, dst + A_BYTES, wave, lane);
+        } else {
+            stage_tile<TBM>(A, lda, m0, M, ti * BK, dst, wave, lane);
+            stage_tile<TBN>(W, ldw, n0, N, ti * BK, dst + A_BYTES, wave, lane);
+        }
+    };
     if constexpr (NS == 2) {
-        stage_tile<TBM>(A, lda, m0, M, 0, smem, wave, lane);
-        stage_tile<TBN>(W, ldw, n0, N, 0, smem + A_BYTES, wave, lane);
+        stage_pair(0, smem);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     } else {
 #pragma unroll
         for (int s0 = 0; s0 < NS - 1; ++s0)
-            if (s0 < nk) {
-                stage_tile<TBM>(A, lda, m0, M, s0 * BK, smem + s0 * STAGE, wave, lane);
-                stage_tile<TBN>(W, ldw, n0, N, s0 * BK, smem + s0 * STAGE + A_BYTES, wave, lane);
-            }
+            if (s0 < nk) stage_pair(s0, smem + s0 * STAGE);
     }
 
     for (int t = 0; t < nk; ++t) {
@@ -446,11 +460,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restr
         if constexpr (NS == 2) {
             const int cur = t & 1;
             a_cur = smem + cur * STAGE;
-            if (t + 1 < nk) {
-                char* a_nxt = smem + (cur ^ 1) * STAGE;
-                stage_tile<TBM>(A, lda, m0, M, (t + 1) * BK, a_nxt, wave, lane);
-                stage_tile<TBN>(W, ldw, n0, N, (t + 1) * BK, a_nxt + A_BYTES, wave, lane);
-            }
+            if (t + 1 < nk) stage_pair(t + 1, smem + (cur ^ 1) * STAGE);
         } else {
             // tiles issued after tile t so far: min(nk - 1, t + NS - 2) - t  (each IPT DMA instructions of this wave)
             const int younger = min(nk - 1, t + NS - 2) - t;
@@ -460,11 +470,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restr
             cbarrier();
             a_cur = smem + (t % NS) * STAGE;
             const int tn_ = t + NS - 1;
-            if (tn_ < nk) {
-                char* a_nxt = smem + (tn_ % NS) * STAGE;
-                stage_tile<TBM>(A, lda, m0, M, tn_ * BK, a_nxt, wave, lane);
-                stage_tile<TBN>(W, ldw, n0, N, tn_ * BK, a_nxt + A_BYTES, wave, lane);
-            }
+            if (tn_ < nk) stage_pair(tn_, smem + (tn_ % NS) * STAGE);
         }
         char* w_cur = a_cur + A_BYTES;
 #pragma unroll
@@ -1449,7 +1455,8 @@ struct Mma16 {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, c, 0, 0, 0);
     }
     // accumulators <- bias row in LDS (bias_row = LDS byte address of the tile's 256-column bf16 row), or zero
-    __device__ static inline void init(Acc (&acc)[8][4], bool has_bias, uint32_t bias_row, int wcol, int lane) {
+    // has_bias2: the second half of the 1 KiB row holds a second bias (bt_linear2) -> start at the sum of the two
+    __device__ static inline void init(Acc (&acc)[8][4], bool has_bias, bool has_bias2, uint32_t bias_row, int wcol, int lane) {
         if (has_bias) {
             // inline asm: a compiler-visible LDS read of a DMA-written region would get a vmcnt(0) in front
             uint64_t b[4];
@@ -1460,11 +1467,23 @@ struct Mma16 {
                          : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
                          : "v"(ba)
                          : "memory");
+            f32x4_t bv[4];
+#pragma unroll
+            for (int jf = 0; jf < 4; ++jf) bv[jf] = bf16x4_to_f32(b[jf]);
+            if (has_bias2) {
+                asm volatile("ds_read_b64 %0, %4 offset:512\n\tds_read_b64 %1, %4 offset:544\n\t"
+                             "ds_read_b64 %2, %4 offset:576\n\tds_read_b64 %3, %4 offset:608\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(b[0]), "=&v"(b[1]), "=&v"(b[2]), "=&v"(b[3])
+                             : "v"(ba)
+                             : "memory");
+#pragma unroll
+                for (int jf = 0; jf < 4; ++jf) bv[jf] += bf16x4_to_f32(b[jf]);
+            }
 #pragma unroll
             for (int jf = 0; jf < 4; ++jf) {
-                const f32x4_t bv = bf16x4_to_f32(b[jf]);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i][jf] = bv;
+                for (int i = 0; i < 8; ++i) acc[i][jf] = bv[jf];
             }
         } else {
 #pragma unroll
@@ -1643,7 +1662,7 @@ struct Mma32 {
     __device__ static inline Acc mma(const bf16x8_t& w, const bf16x8_t& a, const Acc& c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_bf16(w, a, c, 0, 0, 0);
     }
-    __device__ static inline void init(Acc (&acc)[4][2], bool has_bias, uint32_t bias_row, int wcol, int lane) {
+    __device__ static inline void init(Acc (&acc)[4][2], bool has_bias, bool /*has_bias2: Mma16 only*/, uint32_t bias_row, int wcol, int lane) {
         if (has_bias) {
             uint64_t b[8];   // [nb][q]: columns nb * 32 + 8q + 4 (lane >> 5) .. + 3
             const uint32_t ba = bias_row + (wcol + (lane >> 5) * 4) * 2;
@@ -1688,10 +1707,10 @@ struct LoadCursor {   // wave-uniform: the K-tile whose half-tiles are being iss
     bool valid;
 };
 
-template <int MODE, typename P>
+template <int MODE, typename P, bool SEG2 = false>
 __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __restrict__ A, int64_t lda,
                                                                  const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
-                                                                 int K, int tiles_m, int tiles_n) {
+                                                                 int K, int tiles_m, int tiles_n, const Seg2 s2) {
     const int M = ep.M, N = ep.N;
     __shared__ __attribute__((aligned(16))) char smem[PP_SMEM];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1705,8 +1724,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
     const uint32_t lane_slot = (uint32_t)(((lane & 7) ^ ((lane >> 3) & 7)) * 16);
     const uint32_t voff_a = (uint32_t)(lane >> 3) * (uint32_t)(lda * 2) + lane_slot;
     const uint32_t voff_w = (uint32_t)(lane >> 3) * (uint32_t)(ldw * 2) + lane_slot;
+    // optional second operand pair (bt_linear2): K-tiles nk1 .. nk-1 stream s2.x / s2.w into the same accumulators
+    const uint32_t voff_a2 = (uint32_t)(lane >> 3) * (uint32_t)(s2.ldx * 2) + lane_slot;
+    const uint32_t voff_w2 = (uint32_t)(lane >> 3) * (uint32_t)(s2.ldw * 2) + lane_slot;
 
-    const int nk = K / BK;
+    const int nk1 = K / BK;
+    const int nk = nk1 + (SEG2 ? s2.K / BK : 0);
     // tiles of this workgroup: rounds 0 .. nt-1 (all workgroups have the full rounds; the last round may be partial)
     const int nwg = tiles_m * tiles_n;
     const int G = gridDim.x;
@@ -1721,14 +1744,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
     lc.t = 0; lc.j = 0; lc.x = 0;
     lc.valid = pp_tile(0, tiles_m, tiles_n, lc.m0, lc.n0);
     auto issue = [&](int kind) {
-        if (lc.valid)
-            stage_half_at(A, lda, W, ldw, lc.m0, lc.n0, M, N, lc.t * BK, lc.x & 1, kind, smem, wave, lane, voff_a, voff_w);
+        if (lc.valid) {
+            if (!SEG2 || lc.t < nk1)
+                stage_half_at(A, lda, W, ldw, lc.m0, lc.n0, M, N, lc.t * BK, lc.x & 1, kind, smem, wave, lane, voff_a, voff_w);
+            else
+                stage_half_at(s2.x, s2.ldx, s2.w, s2.ldw, lc.m0, lc.n0, M, N, (lc.t - nk1) * BK, lc.x & 1, kind, smem, wave,
+                              lane, voff_a2, voff_w2);
+        }
     };
-    auto issue_bias = [&]() {   // wave 0: bias[n0 .. n0+255] of the cursor's tile -> LDS row (j & 1), before that tile's loads
+    // wave 0: bias[n0 .. n0+255] of the cursor's tile -> LDS row (j & 1), before that tile's loads.  The row is 1 KiB = 64
+    // lanes x 16 B but the tile's bias is 512 B: lanes 32..63 fetch the second pair's bias (or the same bytes again)
+    const bf16* bias_hi = (SEG2 && s2.bias) ? s2.bias : ep.bias;
+    auto issue_bias = [&]() {
         if (wave == 0 && ep.bias && lc.valid) {
             int col = lc.n0 + (lane & 31) * 8;
             col = col <= N - 8 ? col : N - 8;
-            glds16_vaddr(ep.bias + col, lds_addr(smem + PP_BIAS_OFF + (lc.j & 1) * 1024));
+            glds16_vaddr((lane < 32 ? ep.bias : bias_hi) + col, lds_addr(smem + PP_BIAS_OFF + (lc.j & 1) * 1024));
         }
     };
     auto advance = [&]() {
@@ -1770,7 +1801,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
                 cbarrier();
                 if (p == 0) {
                     // new tile: accumulators start at the bias (LDS row j & 1, landed before this barrier)
-                    if (t == 0) P::init(acc, ep.bias != nullptr, lds_addr(smem + PP_BIAS_OFF + (j & 1) * 1024), wcol, lane);
+                    if (t == 0) P::init(acc, ep.bias != nullptr, SEG2 && s2.bias != nullptr, lds_addr(smem + PP_BIAS_OFF + (j & 1) * 1024), wcol, lane);
 #pragma unroll
                     for (int ks = 0; ks < P::KS; ++ks) {
 #pragma unroll
@@ -2430,7 +2461,9 @@ using namespace bt;
 static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* W,
                        const void* bias, const void* residual, int64_t ldr, void* out, int64_t ldo, int act,
                        const QkvEpi* qkv, bool* fused_out, bt_stream stream, void* scratch = nullptr,
-                       int64_t scratch_bytes = 0) {
+                       int64_t scratch_bytes = 0, const Seg2* seg2 = nullptr) {
+    // seg2 (bt_linear2, > 64 rows): a second (x2, W2, bias2) operand pair accumulated into the same output tiles; only
+    // the persistent 256^2 kernel and the non-split small-tile family take it -> BT_ERR_UNSUPPORTED otherwise
     BT_CHECK_ARG(dtype == BT_F32 || dtype == BT_BF16, "bt_linear: bad dtype %d", dtype);
     BT_CHECK_ARG(M >= 0 && N > 0 && K > 0, "bt_linear: bad shape M=%lld N=%lld K=%lld", (long long)M, (long long)N,
                  (long long)K);
@@ -2446,7 +2479,7 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                              (ldo % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 7u) == 0) &&
                              (!residual || ((ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(residual) & 7u) == 0)) &&
                              (!bias || (reinterpret_cast<uintptr_t>(bias) & 7u) == 0);
-        EpiArgs ep;
+        EpiArgs ep{};
         ep.bias = (const bf16*)bias;
         ep.res = (const bf16*)residual;
         ep.ldr = ldr;
@@ -2456,6 +2489,19 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
         ep.N = (int)N;
         ep.act = act;
         ep.q = QkvEpi{};
+        Seg2 s2{};
+        if (seg2) {
+            const bool seg_ok = mfma_ok && !qkv && bias && seg2->bias && aligned16(bias) && aligned16(seg2->bias) &&
+                                seg2->K > 0 && seg2->K % BK == 0 && seg2->ldx % 8 == 0 && seg2->ldw % 8 == 0 &&
+                                aligned16(seg2->x) && aligned16(seg2->w) && (N % 8 == 0) && (ldo % 8 == 0) && aligned16(out) &&
+                                (!residual || (ldr % 8 == 0 && aligned16(residual)));
+            if (!seg_ok) {
+                set_error("bt_linear2: > 64 rows need bf16, both biases, K1 %% 64 == K2 %% 64 == 0, N %% 8 == 0 and 16-byte aligned operands");
+                return BT_ERR_UNSUPPORTED;
+            }
+            s2 = *seg2;
+            ep.bias2 = s2.bias;   // small-tile family: the epilogue adds both; the persistent kernel starts from their sum
+        }
         // fused QKV epilogue: only on the MFMA kernels, rot == 32 (checked by the caller), 32-aligned head_dim
         if (qkv && mfma_ok && !g_no_qkv_fusion) {
             ep.q = *qkv;
@@ -2464,9 +2510,12 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
         }
         const int64_t tiles256 = ceil_div(M, BM2) * ceil_div(N, BN2);
         // big-tile kernel: one 8-wave workgroup per CU -> needs >= ~1 full wave of 256 tiles and little tail quantisation
+        const bool pp_ok = (N % 8 == 0) && (ldo % 8 == 0) && aligned16(out) && (K + s2.K) / BK >= 4 &&
+                           (!residual || (ldr % 8 == 0 && aligned16(residual))) && (!bias || aligned16(bias));
         const bool use256 = mfma_ok && g_gemm_variant != 1 && (N % 4 == 0) &&
                             (g_gemm_variant >= 2 || (tiles256 >= 240 && (tiles256 % 256 == 0 || tiles256 >= 1024 ||
-                                                                         (tiles256 % 256) >= 160)));
+                                                                         (tiles256 % 256) >= 160))) &&
+                            (!seg2 || (pp_ok && (g_gemm_variant == 0 || g_gemm_variant == 14)));
         if (use256) {
             ProfScope ps(BT_PROF_LINEAR_MFMA, s);
             const int tiles_m = (int)ceil_div(M, BM2), tiles_n = (int)ceil_div(N, BN2);
@@ -2494,15 +2543,13 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
 #endif
             {
                 {
-                    const bool pp_ok = (N % 8 == 0) && (ldo % 8 == 0) && aligned16(out) && K / BK >= 4 &&
-                                       (!residual || (ldr % 8 == 0 && aligned16(residual))) && (!bias || aligned16(bias));
                     if (pp_ok) {   // production: persistent, per-wave epilogue
                         const int n_wg = (int)std::min<int64_t>((int64_t)tiles_m * tiles_n, g_max_wg > 0 ? g_max_wg : num_cus());
 #ifdef BT_DEBUG_HOOKS   /* A/B: 32x32x16 MFMA blocks (measured 5-8 % slower in this schedule) */
 #define BT_PP_MMA32_AB(MODE_)                                                                                       \
     if (g_gemm_variant == 14)                                                                                       \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp_kernel<MODE_, Mma32>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,   \
-                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
+                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n, Seg2{});                           \
     else
 #else
 #define BT_PP_MMA32_AB(MODE_)
@@ -2511,15 +2558,21 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
     do {                                                                                                              \
         BT_PP_MMA32_AB(MODE_)                                                                                       \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp_kernel<MODE_, Mma16>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,     \
-                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                     \
+                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n, Seg2{});                             \
     } while (0)
+#define BT_LAUNCH_PP2(MODE_)                                                                                          \
+    hipLaunchKernelGGL((gemm_bf16_mfma256pp_kernel<MODE_, Mma16, true>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,   \
+                       lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n, s2)
                         // (the engine never combines these: QKV has no activation / residual, GELU has no residual)
-                        if (ep.q.enabled) BT_LAUNCH_PP(PP_QKV);
+                        if (seg2 && residual) BT_LAUNCH_PP2(PP_RES);
+                        else if (seg2) BT_LAUNCH_PP2(PP_PLAIN);
+                        else if (ep.q.enabled) BT_LAUNCH_PP(PP_QKV);
                         else if (act == BT_ACT_GELU && !residual) BT_LAUNCH_PP(PP_GELU);
                         else if (act == BT_ACT_NONE && residual) BT_LAUNCH_PP(PP_RES);
                         else if (act == BT_ACT_NONE) BT_LAUNCH_PP(PP_PLAIN);
                         else BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<true>));   // GELU + residual: one-tile kernel
 #undef BT_LAUNCH_PP
+#undef BT_LAUNCH_PP2
 #undef BT_PP_MMA32_AB
                     } else {
                         BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<true>));
@@ -2527,7 +2580,7 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                 }
             }
 #undef BT_LAUNCH_256
-        } else if (M <= 4 && !ep.q.enabled && g_gemm_variant != 1 && g_gemm_variant != 22 && (K % 512 == 0) && (lda % 8 == 0) &&
+        } else if (!seg2 && M <= 4 && !ep.q.enabled && g_gemm_variant != 1 && g_gemm_variant != 22 && (K % 512 == 0) && (lda % 8 == 0) &&
                    (K % 8 == 0) && aligned16(A) && aligned16(W) && !g_force_generic) {
             // a handful of rows: pure weight streaming (one launch, no fp32 partials).  Measured (bench.py, hipGraph replay):
             // B = 1 decode 700 -> 1084 tok/s; at M = 8 the per-row VALU work catches up with the split-K MFMA path, so M <= 4.
@@ -2549,12 +2602,12 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
             else BT_GEMV_RW(4);
 #undef BT_GEMV_RW
 #undef BT_LAUNCH_GEMV
-        } else if (M <= g_skinny_rows && M <= 64 && !ep.q.enabled && g_gemm_variant != 1 && g_gemm_variant != 22 && !g_force_generic &&
+        } else if (!seg2 && M <= g_skinny_rows && M <= 64 && !ep.q.enabled && g_gemm_variant != 1 && g_gemm_variant != 22 && !g_force_generic &&
                    skinny_ok(M, N, K, A, lda, W, bias, residual, ldr, out, ldo)) {
             // 5 .. 64 rows: one pass over W on the matrix pipe, one launch (no fp32 partials, no reduce kernel)
             ProfScope ps(BT_PROF_LINEAR_MFMA, s);
             launch_skinny<false, false>(s, M, N, (const bf16*)A, lda, (const bf16*)W, K, ep, K, LnPro{}, Seg2{});
-        } else if (mfma_ok && scratch && !ep.q.enabled && g_gemm_variant != 1 && (N % 8 == 0) && (ldo % 8 == 0) &&
+        } else if (!seg2 && mfma_ok && scratch && !ep.q.enabled && g_gemm_variant != 1 && (N % 8 == 0) && (ldo % 8 == 0) &&
                    aligned16(out) && (!residual || (ldr % 8 == 0 && aligned16(residual))) && (!bias || aligned16(bias)) &&
                    aligned16(scratch) && ceil_div(M, 64) * ceil_div(N, 64) < 256) {
             // skinny regime: even 64x64 tiles leave CUs idle -> split K until >= ~256 workgroups stream W concurrently
@@ -2596,7 +2649,7 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
             BT_CHECK_ARG((int64_t)tiles_m * tiles_n < (1ll << 31), "bt_linear: grid too large");
 #define BT_LAUNCH_GEMM(TM_, TN_, NS_)                                                                                   \
     hipLaunchKernelGGL((gemm_bf16_mfma_kernel<TM_, TN_, false, NS_>), dim3(tiles_m * tiles_n), dim3(256), 0, s,             \
-                       (const bf16*)A, lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n, nullptr)
+                       (const bf16*)A, lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n, nullptr, s2)
             // ring depth per tile: 64x64 x 4 stages and 128x64 x 3 stages still fit two workgroups per CU (64 / 72 KiB)
             // measured (profiles/r2_ring_ab.jsonl): 64x64 x 4 stages 1.2-1.5x faster at K >= 2048, 128x64 x 3 stages +7 %;
             // 128x128 x 3 stages (one workgroup per CU instead of two) 1.4x SLOWER -> the 128^2 tile keeps the double buffer
@@ -2695,7 +2748,7 @@ extern "C" int bt_ln_linear(int dtype, int64_t M, int64_t N, int64_t K, const vo
         return BT_ERR_UNSUPPORTED;
     }
     hipStream_t s = (hipStream_t)stream;
-    EpiArgs ep;
+    EpiArgs ep{};
     ep.bias = (const bf16*)bias;
     ep.res = (const bf16*)residual;
     ep.ldr = ldr;
@@ -2757,7 +2810,7 @@ extern "C" int bt_ln_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_
         return BT_ERR_UNSUPPORTED;
     }
     hipStream_t s = (hipStream_t)stream;
-    EpiArgs ep;
+    EpiArgs ep{};
     ep.bias = (const bf16*)qkv_b;
     ep.res = nullptr;
     ep.ldr = 0;
@@ -2809,6 +2862,19 @@ extern "C" int bt_linear2(int dtype, int64_t M, int64_t N, int64_t K1, const voi
                           const void* bias1, int64_t K2, const void* x2, int64_t ldx2, const void* W2, const void* bias2,
                           const void* residual, int64_t ldr, void* out, int64_t ldo, bt_stream stream) {
     BT_CHECK_ARG(x1 && W1 && x2 && W2 && out, "bt_linear2: null pointer");
+    if (dtype == BT_BF16 && M > 64) {
+        // large stacks: one MFMA GEMM over K = K1 + K2 (persistent 256^2 kernel or the small-tile family), both biases and
+        // the residual in its epilogue -- the residual stream is read and written once instead of twice
+        Seg2 seg;
+        seg.x = (const bf16*)x2;
+        seg.w = (const bf16*)W2;
+        seg.bias = (const bf16*)bias2;
+        seg.ldx = ldx2;
+        seg.ldw = K2;
+        seg.K = (int)K2;
+        return linear_impl(dtype, M, N, K1, x1, ldx1, W1, bias1, residual, ldr, out, ldo, BT_ACT_NONE, nullptr, nullptr, stream,
+                           nullptr, 0, &seg);
+    }
     const bool ok = dtype == BT_BF16 && M >= 1 && M <= 4 && N > 0 && K1 % GV_KC == 0 && K2 % 512 == 0 && K1 > 0 && K2 > 0 &&
                     ldx1 % 8 == 0 && ldx2 % 8 == 0 && aligned16(x1) && aligned16(x2) && aligned16(W1) && aligned16(W2) &&
                     !g_force_generic && g_gemm_variant != 22;
@@ -2816,12 +2882,12 @@ extern "C" int bt_linear2(int dtype, int64_t M, int64_t N, int64_t K1, const voi
                         skinny_ok(M, N, K1, x1, ldx1, W1, bias1, residual, ldr, out, ldo) &&
                         (!bias2 || (reinterpret_cast<uintptr_t>(bias2) & 7u) == 0) && !g_force_generic && g_gemm_variant != 22;
     if (!ok && !skinny) {
-        set_error("bt_linear2: only bf16 with 1 <= M <= 4 (K1 %% %d == 0, K2 %% 512 == 0) or 5 <= M <= 64 (K %% 32 == 0, N %% 4 == 0), "
-                  "16-byte aligned operands", GV_KC);
+        set_error("bt_linear2: only bf16 with 1 <= M <= 4 (K1 %% %d == 0, K2 %% 512 == 0), 5 <= M <= 64 (K %% 32 == 0, N %% 4 == 0) or "
+                  "M > 64 (K %% 64 == 0, N %% 8 == 0, both biases), 16-byte aligned operands", GV_KC);
         return BT_ERR_UNSUPPORTED;
     }
     hipStream_t s = (hipStream_t)stream;
-    EpiArgs ep;
+    EpiArgs ep{};
     ep.bias = (const bf16*)bias1;
     ep.res = (const bf16*)residual;
     ep.ldr = ldr;

@@ -152,7 +152,8 @@ int bt_ln_linear(int dtype, int64_t M, int64_t N, int64_t K, const void* x, int6
                  float eps, const void* W, const void* bias, const void* residual, int64_t ldr, void* out, int64_t ldo,
                  int act, bt_stream stream);
 /*   bt_linear2:            out = x1 . W1^T + bias1 + x2 . W2^T + bias2 + residual   (1..4 rows: K1 % 2048 == 0, K2 % 512 == 0;
- *                          5..64 rows: K % 32 == 0, N % 4 == 0): the two
+ *                          5..64 rows: K % 32 == 0, N % 4 == 0; > 64 rows: one MFMA GEMM over K1 + K2, K % 64 == 0,
+ *                          N % 8 == 0, both biases present; BT_ERR_UNSUPPORTED otherwise): the two
  *                          projections that feed the residual stream of a parallel-residual layer (attention.dense and
  *                          mlp.dense_4h_to_h) as one launch */
 int bt_linear2(int dtype, int64_t M, int64_t N, int64_t K1, const void* x1, int64_t ldx1, const void* W1, const void* bias1,

@@ -325,6 +325,53 @@ def test_linear2_two_projections_one_launch(M, N, K1, K2):
     assert torch.equal(hid[:, N:], pad)
 
 
+@pytest.mark.parametrize("M,N,K1,K2", [
+    (65, 2048, 8192, 2048), (200, 1000, 2048, 512), (1000, 2048, 8192, 2048),      # small-tile family (64x64 / 128x64)
+    (4096, 2048, 8192, 2048),                                                      # 128x128 tiles (the decode step's shape)
+    (7700, 2048, 8192, 2048), (8192, 2048, 1024, 256),                             # persistent 256^2 (partial last row tile)
+    (16384, 1024, 256, 128), (8192, 2048, 128, 128),                               # short K: ring wraps across tiles / pairs
+])
+def test_linear2_large_stack_one_gemm(M, N, K1, K2):
+    """bt_linear2 with > 64 rows: ONE MFMA GEMM over K1 + K2 with both biases and the residual in its epilogue (what
+    bt_decoder_forward runs for attention.dense + mlp.dense_4h_to_h on prefill / large-batch stacks) == fp64 and == the
+    two separate bt_linear calls; in place on a strided residual stream, strided second operand."""
+    x1 = rnd(M, K1, seed=1).bfloat16().to(DEV)
+    x2 = rnd(M, K2 + 8, seed=2).bfloat16().to(DEV)[:, :K2]
+    w1 = rnd(N, K1, seed=3, scale=K1 ** -0.5).bfloat16().to(DEV)
+    w2 = rnd(N, K2, seed=4, scale=K2 ** -0.5).bfloat16().to(DEV)
+    b1, b2 = rnd(N, seed=5).bfloat16().to(DEV), rnd(N, seed=6).bfloat16().to(DEV)
+    hid = rnd(M, N + 16, seed=7).bfloat16().to(DEV)
+    view = hid[:, :N]
+    ref = (view.double() + x1.double() @ w1.double().T + b1.double() + x2.double() @ w2.double().T + b2.double()).cpu()
+    two = ops.linear(x2.contiguous(), w2, b2, ops.linear(x1, w1, b1, view.contiguous())).double().cpu()
+    pad = hid[:, N:].clone()
+    check(lib().bt_linear2(_lib.BT_BF16, M, N, K1, ptr(x1), K1, ptr(w1), ptr(b1), K2, ptr(x2), x2.stride(0), ptr(w2), ptr(b2),
+                           ptr(view), hid.stride(0), ptr(view), hid.stride(0), current_stream()))
+    torch.cuda.synchronize()
+    got = view.double().cpu()
+    assert rel_err(got, ref) <= 8e-3, rel_err(got, ref)
+    err = (got - ref).abs()
+    assert float((err - 1e-2 * ref.abs() - 2e-2).max()) <= 0, float(err.max())   # elementwise: no tile / K-tile dropped
+    assert rel_err(got, two) <= 1.2e-2
+    assert torch.equal(hid[:, N:], pad)
+
+
+def test_linear2_large_stack_rejections():
+    M, N, K1, K2 = 128, 52, 2048, 512
+    x1, x2 = rnd(M, K1, seed=1).bfloat16().to(DEV), rnd(M, K2, seed=2).bfloat16().to(DEV)
+    w1, w2 = rnd(N, K1, seed=3).bfloat16().to(DEV), rnd(N, K2, seed=4).bfloat16().to(DEV)
+    b = rnd(64, seed=5).bfloat16().to(DEV)
+    out = torch.zeros(M, 64, dtype=torch.bfloat16, device=DEV)
+    rc = lib().bt_linear2(_lib.BT_BF16, M, N, K1, ptr(x1), K1, ptr(w1), ptr(b), K2, ptr(x2), K2, ptr(w2), ptr(b), None, 0,
+                          ptr(out), 64, current_stream())
+    assert rc == -2 and b"bt_linear2" in lib().bt_last_error()      # N % 8 != 0
+    rc = lib().bt_linear2(_lib.BT_BF16, M, 48, K1, ptr(x1), K1, ptr(w1), ptr(b), K2, ptr(x2), K2, ptr(w2), None, None, 0,
+                          ptr(out), 64, current_stream())
+    assert rc == -2                                                 # a missing bias
+    torch.cuda.synchronize()
+    assert float(out.abs().max()) == 0.0                            # nothing was launched
+
+
 def test_ln_linear_rejects_what_it_cannot_fuse():
     x = rnd(65, 4096, seed=1).bfloat16().to(DEV)
     w = rnd(64, 4096, seed=2).bfloat16().to(DEV)

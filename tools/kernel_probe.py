@@ -57,6 +57,32 @@ def probe_gemm(M, N, K, iters, act="none", bias=True, res=False, scratch=False, 
             "weight_GBps": round(N * K * 2 / (ms * 1e-3) / 1e9, 1)}
 
 
+def probe_lin2(M, N, K1, K2, iters):
+    """attention.dense (K2) + mlp.dense_4h_to_h (K1) onto the residual stream: one bt_linear2 GEMM vs the two bt_linear launches."""
+    x1 = torch.randn(M, K1, device=DEV).bfloat16()
+    x2 = torch.randn(M, K2, device=DEV).bfloat16()
+    w1 = (torch.randn(N, K1, device=DEV) * K1 ** -0.5).bfloat16()
+    w2 = (torch.randn(N, K2, device=DEV) * K2 ** -0.5).bfloat16()
+    b1, b2 = torch.randn(N, device=DEV).bfloat16(), torch.randn(N, device=DEV).bfloat16()
+    x = torch.randn(M, N, device=DEV).bfloat16()
+    st = current_stream()
+
+    def one():
+        check(lib().bt_linear2(_lib.BT_BF16, M, N, K1, ptr(x1), K1, ptr(w1), ptr(b1), K2, ptr(x2), K2, ptr(w2), ptr(b2), ptr(x), N,
+                               ptr(x), N, st))
+
+    def two():
+        ops.linear(x2, w2, b2, x, out=x)
+        ops.linear(x1, w1, b1, x, out=x)
+
+    out = {"op": "lin2", "M": M, "N": N, "K1": K1, "K2": K2}
+    for name, fn in (("two_ms", two), ("one_ms", one), ("two_ms_b", two), ("one_ms_b", one)):
+        out[name] = round(timed(fn, iters), 4)
+    out["TFLOPs_one"] = round(2.0 * M * N * (K1 + K2) / (min(out["one_ms"], out["one_ms_b"]) * 1e-3) / 1e12, 1)
+    out["TFLOPs_two"] = round(2.0 * M * N * (K1 + K2) / (min(out["two_ms"], out["two_ms_b"]) * 1e-3) / 1e12, 1)
+    return out
+
+
 def probe_attn(B, n, iters, heads=16, d=128, n_split=1, dtype=torch.bfloat16):
     H = heads * d
     n_max = n + 1
@@ -125,7 +151,7 @@ def probe_copy(nbytes, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=["gemm", "attn", "flash", "suite", "copy", "ab", "abl", "skinny", "decode", "vendor", "pitch",
-                                     "local"])
+                                     "local", "lin2"])
     ap.add_argument("--m", type=int, default=32768)
     ap.add_argument("--n", type=int, default=6144)
     ap.add_argument("--k", type=int, default=2048)
@@ -140,6 +166,9 @@ def main():
     lib().bt_debug_gemm_variant(args.variant)
     if args.what == "gemm":
         res.append(probe_gemm(args.m, args.n, args.k, args.iters))
+    elif args.what == "lin2":    # the residual-stream projections of block_main_b4_1.2b at decode / prefill stack heights
+        for M in (4096, 8192, 16384, 32768):
+            res.append(probe_lin2(M, 2048, 8192, 2048, args.iters))
     elif args.what == "local":   # the four local steps of a token block at batch --batch: step 0 (q = E = 2), then rows 2, 3, 4
         res.append(probe_local(args.batch, 2, 0, args.iters))
         for pos0 in (2, 3, 4):
