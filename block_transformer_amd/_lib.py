@@ -135,6 +135,7 @@ _DEBUG_SIGS = {
     "bt_debug_few_rows_max": (None, [c_int]),
     "bt_debug_no_few_rows_fusion": (None, [c_int]),
     "bt_debug_lin2_large": (None, [c_int]),
+    "bt_debug_ln_streaming": (None, [c_int]),
     "bt_debug_tr_probe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 

@@ -672,7 +672,12 @@ __device__ inline void flash_stage_tile(const bf16* __restrict__ kbase, const bf
 //              the SAME speed (287-307 TF at n = 512), i.e. the tile loop is not waiting for its loads -- it is
 //              instruction-issue / dependency bound (~450 non-MFMA instructions and ~30 waits per 64 MFMAs, two waves
 //              per SIMD at 240 VGPRs).  Kept as test variant 2.
-template <int D, int NW, int ST>
+//   OPT bits (A/B in the debug library): 1 = the first ST-1 K/V tiles are put in flight BEFORE the Q fragment loads (their
+//   latencies overlap instead of adding up: a 512-key prompt has only 2..8 tiles per workgroup, so the prologue is a large
+//   share of its time); 2 = query blocks are dispatched heaviest-first (causal: block qb has 2 qb + 2 tiles); 4 = s_setprio
+//   around the MFMA clusters (the two workgroups of a CU are at independent phases).
+constexpr int FLASH_OPT = 3;
+template <int D, int NW, int ST, int OPT = FLASH_OPT>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void flash_prefill_v2_kernel(const bf16* __restrict__ qkv, int64_t ld_qkv,
                                                               const bf16* __restrict__ kc, const bf16* __restrict__ vc,
                                                               int64_t n_max, const int32_t* __restrict__ pos0_dev,
@@ -688,7 +693,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void flash_prefill_v2_ker
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int qb = blockIdx.x, head = blockIdx.y;
+    const int qb = (OPT & 2) ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x, head = blockIdx.y;
     const int64_t b = blockIdx.z;
     const int pos0 = pos0_dev ? *pos0_dev : pos0_host;
     const int qbase = qb * FQ + wave * (QF * 16);
@@ -702,6 +707,13 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void flash_prefill_v2_ker
     const int wave_last_pos = pos0 + min(qbase + QF * 16, q_len) - 1;  // last query position this wave owns
     const float sl2 = scale * 1.44269504088896340736f;                 // softmax in base 2
 
+    if (OPT & 1) {   // tiles 0 .. ST-2 into the ring first; the Q loads below are younger (the first in-loop wait covers both)
+#pragma unroll
+        for (int x = 0; x < ST - 1; ++x)
+            if (x < n_tiles)
+                flash_stage_tile<D, NW>(kbase, vbase, x * FK_TILE, n_keys, smem + x * 2 * TILE_B, smem + x * 2 * TILE_B + TILE_B,
+                                        wave, lane);
+    }
     bf16x8_t qf[QF][KK];
     int qrow[QF];
 #pragma unroll
@@ -735,13 +747,18 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void flash_prefill_v2_ker
 #pragma unroll
         for (int d = 0; d < DF; ++d) vaddr[d] = rl * ROWB + (((d * 16 + (l15 & 3) * 4) * 2) ^ swz);
     }
-    // the Q fragments are loaded first (older than every DMA), then tiles 0 .. ST-2 go into the ring
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!(OPT & 1)) {
+        // the Q fragments are loaded first (older than every DMA), then tiles 0 .. ST-2 go into the ring
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int x = 0; x < ST - 1; ++x)
-        if (x < n_tiles)
-            flash_stage_tile<D, NW>(kbase, vbase, x * FK_TILE, n_keys, smem + x * 2 * TILE_B, smem + x * 2 * TILE_B + TILE_B, wave,
-                                    lane);
+        for (int x = 0; x < ST - 1; ++x)
+            if (x < n_tiles)
+                flash_stage_tile<D, NW>(kbase, vbase, x * FK_TILE, n_keys, smem + x * 2 * TILE_B, smem + x * 2 * TILE_B + TILE_B,
+                                        wave, lane);
+    } else if (ST > 2) {
+        // deeper rings leave younger tiles in flight at the first in-loop wait: the Q loads (youngest) must have landed by then
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
 
     for (int kt = 0; kt < n_tiles; ++kt) {
         const int key0 = kt * FK_TILE;
@@ -772,6 +789,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void flash_prefill_v2_ker
             for (int f = 0; f < QF; ++f)
 #pragma unroll
                 for (int kf = 0; kf < 4; ++kf) sacc[f][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (OPT & 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kf = 0; kf < 4; ++kf) {
 #pragma unroll
@@ -782,6 +800,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void flash_prefill_v2_ker
                         sacc[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[f][kk], sacc[f][kf], 0, 0, 0);
                 }
             }
+            if (OPT & 4) __builtin_amdgcn_s_setprio(0);
             // scores -> probabilities (online softmax, base 2: `sl2` = scale * log2(e) is folded into one multiply).
             // Interior tiles -- every key of the tile visible to every query row of this wave, no padding mask, no key past
             // n_keys -- skip the visibility compares and selects (most tiles of a causal prefill).
@@ -846,6 +865,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void flash_prefill_v2_ker
                 }
             }
             // O += P V.  key slot (g, e): e < 4 -> tile key (2ks)*16 + g*4 + e ; e >= 4 -> (2ks+1)*16 + g*4 + (e-4)
+            if (OPT & 4) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 bf16x8_t pf[QF];
@@ -878,6 +898,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void flash_prefill_v2_ker
                         oacc[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[f], vf.v, oacc[f][d], 0, 0, 0);
                 }
             }
+            if (OPT & 4) __builtin_amdgcn_s_setprio(0);
         }
     }
     // epilogue: normalise, stage the FQ x D output tile through LDS (K/V buffers are free now) and store whole rows with
@@ -995,6 +1016,10 @@ static constexpr int g_flash_variant = 0;
                                  // 0 = v2 <4 waves, double buffer> (LDS-DMA + transpose reads), 2 = v2 <8 waves, 4-deep ring>,
                                  // 1 = v1 (register/LDS-transposed V)
 
+#define BT_FLASH_OPT(OPT_)                                                                                              \
+    hipLaunchKernelGGL((flash_prefill_v2_kernel<D, 4, 2, OPT_>), grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv,       \
+                       (const bf16*)kc, (const bf16*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (bf16*)out, ldo, q_len, \
+                       heads, scale)
 template <int D>
 static int launch_flash(int64_t B, int q_len, int heads, const void* qkv, int64_t ld_qkv, const void* kc, const void* vc,
                         int64_t n_max, const int32_t* pos0_dev, int pos0_host, const uint8_t* mask, int64_t mask_ld,
@@ -1008,6 +1033,17 @@ static int launch_flash(int64_t B, int q_len, int heads, const void* qkv, int64_
                            (const bf16*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (bf16*)out, ldo, q_len, heads,
                            scale);
     else
+#endif
+#ifdef BT_DEBUG_HOOKS
+    if (g_flash_variant >= 3 && g_flash_variant <= 7) {   // A/B of the OPT bits: 3 -> 0 (round-1 kernel), 4 -> 1, 5 -> 3, 6 -> 7, 7 -> 5
+        switch (g_flash_variant) {
+            case 3: BT_FLASH_OPT(0); break;
+            case 4: BT_FLASH_OPT(1); break;
+            case 5: BT_FLASH_OPT(3); break;
+            case 6: BT_FLASH_OPT(7); break;
+            default: BT_FLASH_OPT(5); break;
+        }
+    } else
 #endif
     if (g_flash_variant != 2 || D < 64)   // production: 4 waves, double buffer, two workgroups per CU
         hipLaunchKernelGGL((flash_prefill_v2_kernel<D, 4, 2>), grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv,

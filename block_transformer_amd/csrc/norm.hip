@@ -77,6 +77,74 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
     }
 }
 
+// Register-resident variant for H <= NV * 64 * VEC (vector-aligned rows): a lane loads its NV 16-byte pieces of the row ONCE,
+// all in flight together; the statistics and both outputs come from registers.  The streaming kernel above pays three
+// dependent load latencies per row (HBM, then two L1/L2 re-reads) with one 1 KiB wave-load in flight at a time; here the
+// row costs one latency.  Same per-lane summation order and the same two-pass statistics -> bit-identical results.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm_reg_kernel(const T* __restrict__ x, int64_t ldx, const T* __restrict__ w1,
+                                                           const T* __restrict__ b1, T* __restrict__ o1, int64_t ldo1,
+                                                           const T* __restrict__ w2, const T* __restrict__ b2,
+                                                           T* __restrict__ o2, int64_t ldo2, int64_t M, int H, float eps) {
+    constexpr int V = Elem<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const T* xr = x + row * ldx;
+    float v[NV][V];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * V;
+        if (c < H) load_vec<T>(xr + c, v[i]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if ((i * 64 + lane) * V < H) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) sum += v[i][j];
+        }
+    const float mean = wave_sum(sum) / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if ((i * 64 + lane) * V < H) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float d = v[i][j] - mean;
+                sq = fmaf(d, d, sq);
+            }
+        }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+    T* o1r = o1 + row * ldo1;
+    T* o2r = o2 ? o2 + row * ldo2 : nullptr;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * V;
+        if (c < H) {
+            float g[V], b[V], r[V];
+            load_vec<T>(w1 + c, g);
+            load_vec<T>(b1 + c, b);
+#pragma unroll
+            for (int j = 0; j < V; ++j) r[j] = fmaf((v[i][j] - mean) * rstd, g[j], b[j]);
+            store_vec<T>(o1r + c, r);
+            if (o2r) {
+                load_vec<T>(w2 + c, g);
+                load_vec<T>(b2 + c, b);
+#pragma unroll
+                for (int j = 0; j < V; ++j) r[j] = fmaf((v[i][j] - mean) * rstd, g[j], b[j]);
+                store_vec<T>(o2r + c, r);
+            }
+        }
+    }
+}
+
+#ifdef BT_DEBUG_HOOKS
+static bool g_ln_streaming = false;   // A/B (debug library only): force the three-pass streaming kernel
+#else
+static constexpr bool g_ln_streaming = false;
+#endif
+
 template <typename T>
 static int launch_ln(int64_t M, int64_t H, const void* x, int64_t ldx, const void* w1, const void* b1, void* o1,
                      int64_t ldo1, const void* w2, const void* b2, void* o2, int64_t ldo2, float eps, hipStream_t s) {
@@ -86,12 +154,22 @@ static int launch_ln(int64_t M, int64_t H, const void* x, int64_t ldx, const voi
     if (o2) vec = vec && (ldo2 % V == 0) && aligned16(w2) && aligned16(b2) && aligned16(o2);
     const unsigned grid = (unsigned)ceil_div(M, 4);
     ProfScope ps(BT_PROF_LAYERNORM, s);
-    if (vec)
+    const int nv = (int)ceil_div(H, (int64_t)64 * V);
+#define BT_LN_REG(NV_)                                                                                                  \
+    hipLaunchKernelGGL((layernorm_reg_kernel<T, NV_>), dim3(grid), dim3(256), 0, s, (const T*)x, ldx, (const T*)w1,     \
+                       (const T*)b1, (T*)o1, ldo1, (const T*)w2, (const T*)b2, (T*)o2, ldo2, M, (int)H, eps)
+    if (vec && nv <= 8 && !g_ln_streaming) {
+        if (nv <= 1) BT_LN_REG(1);
+        else if (nv <= 2) BT_LN_REG(2);
+        else if (nv <= 4) BT_LN_REG(4);
+        else BT_LN_REG(8);
+    } else if (vec)
         hipLaunchKernelGGL((layernorm_kernel<T, true>), dim3(grid), dim3(256), 0, s, (const T*)x, ldx, (const T*)w1,
                            (const T*)b1, (T*)o1, ldo1, (const T*)w2, (const T*)b2, (T*)o2, ldo2, M, (int)H, eps);
     else
         hipLaunchKernelGGL((layernorm_kernel<T, false>), dim3(grid), dim3(256), 0, s, (const T*)x, ldx, (const T*)w1,
                            (const T*)b1, (T*)o1, ldo1, (const T*)w2, (const T*)b2, (T*)o2, ldo2, M, (int)H, eps);
+#undef BT_LN_REG
     BT_LAUNCH_CHECK("bt_layernorm launch");
     return BT_OK;
 }
@@ -113,3 +191,7 @@ extern "C" int bt_layernorm(int dtype, int64_t M, int64_t H, const void* x, int6
         return launch_ln<bf16>(M, H, x, ldx, w1, b1, out1, ldo1, w2, b2, out2, ldo2, eps, (hipStream_t)stream);
     return launch_ln<float>(M, H, x, ldx, w1, b1, out1, ldo1, w2, b2, out2, ldo2, eps, (hipStream_t)stream);
 }
+
+#ifdef BT_DEBUG_HOOKS
+extern "C" void bt_debug_ln_streaming(int on) { bt::g_ln_streaming = on != 0; }
+#endif

@@ -444,7 +444,7 @@ def test_linear_strided_inplace_residual():
 
 # ---- bt_layernorm -----------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-@pytest.mark.parametrize("M,H", [(1, 64), (7, 256), (33, 2048), (5, 100)])
+@pytest.mark.parametrize("M,H", [(1, 64), (7, 256), (33, 2048), (5, 100), (9, 264), (6, 1536), (5, 4096), (3, 5120), (4099, 2048)])
 def test_layernorm_dual(dtype, M, H):
     x = (rnd(M, H, seed=1) * 3 + 0.5).to(dtype)
     w1, b1, w2, b2 = [(rnd(H, seed=s) * 0.5 + (1 if s % 2 == 0 else 0)).to(dtype) for s in (2, 3, 4, 5)]
@@ -455,6 +455,22 @@ def test_layernorm_dual(dtype, M, H):
     assert rel_err(o1.cpu(), r1) <= tol and rel_err(o2.cpu(), r2) <= tol
     o = ops.layernorm(x.to(DEV), w1.to(DEV), b1.to(DEV), 1e-5)
     assert rel_err(o.cpu(), r1) <= tol
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,H", [(7, 256), (33, 2048), (9, 264), (5, 4096), (1000, 1024)])
+def test_layernorm_register_kernel_bit_identical_to_streaming(dtype, M, H, dbg_lib):
+    """Rows that fit the register-resident kernel (H <= 8 x 64 x 16-byte pieces) produce the same bits as the three-pass
+    streaming kernel (same per-lane summation order, same two-pass statistics)."""
+    x = (rnd(M, H, seed=1) * 3 + 0.5).to(dtype).to(DEV)
+    w1, b1, w2, b2 = [(rnd(H, seed=s) * 0.5 + (1 if s % 2 == 0 else 0)).to(dtype).to(DEV) for s in (2, 3, 4, 5)]
+    o1, o2 = ops.layernorm(x, w1, b1, 1e-5, w2, b2)
+    lib().bt_debug_ln_streaming(1)
+    try:
+        s1, s2 = ops.layernorm(x, w1, b1, 1e-5, w2, b2)
+    finally:
+        lib().bt_debug_ln_streaming(0)
+    assert torch.equal(o1, s1) and torch.equal(o2, s2)
 
 
 def test_layernorm_strided_rows():
@@ -671,7 +687,7 @@ def test_attention_rows_mask(dtype):
         assert out.view(B, -1)[1].abs().max() == 0
 
 
-@pytest.fixture(params=[0, 2, 1], ids=["flash_v2_4w2s", "flash_v2_8w4s", "flash_v1"])
+@pytest.fixture(params=[0, 2, 1, 3, 6], ids=["flash_v2_4w2s", "flash_v2_8w4s", "flash_v1", "flash_v2_opt0", "flash_v2_opt7"])
 def flash_variant(request, dbg_lib):
     """0 = LDS-DMA + ds_read_b64_tr_b16 kernel, 4 waves / 128 query rows / double buffer (default), 2 = the same kernel
     with 8 waves / 256 query rows / 4-deep K/V ring (d >= 64), 1 = first-generation kernel (kept for A/B)."""

@@ -151,7 +151,7 @@ def probe_copy(nbytes, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=["gemm", "attn", "flash", "suite", "copy", "ab", "abl", "skinny", "decode", "vendor", "pitch",
-                                     "local", "lin2"])
+                                     "local", "lin2", "ln"])
     ap.add_argument("--m", type=int, default=32768)
     ap.add_argument("--n", type=int, default=6144)
     ap.add_argument("--k", type=int, default=2048)
@@ -181,12 +181,30 @@ def main():
             res.append(r)
         lib().bt_debug_attn_nt(0)
     elif args.what == "flash":
-        for v in (0, 2, 1, 0, 2, 1):
+        names = {0: "production", 2: "v2 <8 waves, 4-deep ring>", 1: "v1", 3: "OPT 0 (round-1 kernel)", 4: "OPT 1 (K/V DMA before Q)",
+                 5: "OPT 3 (+ heaviest block first)", 6: "OPT 7 (+ setprio)", 7: "OPT 5 (DMA first + setprio)"}
+        outs = {}
+        for v in (3, 4, 5, 6, 7, 0, 3, 4, 5, 6, 7, 0):
             lib().bt_debug_flash_variant(v)
             r = probe_flash(args.batch, args.keys, args.iters)
-            r["variant"] = {0: "v2 <4 waves, double buffer>", 2: "v2 <8 waves, 4-deep ring>", 1: "v1"}[v]
+            r["variant"] = names[v]
             res.append(r)
         lib().bt_debug_flash_variant(0)
+    elif args.what == "ln":      # dual LayerNorm at H = 2048: register-resident kernel vs the three-pass streaming kernel
+        for M in (4096, 32768, 131072):
+            x = torch.randn(M, 2048, device=DEV).bfloat16()
+            w = [torch.randn(2048, device=DEV).bfloat16() for _ in range(4)]
+            o1, o2 = torch.empty_like(x), torch.empty_like(x)
+            st = current_stream()
+            rec = {"op": "layernorm_dual", "M": M, "H": 2048}
+            for tag, flag in (("streaming", 1), ("register", 0), ("streaming_b", 1), ("register_b", 0)):
+                lib().bt_debug_ln_streaming(flag)
+                ms = timed(lambda: check(lib().bt_layernorm(_lib.BT_BF16, M, 2048, ptr(x), 2048, ptr(w[0]), ptr(w[1]), ptr(o1), 2048,
+                                                            ptr(w[2]), ptr(w[3]), ptr(o2), 2048, 1e-5, st)), args.iters)
+                rec[tag + "_us"] = round(ms * 1e3, 2)
+                rec[tag + "_GBps"] = round(3 * M * 2048 * 2 / (ms * 1e-3) / 1e9, 1)
+            lib().bt_debug_ln_streaming(0)
+            res.append(rec)
     elif args.what == "copy":
         res.append(probe_copy(1 << 30, args.iters))
     elif args.what == "ab":
