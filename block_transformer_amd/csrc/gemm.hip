@@ -18,6 +18,7 @@
 //
 // Roofline: MFMA-bound for M >~ 300 rows (2*M*N*K flop vs 2*(M*K + N*K + M*N) bytes); HBM-bound on W below that.
 #include "bt_common.h"
+#include <type_traits>
 
 #include <algorithm>
 
@@ -1910,33 +1911,59 @@ __device__ __forceinline__ void gemv_body(const int bid, const bf16* __restrict_
         for (int m = 0; m < MR; ++m) acc[r][m] = 0.f;
 
     const int k_all = K + ((LN || QKV) ? 0 : s2.K);   // K chunks of the first operand pair, then of the second
-    for (int kg = 0; kg < k_all; kg += GV_KC) {
+    // Load pipeline.  A wave keeps one chunk of its W rows in registers (RW x 4 x 16 bytes per lane).  With several chunks
+    // (the residual-stream projections: K = 8192 + 2048 -> five) a single buffer pays a full HBM latency per chunk with
+    // only 8 waves per CU in flight (measured 3.6 TB/s); PIPE double-buffers: the NEXT chunk's rows are issued before this
+    // chunk is consumed.  Within a chunk the x pieces are loaded FIRST and the W rows right behind them: vmcnt retires in
+    // order, so waiting for the (older, L2-resident) x pieces leaves the W stream in flight, and the LDS staging and the
+    // LayerNorm prologue run in its shadow.  Summation order is unchanged -> bit-identical results.
+    constexpr bool PIPE = !LN && !QKV && RW < 4;
+    constexpr int NBUF = PIPE ? 2 : 1;
+    uint4 wv[NBUF][RW][GV_KC / 512];
+    // `live` = false (no next chunk): the same number of loads is issued from a harmless L2-resident address (the first x
+    // row) -- a branch around the prefetch would make the compiler merge both paths' vmcnt states and wait for the prefetch
+    auto load_w = [&](auto BUF, int kg_req, bool live) {
+        constexpr int buf = decltype(BUF)::value;
+        const int kg = live ? kg_req : 0;
         const bool second = kg >= K;                   // (K is a multiple of GV_KC whenever a second segment follows)
         const int kc = second ? kg - K : kg;
-        const bf16* Xs = second ? s2.x : X;
         const bf16* Ws = second ? s2.w : W;
-        const int64_t ldxs = second ? s2.ldx : ldx, ldws = second ? s2.ldw : ldw;
+        const int64_t ldws = second ? s2.ldw : ldw;
         const int kw = min(GV_KC, (second ? s2.K : K) - kc);   // multiple of 512
-        __syncthreads();                               // previous chunk fully consumed
-        for (int idx = tid; idx < MR * (kw / 8); idx += 256) {
-            const int m = idx / (kw / 8), c = idx - m * (kw / 8);
-            uint4 v = uint4{0, 0, 0, 0};
-            if (m < M) v = *reinterpret_cast<const uint4*>(Xs + (int64_t)m * ldxs + kc + c * 8);
-            *reinterpret_cast<uint4*>(xs + (m * GV_KC + c * 8) * 2) = v;
-        }
-        // this wave's W rows of the chunk: all loads in flight before the first use
-        uint4 wv[RW][GV_KC / 512];
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             const int n = rows[r] < N ? rows[r] : N - 1;
-            const bf16* wp = Ws + (int64_t)n * ldws + kc + lane * 8;
+            const bf16* wp = (live ? Ws + (int64_t)n * ldws : X) + kc + lane * 8;
+            // every load is issued unconditionally (pieces past a short last chunk re-read its last valid piece and are
+            // never multiplied): no branch around a load, so the compiler's vmcnt bookkeeping stays exact
 #pragma unroll
             for (int j = 0; j < GV_KC / 512; ++j)
-                wv[r][j] = (j * 512 < kw) ? load_w16<(RW < 4)>(wp + j * 512) : uint4{0, 0, 0, 0};   // RW == 4: the logits matrix, re-read every token -> cacheable
+                wv[buf][r][j] = load_w16<(RW < 4)>(wp + min(j * 512, kw - 512));   // RW == 4: the logits matrix, re-read every token -> cacheable
+        }
+    };
+    auto chunk = [&](auto BUF, int kg) {
+        constexpr int buf = decltype(BUF)::value;
+        const bool second = kg >= K;
+        const int kc = second ? kg - K : kg;
+        const bf16* Xs = second ? s2.x : X;
+        const int64_t ldxs = second ? s2.ldx : ldx;
+        const int kw = min(GV_KC, (second ? s2.K : K) - kc);
+        // thread t owns the 16-byte piece t of every x row of the chunk (kw / 8 <= 256 pieces per row)
+        const bool own = tid < kw / 8;
+        uint4 xv[MR];
+#pragma unroll
+        for (int m = 0; m < MR; ++m)   // unconditional (clamped) loads, see load_w; rows >= M are zeroed when staged
+            xv[m] = *reinterpret_cast<const uint4*>(Xs + (int64_t)min(m, M - 1) * ldxs + kc + (own ? tid : 0) * 8);
+        if (!PIPE || kg == 0) load_w(BUF, kg, true);                                    // this chunk's rows (first chunk / no pipeline)
+        if (PIPE) load_w(std::integral_constant<int, (buf + 1) % NBUF>{}, kg + GV_KC, kg + GV_KC < k_all);   // next chunk's rows
+        __syncthreads();                               // previous chunk fully consumed
+        if (own) {
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+                *reinterpret_cast<uint4*>(xs + (m * GV_KC + tid * 8) * 2) = m < M ? xv[m] : uint4{0, 0, 0, 0};
         }
         __syncthreads();
         if (LN) {   // K <= GV_KC: the chunk is the whole row.  Thread t owns the 16-byte piece t of every row.
-            const bool own = tid < kw / 8;
             float v[MR][8];
             float part[MR];
 #pragma unroll
@@ -1990,12 +2017,16 @@ __device__ __forceinline__ void gemv_body(const int bid, const bf16* __restrict_
             if (j * 512 < kw) {
 #pragma unroll
                 for (int m = 0; m < MR; ++m) {
-                    const uint4 xv = *reinterpret_cast<const uint4*>(xs + (m * GV_KC + j * 512 + lane * 8) * 2);
+                    const uint4 xq = *reinterpret_cast<const uint4*>(xs + (m * GV_KC + j * 512 + lane * 8) * 2);
 #pragma unroll
-                    for (int r = 0; r < RW; ++r) acc[r][m] = dot8_bf16(wv[r][j], xv, acc[r][m]);
+                    for (int r = 0; r < RW; ++r) acc[r][m] = dot8_bf16(wv[buf][r][j], xq, acc[r][m]);
                 }
             }
         }
+    };
+    for (int kg = 0; kg < k_all; kg += NBUF * GV_KC) {
+        chunk(std::integral_constant<int, 0>{}, kg);
+        if (PIPE && kg + GV_KC < k_all) chunk(std::integral_constant<int, NBUF - 1>{}, kg + GV_KC);
     }
     // finish the dot products; afterwards every lane holds every sum
 #pragma unroll

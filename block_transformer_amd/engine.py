@@ -14,9 +14,11 @@ the kernels.  Finished sequences are masked, not compacted (the reference compac
 C13/C14): fixed batch => static shapes => graph replay.  Local-KV "reset" costs nothing: every token block starts
 writing the local cache at row 0 again.
 
-Large batches are run as TWO half-batch shards on two HIP streams, one token block apart (``PipelinedEngine``): while
-shard A streams its global KV cache (block-decoder step, HBM-bound, matrix cores idle) shard B runs its token-decoder
-GEMMs (MFMA-bound, HBM idle) — the "two roofs" of SURVEY.md section 7 overlapped instead of added.
+``PipelinedEngine`` (opt-in: ``model.pipeline = True`` / ``BT_PIPELINE=1``) runs TWO half-batch shards on two HIP streams,
+one token block apart, so that shard A's global-KV stream (block-decoder step, HBM-bound, matrix cores idle) can overlap
+shard B's token-decoder GEMMs (MFMA-bound).  Measured on MI355X it does not pay with the production kernels (DESIGN.md
+section 3: the attention grid and the persistent GEMM each fill the CUs, <= 30 % of the shorter phase hides even with
+bounded-footprint kernels), so ``BlockTransformer`` uses the single-stream engine by default.
 """
 from __future__ import annotations
 
