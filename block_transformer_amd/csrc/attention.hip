@@ -676,25 +676,57 @@ __device__ inline void flash_stage_tile(const bf16* __restrict__ kbase, const bf
 //   latencies overlap instead of adding up: a 512-key prompt has only 2..8 tiles per workgroup, so the prologue is a large
 //   share of its time); 2 = query blocks are dispatched heaviest-first (causal: block qb has 2 qb + 2 tiles); 4 = s_setprio
 //   around the MFMA clusters (the two workgroups of a CU are at independent phases).
-constexpr int FLASH_OPT = 3;
-template <int D, int NW, int ST, int OPT = FLASH_OPT>
-__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void flash_prefill_v2_kernel(const bf16* __restrict__ qkv, int64_t ld_qkv,
+constexpr int FLASH_OPT = 95;
+//   QF_ = 16-row query fragments per wave: <D, 8, 2, OPT, 1> = the same 128-row block on 8 waves of 16 rows -- half the
+//   accumulator registers per wave, so four waves per SIMD instead of two hide the tile loop's LDS / MFMA latencies.
+template <int D, int NW, int ST, int OPT = FLASH_OPT, int QF_ = 2>
+__global__ __launch_bounds__(NW * 64, NW * QF_ == 8 ? (QF_ == 1 ? 4 : 2) : 1) void flash_prefill_v2_kernel(const bf16* __restrict__ qkv, int64_t ld_qkv,
                                                               const bf16* __restrict__ kc, const bf16* __restrict__ vc,
                                                               int64_t n_max, const int32_t* __restrict__ pos0_dev,
                                                               int pos0_host, const uint8_t* __restrict__ mask,
                                                               int64_t mask_ld, bf16* __restrict__ out, int64_t ldo,
                                                               int q_len, int heads, float scale) {
-    constexpr int KK = D / 32, DF = D / 16, QF = 2;
+    constexpr int KK = D / 32, DF = D / 16, QF = QF_;
+    // OPT bit 8: accumulate O TRANSPOSED (O^T = V^T P^T: the same two operand registers, swapped).  D[i = dim][j = query]
+    // puts query row l15 in the lane that also holds that row's softmax statistics, so the per-tile rescale needs no
+    // cross-lane broadcast (8 of the loop's 12 ds_bpermute round trips) and the epilogue packs four consecutive dims
+    constexpr bool OT = (OPT & 8) != 0;
+    constexpr bool FS = (OPT & 16) != 0;   // bit 16: softmax scale folded into the exponent FMA (no separate multiply per score)
+    constexpr bool LZ = (OPT & 32) != 0;   // bit 32: skip the O rescale on tiles where no running max of the wave moved
     constexpr int ROWB = D * 2, SLOTS = ROWB / 16;
     constexpr int TILE_B = FK_TILE * ROWB;  // bytes of one K (or V) tile
-    constexpr int FQ = NW * 32;                                          // query rows per workgroup
+    constexpr int FQ = NW * QF * 16;                                     // query rows per workgroup
     constexpr int NI = 64 / (1024 / ROWB) / NW;                          // DMA instructions per wave, operand and tile
     __shared__ __attribute__((aligned(16))) char smem[ST * 2 * TILE_B];  // [stage][K | V]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g = lane >> 4;
-    const int qb = (OPT & 2) ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x, head = blockIdx.y;
-    const int64_t b = blockIdx.z;
+    int qb, head;
+    int64_t b;
+    if (OPT & 64) {
+        // 1-D grid, XCD-aware: workgroup w runs on XCD w % 8 (round-robin dispatch) and each XCD has its own L2, so the
+        // query blocks of one (sequence, head) -- which all stream the SAME K/V rows -- get ids 8 apart: same XCD, dispatched
+        // together, the K/V tiles come from HBM once instead of once per query block (a 512-key prompt: 640 -> 256 KB)
+        const int nq = (q_len + FQ - 1) / FQ;
+        const int w = blockIdx.x, ng = gridDim.x / nq, full = ng / 8;
+        int grp, qi;
+        if (w < full * 8 * nq) {
+            const int c = w / (8 * nq), r = w - c * (8 * nq);
+            grp = c * 8 + (r & 7);
+            qi = r >> 3;
+        } else {   // the last ng % 8 groups
+            const int rem = ng - full * 8, r = w - full * 8 * nq;
+            grp = full * 8 + r % rem;
+            qi = r / rem;
+        }
+        qb = (OPT & 2) ? nq - 1 - qi : qi;
+        head = grp % heads;
+        b = grp / heads;
+    } else {
+        qb = (OPT & 2) ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
+        head = blockIdx.y;
+        b = blockIdx.z;
+    }
     const int pos0 = pos0_dev ? *pos0_dev : pos0_host;
     const int qbase = qb * FQ + wave * (QF * 16);
 
@@ -822,10 +854,10 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void flash_prefill_v2_ker
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int key = key0 + kf * 16 + g * 4 + r;
-                            sacc[f][kf][r] = (key <= qpos && kvis[kf][r]) ? sacc[f][kf][r] * sl2 : -INFINITY;
+                            sacc[f][kf][r] = (key <= qpos && kvis[kf][r]) ? (FS ? sacc[f][kf][r] : sacc[f][kf][r] * sl2) : -INFINITY;
                         }
                 }
-            } else {
+            } else if (!FS) {
 #pragma unroll
                 for (int f = 0; f < QF; ++f)
 #pragma unroll
@@ -844,24 +876,37 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void flash_prefill_v2_ker
                 tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
                 const float mnew = fmaxf(mrun[f], tmax);
                 const bool dead = (mnew == -INFINITY);          // no visible key so far for this query row
-                const float msub = dead ? 0.f : mnew;
-                const float alpha = dead ? 1.0f : __builtin_amdgcn_exp2f(mrun[f] - mnew);
+                // FS: the running max stays in RAW score units and the softmax scale rides in the exponent's FMA
+                // (exp2(s * sl2 - m * sl2)): one multiply per score less, and one rounding less
+                const float msub = dead ? 0.f : (FS ? -mnew * sl2 : mnew);
+                const float alpha = dead ? 1.0f : __builtin_amdgcn_exp2f(FS ? (mrun[f] - mnew) * sl2 : mrun[f] - mnew);
                 float psum = 0.f;
 #pragma unroll
                 for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float pv = __builtin_amdgcn_exp2f(sacc[f][kf][r] - msub);   // exp2(-inf) = 0 for masked keys
+                        // exp2(-inf) = 0 for masked keys
+                        const float pv = __builtin_amdgcn_exp2f(FS ? fmaf(sacc[f][kf][r], sl2, msub) : sacc[f][kf][r] - msub);
                         sacc[f][kf][r] = pv;
                         psum += pv;
                     }
                 lrun[f] = lrun[f] * alpha + psum;
                 mrun[f] = mnew;
+                if (OT) {   // O^T accumulators: the lane's column IS query row l15 -> its own alpha, no broadcast
+                    // (and when no row of the wave raised its running max -- alpha == 1 everywhere -- nothing to do)
+                    if (!LZ || __builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float a = __shfl(alpha, g * 4 + r, 64);
+                        for (int d = 0; d < DF; ++d)
 #pragma unroll
-                    for (int d = 0; d < DF; ++d) oacc[f][d][r] *= a;
+                            for (int r = 0; r < 4; ++r) oacc[f][d][r] *= alpha;
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float a = __shfl(alpha, g * 4 + r, 64);
+#pragma unroll
+                        for (int d = 0; d < DF; ++d) oacc[f][d][r] *= a;
+                    }
                 }
             }
             // O += P V.  key slot (g, e): e < 4 -> tile key (2ks)*16 + g*4 + e ; e >= 4 -> (2ks+1)*16 + g*4 + (e-4)
@@ -895,7 +940,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void flash_prefill_v2_ker
                     vf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vb + a2));
 #pragma unroll
                     for (int f = 0; f < QF; ++f)
-                        oacc[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[f], vf.v, oacc[f][d], 0, 0, 0);
+                        oacc[f][d] = OT ? __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[f], oacc[f][d], 0, 0, 0)
+                                        : __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf[f], vf.v, oacc[f][d], 0, 0, 0);
                 }
             }
             if (OPT & 4) __builtin_amdgcn_s_setprio(0);
@@ -912,13 +958,24 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void flash_prefill_v2_ker
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
         const float inv = l > 0.f ? 1.0f / l : 0.f;
+        if (OT) {   // lane = query row l15, four consecutive dims per fragment: 8-byte LDS stores
+            char* orow = smem + (wave * (QF * 16) + f * 16 + l15) * OP + g * 8;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float a = __shfl(inv, g * 4 + r, 64);
-            const int rl = wave * (QF * 16) + f * 16 + g * 4 + r;  // row inside the block's tile
-            uint16_t* orow = reinterpret_cast<uint16_t*>(smem + rl * OP) + l15;
+            for (int d = 0; d < DF; ++d) {
+                uint2 o2;
+                o2.x = pack_bf16x2(oacc[f][d][0] * inv, oacc[f][d][1] * inv);
+                o2.y = pack_bf16x2(oacc[f][d][2] * inv, oacc[f][d][3] * inv);
+                *reinterpret_cast<uint2*>(orow + d * 32) = o2;
+            }
+        } else {
 #pragma unroll
-            for (int d = 0; d < DF; ++d) orow[d * 16] = f32_to_bf16(oacc[f][d][r] * a);
+            for (int r = 0; r < 4; ++r) {
+                const float a = __shfl(inv, g * 4 + r, 64);
+                const int rl = wave * (QF * 16) + f * 16 + g * 4 + r;  // row inside the block's tile
+                uint16_t* orow = reinterpret_cast<uint16_t*>(smem + rl * OP) + l15;
+#pragma unroll
+                for (int d = 0; d < DF; ++d) orow[d * 16] = f32_to_bf16(oacc[f][d][r] * a);
+            }
         }
     }
     __syncthreads();
@@ -1017,7 +1074,7 @@ static constexpr int g_flash_variant = 0;
                                  // 1 = v1 (register/LDS-transposed V)
 
 #define BT_FLASH_OPT(OPT_)                                                                                              \
-    hipLaunchKernelGGL((flash_prefill_v2_kernel<D, 4, 2, OPT_>), grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv,       \
+    hipLaunchKernelGGL((flash_prefill_v2_kernel<D, 4, 2, OPT_>), ((OPT_) & 64) ? grid1 : grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, \
                        (const bf16*)kc, (const bf16*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (bf16*)out, ldo, q_len, \
                        heads, scale)
 template <int D>
@@ -1027,6 +1084,9 @@ static int launch_flash(int64_t B, int q_len, int heads, const void* qkv, int64_
     const float scale = 1.0f / sqrtf((float)D);
     ProfScope ps(BT_PROF_ATTN_FLASH, s);
     const dim3 grid((unsigned)ceil_div(q_len, FQ_ROWS), (unsigned)heads, (unsigned)B);
+    const int64_t n_wg = ceil_div(q_len, FQ_ROWS) * heads * B;
+    BT_CHECK_ARG(n_wg < (1ll << 31), "bt_attention: prefill grid too large");
+    const dim3 grid1((unsigned)n_wg);   // 1-D, XCD-aware mapping (OPT bit 64)
 #ifdef BT_DEBUG_HOOKS
     if (g_flash_variant == 1)
         hipLaunchKernelGGL(flash_prefill_kernel<D>, grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)kc,
@@ -1035,23 +1095,36 @@ static int launch_flash(int64_t B, int q_len, int heads, const void* qkv, int64_
     else
 #endif
 #ifdef BT_DEBUG_HOOKS
-    if (g_flash_variant >= 3 && g_flash_variant <= 7) {   // A/B of the OPT bits: 3 -> 0 (round-1 kernel), 4 -> 1, 5 -> 3, 6 -> 7, 7 -> 5
+    if ((g_flash_variant >= 3 && g_flash_variant <= 7) || (g_flash_variant >= 9 && g_flash_variant <= 12)) {   // A/B of the OPT bits: 3 -> 0 (round-1 kernel), 4 -> 1, 5 -> 3, 6 -> 7, 7 -> 15
         switch (g_flash_variant) {
             case 3: BT_FLASH_OPT(0); break;
+            case 9: BT_FLASH_OPT(31); break;    // + scale folded into the exponent FMA
+            case 12: BT_FLASH_OPT(95); break;   // 31 + XCD-aware 1-D grid
+            case 10: BT_FLASH_OPT(63); break;   // + lazy rescale
+            case 11: BT_FLASH_OPT(59); break;   // 63 without setprio
             case 4: BT_FLASH_OPT(1); break;
             case 5: BT_FLASH_OPT(3); break;
             case 6: BT_FLASH_OPT(7); break;
-            default: BT_FLASH_OPT(5); break;
+            default: BT_FLASH_OPT(15); break;   // 7: transposed O accumulators (bit 8) + setprio
         }
     } else
 #endif
-    if (g_flash_variant != 2 || D < 64)   // production: 4 waves, double buffer, two workgroups per CU
-        hipLaunchKernelGGL((flash_prefill_v2_kernel<D, 4, 2>), grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv,
+    if ((g_flash_variant != 2 && g_flash_variant != 8) || D < 64)   // production: 4 waves, double buffer, two workgroups per CU
+        hipLaunchKernelGGL((flash_prefill_v2_kernel<D, 4, 2>), (FLASH_OPT & 64) ? grid1 : grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv,
                            (const bf16*)kc, (const bf16*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (bf16*)out, ldo, q_len,
                            heads, scale);
 #ifdef BT_DEBUG_HOOKS
-    else if constexpr (D >= 64) {   // variant 2 (A/B): 8 waves, 4-deep ring -- same speed: the loop is issue-bound, not load-bound
-        const dim3 grid8((unsigned)ceil_div(q_len, 256), (unsigned)heads, (unsigned)B);
+    else if constexpr (D >= 64) {
+        if (g_flash_variant == 8) {   // 8 waves x 16 query rows, double buffer, two workgroups per CU (four waves per SIMD)
+            hipLaunchKernelGGL((flash_prefill_v2_kernel<D, 8, 2, FLASH_OPT, 1>), (FLASH_OPT & 64) ? grid1 : grid, dim3(512), 0, s, (const bf16*)qkv, ld_qkv,
+                               (const bf16*)kc, (const bf16*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (bf16*)out, ldo,
+                               q_len, heads, scale);
+            BT_LAUNCH_CHECK("bt_attention(flash) launch");
+            return BT_OK;
+        }
+        // variant 2 (A/B): 8 waves, 4-deep ring -- same speed: the loop is issue-bound, not load-bound
+        const dim3 grid8 = (FLASH_OPT & 64) ? dim3((unsigned)(ceil_div(q_len, 256) * heads * B))
+                                            : dim3((unsigned)ceil_div(q_len, 256), (unsigned)heads, (unsigned)B);
         hipLaunchKernelGGL((flash_prefill_v2_kernel<D, 8, 4>), grid8, dim3(512), 0, s, (const bf16*)qkv, ld_qkv,
                            (const bf16*)kc, (const bf16*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (bf16*)out, ldo, q_len,
                            heads, scale);

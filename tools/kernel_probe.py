@@ -184,7 +184,14 @@ def main():
         names = {0: "production", 2: "v2 <8 waves, 4-deep ring>", 1: "v1", 3: "OPT 0 (round-1 kernel)", 4: "OPT 1 (K/V DMA before Q)",
                  5: "OPT 3 (+ heaviest block first)", 6: "OPT 7 (+ setprio)", 7: "OPT 5 (DMA first + setprio)"}
         outs = {}
-        for v in (3, 4, 5, 6, 7, 0, 3, 4, 5, 6, 7, 0):
+        names[8] = "8 waves x 16 query rows, 4 waves per SIMD"
+        names[5] = "OPT 3 (DMA first + heaviest first; O accumulated row-major)"
+        names[7] = "OPT 15 (transposed O + setprio)"
+        names[0] = "production (OPT 11: transposed O accumulators)"
+        names.update({9: "OPT 31 (+ scale in the exponent FMA)", 10: "OPT 63 (+ lazy rescale)", 11: "OPT 59 (63 without setprio)"})
+        names[12] = "OPT 95 (31 + XCD-aware grid: a sequence-head's query blocks share one L2)"
+        names[0] = "production (OPT 95)"
+        for v in ((0, 2, 8, 9, 0, 2, 8, 9) if args.split == 1 else (3, 4, 5, 6, 7, 0, 3, 4, 5, 6, 7, 0)):
             lib().bt_debug_flash_variant(v)
             r = probe_flash(args.batch, args.keys, args.iters)
             r["variant"] = names[v]
