@@ -989,6 +989,339 @@ __global__ __launch_bounds__(NW * 64, NW * QF_ == 8 ? (QF_ == 1 ? 4 : 2) : 1) vo
     }
 }
 
+// K/V tile staging for the persistent kernel: wave-uniform 64-bit base in SGPRs + one 32-bit byte offset per lane (the v2
+// helper's per-lane 64-bit addresses cost the persistent kernel its last registers: 29 spills, reloaded inside the tile loop).
+// Every LDS-DMA of that kernel goes through this helper, so the compiler never has its own idea of M0 there.
+template <int D, int NW = 4>
+__device__ inline void flash_stage_tile_s(const bf16* __restrict__ kbase, const bf16* __restrict__ vbase, int key0, int n_keys,
+                                          char* kbuf, char* vbuf, int wave, int lane) {
+    constexpr int ROWB = D * 2;
+    constexpr int SLOTS = ROWB / 16;
+    constexpr int RPI = 1024 / ROWB;
+    constexpr int NI = 64 / RPI / NW;
+    static_assert(NI >= 1, "more waves than 1 KiB pieces in a K tile");
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int rbase = (wave * NI + i) * RPI;
+        const int row = rbase + lane / SLOTS;
+        const int p = lane % SLOTS;
+        int kr = key0 + row;
+        kr = kr < n_keys ? kr : n_keys - 1;          // never-written rows: re-read the last visible one (weight exactly 0)
+        const uint32_t ko = (uint32_t)(kr * ROWB + ((p ^ (row & (SLOTS - 1))) << 4));
+        const uint32_t vo = (uint32_t)(kr * ROWB + ((p ^ (((row & 7) << 1) & (SLOTS - 1))) << 4));
+        const uint32_t kl = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(kbuf + rbase * ROWB);
+        const uint32_t vl = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)(vbuf + rbase * ROWB);
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(ko), "s"(kbase), "s"(kl) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(vo), "s"(vbase), "s"(vl) : "memory");
+    }
+}
+
+// ---- bf16 MFMA flash prefill, v3: persistent workgroups ------------------------------------------------------------------
+// Same tile math as flash_prefill_v2_kernel<D, 4, 2> with its measured options fixed (transposed O accumulators, scale in the
+// exponent FMA, s_setprio), but a workgroup does not end with its 128-row query block: it walks a list of (sequence, head,
+// query block) items.  Why: a 512-key prompt gives a workgroup only 2..8 key tiles, and `profiles/r2_probe_flash_lengths.jsonl`
+// shows what that costs -- the SAME kernel runs 914 TF at n = 8192, 739 at 2048, 402 at 512, 168 at 128: ~10 us per
+// workgroup go to dispatch, the exposed Q / first-tile load latency and the store tail, not to tiles.  Here
+//   * the NEXT item's first K/V tile is put in flight (LDS-DMA into the ring stage the last tile does not use) while the
+//     current item's last tile is computed, and its Q fragments are loaded as soon as the last S = K Q^T has issued, so an
+//     item starts with its operands already there;
+//   * the normalised output tile is staged in the last tile's ring stage (128 rows x D bf16 = exactly one K|V stage, 16-byte
+//     chunks XOR-swizzled by row instead of a padded pitch) and leaves as coalesced 16-byte stores under the next item;
+//   * items are assigned XCD-aware like v2's 1-D grid (workgroup p works for XCD p % 8 on groups with group % 8 == XCD, the
+//     query blocks of one group run at the same time on that XCD's workgroups and share its L2), and a workgroup's position
+//     in the per-XCD list rotates by one per round so that it sees every causal block weight (2, 4, 6, 8 tiles) in turn.
+template <int D>
+__global__ __launch_bounds__(256, 2) void flash_prefill_v3_kernel(const bf16* __restrict__ qkv, int64_t ld_qkv,
+                                                                 const bf16* __restrict__ kc, const bf16* __restrict__ vc,
+                                                                 int64_t n_max, const int32_t* __restrict__ pos0_dev,
+                                                                 int pos0_host, const uint8_t* __restrict__ mask,
+                                                                 int64_t mask_ld, bf16* __restrict__ out, int64_t ldo,
+                                                                 int q_len, int heads, float scale, int n_groups) {
+    constexpr int NW = 4, QF = 2, KK = D / 32, DF = D / 16;
+    constexpr int ROWB = D * 2, SLOTS = ROWB / 16;
+    constexpr int TILE_B = FK_TILE * ROWB;
+    constexpr int FQ = NW * QF * 16;
+    static_assert(FQ * ROWB == 2 * TILE_B, "the output tile must be exactly one K|V ring stage");
+    __shared__ __attribute__((aligned(16))) char smem[2 * 2 * TILE_B];  // [stage][K | V]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int pos0 = pos0_dev ? *pos0_dev : pos0_host;
+    const float sl2 = scale * 1.44269504088896340736f;                 // softmax in base 2
+    const int nq = (q_len + FQ - 1) / FQ;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, S = gridDim.x >> 3;
+    const int lim = ((n_groups - xcd + 7) >> 3) * nq;                  // items of this XCD: its groups x query blocks
+
+    // item of round k for this workgroup (false: none left -- and then none in any later round either)
+    auto item_of = [&](int k, int& qb, int& head, int64_t& b) -> bool {
+        const int j = k * S + (slot + k) % S;
+        if (j >= lim) return false;
+        const int gi = j / nq, qi = j - gi * nq;
+        const int grp = gi * 8 + xcd;
+        qb = nq - 1 - qi;                                              // heaviest causal block of a group first
+        head = grp % heads;
+        b = grp / heads;
+        return true;
+    };
+    auto load_q = [&](int qb, int head, int64_t b, bf16x8_t (&qf)[QF][KK]) {
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+            const int row = qb * FQ + wave * (QF * 16) + f * 16 + l15;
+            const int r = row < q_len ? row : q_len - 1;
+            const bf16* qp = qkv + (b * q_len + r) * ld_qkv + (int64_t)head * 3 * D + g * 8;
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) qf[f][kk] = *reinterpret_cast<const bf16x8_t*>(qp + kk * 32);
+        }
+    };
+    auto n_keys_of = [&](int qb) { return pos0 + min(q_len, (qb + 1) * FQ); };
+
+    // lane-constant LDS offsets of the fragment reads (see v2)
+    int kaddr[KK], vaddr[DF];
+#pragma unroll
+    for (int kk = 0; kk < KK; ++kk) kaddr[kk] = l15 * ROWB + (((kk * 4 + g) ^ (l15 & (SLOTS - 1))) * 16);
+    {
+        const int rl = g * 4 + (l15 >> 2);
+        const int swz = (((rl & 7) << 1) & (SLOTS - 1)) << 4;
+#pragma unroll
+        for (int d = 0; d < DF; ++d) vaddr[d] = rl * ROWB + (((d * 16 + (l15 & 3) * 4) * 2) ^ swz);
+    }
+
+    int qb, head;
+    int64_t b;
+    int k = 0;
+    if (!item_of(0, qb, head, b)) return;
+    constexpr int ST_FULL = FQ * SLOTS / (NW * 64);   // output store instructions per thread of a full 128-row block
+    int pend_stores = 0;   // store instructions this wave issued in the previous item's epilogue (ST_FULL or "unknown" = 0)
+    int gt = 0;   // key tiles this workgroup has consumed so far: tile kt of the current item lives in ring stage (gt + kt) & 1
+    bf16x8_t qf[QF][KK];
+    {   // first item: tile 0 into the ring, then the Q fragments (younger: the first in-loop wait covers both)
+        const bf16* kbase0 = kc + (b * heads + head) * n_max * D;
+        const bf16* vbase0 = vc + (b * heads + head) * n_max * D;
+        flash_stage_tile_s<D, NW>(kbase0, vbase0, 0, n_keys_of(qb), smem, smem + TILE_B, wave, lane);
+        load_q(qb, head, b, qf);
+    }
+    while (true) {
+        int nqb = 0, nhead = 0;
+        int64_t nb = 0;
+        const bool has_next = item_of(k + 1, nqb, nhead, nb);
+        const int qbase = qb * FQ + wave * (QF * 16);
+        const bf16* kbase = kc + (b * heads + head) * n_max * D;
+        const bf16* vbase = vc + (b * heads + head) * n_max * D;
+        const uint8_t* mrow = mask ? mask + b * mask_ld : nullptr;
+        const int n_keys = n_keys_of(qb);
+        const int n_tiles = (n_keys + FK_TILE - 1) / FK_TILE;
+        const int wave_last_pos = pos0 + min(qbase + QF * 16, q_len) - 1;  // last query position this wave owns
+        int qrow[QF];
+#pragma unroll
+        for (int f = 0; f < QF; ++f) qrow[f] = qbase + f * 16 + l15;
+        f32x4_t oacc[QF][DF];   // O^T accumulators: oacc[f][d][r] = O[query f*16 + l15][dim d*16 + g*4 + r]
+#pragma unroll
+        for (int f = 0; f < QF; ++f)
+#pragma unroll
+            for (int d = 0; d < DF; ++d) oacc[f][d] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        float mrun[QF], lrun[QF];   // running max in RAW score units, running sum
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+            mrun[f] = -INFINITY;
+            lrun[f] = 0.f;
+        }
+
+        for (int kt = 0; kt < n_tiles; ++kt) {
+            const int key0 = kt * FK_TILE;
+            const char* kb = smem + ((gt + kt) & 1) * 2 * TILE_B;
+            const char* vb = kb + TILE_B;
+            // this wave's share of tile kt has landed.  On an item's first tile that is the prefetched tile and the Q fragments,
+            // both OLDER than the previous item's output stores (vmcnt retires in order, and gfx9 counts stores in it): wait
+            // for everything but those stores instead of paying their acknowledge latency once per item
+            if (kt == 0 && pend_stores == ST_FULL) {
+                if (ST_FULL == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (ST_FULL == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            __syncthreads();   // tile kt visible to everybody; everybody is done with the other stage -> it can be refilled
+            {
+                char* nbuf = smem + ((gt + kt + 1) & 1) * 2 * TILE_B;
+                if (kt + 1 < n_tiles) {
+                    flash_stage_tile_s<D, NW>(kbase, vbase, key0 + FK_TILE, n_keys, nbuf, nbuf + TILE_B, wave, lane);
+                } else if (has_next) {   // the next item's first tile rides under this item's last one
+                    const bf16* kn = kc + (nb * heads + nhead) * n_max * D;
+                    const bf16* vn = vc + (nb * heads + nhead) * n_max * D;
+                    flash_stage_tile_s<D, NW>(kn, vn, 0, n_keys_of(nqb), nbuf, nbuf + TILE_B, wave, lane);
+                }
+            }
+            const bool visible = key0 <= wave_last_pos;   // wave-uniform: some query of this wave can see this tile
+            f32x4_t sacc[QF][4];
+            if (visible) {
+#pragma unroll
+                for (int f = 0; f < QF; ++f)
+#pragma unroll
+                    for (int kf = 0; kf < 4; ++kf) sacc[f][kf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int kf = 0; kf < 4; ++kf) {
+#pragma unroll
+                    for (int kk = 0; kk < KK; ++kk) {
+                        const bf16x8_t kfr = *reinterpret_cast<const bf16x8_t*>(kb + kaddr[kk] + kf * 16 * ROWB);
+#pragma unroll
+                        for (int f = 0; f < QF; ++f)
+                            sacc[f][kf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kfr, qf[f][kk], sacc[f][kf], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+            }
+            // the current Q fragments have issued their last MFMA: the next item's go in flight under softmax, PV and the epilogue
+            if (kt == n_tiles - 1 && has_next) load_q(nqb, nhead, nb, qf);
+            if (visible) {
+                const bool need_mask = (mrow != nullptr) || (key0 + FK_TILE > n_keys) || (key0 + FK_TILE - 1 > pos0 + qbase);
+                if (need_mask && mrow == nullptr && key0 + FK_TILE <= n_keys) {
+                    // causal diagonal of an unpadded batch (the common masked tile): compares and selects only
+#pragma unroll
+                    for (int f = 0; f < QF; ++f) {
+                        const int qpos = pos0 + qrow[f];
+#pragma unroll
+                        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r)
+                                sacc[f][kf][r] = (key0 + kf * 16 + g * 4 + r <= qpos) ? sacc[f][kf][r] : -INFINITY;
+                    }
+                } else if (need_mask) {
+                    // padding mask / ragged end: the 16 mask bytes of the lane's keys are loaded up front (clamped index, all
+                    // in flight together, one wait) instead of one dependent byte load per key
+                    bool kvis[4][4];
+                    if (mrow != nullptr) {
+                        uint8_t mb[4][4];
+#pragma unroll
+                        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) mb[kf][r] = mrow[min(key0 + kf * 16 + g * 4 + r, n_keys - 1)];
+#pragma unroll
+                        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) kvis[kf][r] = (key0 + kf * 16 + g * 4 + r < n_keys) && mb[kf][r] != 0;
+                    } else {
+#pragma unroll
+                        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) kvis[kf][r] = key0 + kf * 16 + g * 4 + r < n_keys;
+                    }
+#pragma unroll
+                    for (int f = 0; f < QF; ++f) {
+                        const int qpos = pos0 + qrow[f];
+#pragma unroll
+                        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int key = key0 + kf * 16 + g * 4 + r;
+                                sacc[f][kf][r] = (key <= qpos && kvis[kf][r]) ? sacc[f][kf][r] : -INFINITY;
+                            }
+                    }
+                }
+#pragma unroll
+                for (int f = 0; f < QF; ++f) {
+                    float tmax = -INFINITY;
+#pragma unroll
+                    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) tmax = fmaxf(tmax, sacc[f][kf][r]);
+                    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+                    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+                    const float mnew = fmaxf(mrun[f], tmax);
+                    const bool dead = (mnew == -INFINITY);          // no visible key so far for this query row
+                    const float msub = dead ? 0.f : -mnew * sl2;
+                    const float alpha = dead ? 1.0f : __builtin_amdgcn_exp2f((mrun[f] - mnew) * sl2);
+                    float psum = 0.f;
+#pragma unroll
+                    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float pv = __builtin_amdgcn_exp2f(fmaf(sacc[f][kf][r], sl2, msub));   // exp2(-inf) = 0: masked keys
+                            sacc[f][kf][r] = pv;
+                            psum += pv;
+                        }
+                    lrun[f] = lrun[f] * alpha + psum;
+                    mrun[f] = mnew;
+#pragma unroll
+                    for (int d = 0; d < DF; ++d)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) oacc[f][d][r] *= alpha;   // the lane's column IS query row l15: its own alpha
+                }
+                // O^T += V^T P^T.  key slot (g, e): e < 4 -> tile key (2ks)*16 + g*4 + e ; e >= 4 -> (2ks+1)*16 + g*4 + (e-4)
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    bf16x8_t pf[QF];
+#pragma unroll
+                    for (int f = 0; f < QF; ++f) {
+                        union {
+                            uint32_t u[4];
+                            bf16x8_t v;
+                        } pk;
+                        pk.u[0] = pack_bf16x2(sacc[f][2 * ks][0], sacc[f][2 * ks][1]);
+                        pk.u[1] = pack_bf16x2(sacc[f][2 * ks][2], sacc[f][2 * ks][3]);
+                        pk.u[2] = pack_bf16x2(sacc[f][2 * ks + 1][0], sacc[f][2 * ks + 1][1]);
+                        pk.u[3] = pack_bf16x2(sacc[f][2 * ks + 1][2], sacc[f][2 * ks + 1][3]);
+                        pf[f] = pk.v;
+                    }
+#pragma unroll
+                    for (int d = 0; d < DF; ++d) {
+                        const int a1 = vaddr[d] + (2 * ks) * 16 * ROWB;
+                        const int a2 = a1 + 16 * ROWB;
+                        union {
+                            s16x4_t h[2];
+                            bf16x8_t v;
+                        } vf;
+                        vf.h[0] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vb + a1));
+                        vf.h[1] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(vb + a2));
+#pragma unroll
+                        for (int f = 0; f < QF; ++f)
+                            oacc[f][d] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf.v, pf[f], oacc[f][d], 0, 0, 0);
+                    }
+                }
+                __builtin_amdgcn_s_setprio(0);
+            }
+        }
+        // epilogue: normalise, stage the 128 x D tile in the LAST tile's ring stage (the other one is receiving the next
+        // item's first tile), 16-byte chunks swizzled by row; then whole rows leave as coalesced 16-byte stores
+        char* ost = smem + ((gt + n_tiles - 1) & 1) * 2 * TILE_B;
+        __syncthreads();   // every wave is done reading the last tile's K / V
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+            float l = lrun[f];
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+            const float inv = l > 0.f ? 1.0f / l : 0.f;
+            const int rl = wave * (QF * 16) + f * 16 + l15;
+            char* orow = ost + rl * ROWB + (g & 1) * 8;
+#pragma unroll
+            for (int d = 0; d < DF; ++d) {
+                uint2 o2;
+                o2.x = pack_bf16x2(oacc[f][d][0] * inv, oacc[f][d][1] * inv);
+                o2.y = pack_bf16x2(oacc[f][d][2] * inv, oacc[f][d][3] * inv);
+                const int c = d * 2 + (g >> 1);
+                *reinterpret_cast<uint2*>(orow + ((c ^ (rl & (SLOTS - 1))) << 4)) = o2;
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < FQ * SLOTS; idx += NW * 64) {
+            const int rl = idx / SLOTS, c = idx - rl * SLOTS;
+            const int row = qb * FQ + rl;
+            if (row < q_len)
+                *reinterpret_cast<uint4*>(out + (b * q_len + row) * ldo + (int64_t)head * D + c * 8) =
+                    *reinterpret_cast<const uint4*>(ost + rl * ROWB + ((c ^ (rl & (SLOTS - 1))) << 4));
+        }
+        if (!has_next) break;
+        pend_stores = ((qb + 1) * FQ <= q_len) ? ST_FULL : 0;   // a block cut by q_len skips stores per wave: wait for all
+        gt += n_tiles;
+        qb = nqb;
+        head = nhead;
+        b = nb;
+        ++k;
+    }
+}
+
 // ---- host dispatch ------------------------------------------------------------------------------------------------------
 #ifdef BT_DEBUG_HOOKS
 static int g_attn_nt = 0;   // A/B hook (debug library only): non-temporal K/V loads in the global (NW = 4) streaming kernel
@@ -1077,6 +1410,19 @@ static constexpr int g_flash_variant = 0;
     hipLaunchKernelGGL((flash_prefill_v2_kernel<D, 4, 2, OPT_>), ((OPT_) & 64) ? grid1 : grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, \
                        (const bf16*)kc, (const bf16*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (bf16*)out, ldo, q_len, \
                        heads, scale)
+static int flash_num_cus() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+            n = v;
+        else
+            n = 256;
+    }
+    return n;
+}
+
 template <int D>
 static int launch_flash(int64_t B, int q_len, int heads, const void* qkv, int64_t ld_qkv, const void* kc, const void* vc,
                         int64_t n_max, const int32_t* pos0_dev, int pos0_host, const uint8_t* mask, int64_t mask_ld,
@@ -1087,6 +1433,20 @@ static int launch_flash(int64_t B, int q_len, int heads, const void* qkv, int64_
     const int64_t n_wg = ceil_div(q_len, FQ_ROWS) * heads * B;
     BT_CHECK_ARG(n_wg < (1ll << 31), "bt_attention: prefill grid too large");
     const dim3 grid1((unsigned)n_wg);   // 1-D, XCD-aware mapping (OPT bit 64)
+    if (g_flash_variant == 0 && ceil_div(q_len, FQ_ROWS) <= 8) {
+        // production for prompts of <= 1024 block positions (2 .. 16 key tiles per item: per-item fixed costs dominate; longer
+        // prompts keep the one-workgroup-per-block grid, whose dynamic dispatch balances 2 .. 32+-tile items better: n = 2048
+        // 733 vs 686 TF): persistent workgroups, two per CU; 8 x S of them, S = slots per XCD
+        const int64_t n_groups = (int64_t)heads * B;
+        BT_CHECK_ARG(n_groups < (1ll << 31), "bt_attention: too many (sequence, head) groups");
+        const int64_t per_xcd = ceil_div(n_groups, 8) * ceil_div(q_len, FQ_ROWS);
+        const int S = (int)std::min<int64_t>(std::max(1, 2 * flash_num_cus() / 8), per_xcd);
+        hipLaunchKernelGGL((flash_prefill_v3_kernel<D>), dim3(8 * S), dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)kc,
+                           (const bf16*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (bf16*)out, ldo, q_len, heads, scale,
+                           (int)n_groups);
+        BT_LAUNCH_CHECK("bt_attention(flash) launch");
+        return BT_OK;
+    }
 #ifdef BT_DEBUG_HOOKS
     if (g_flash_variant == 1)
         hipLaunchKernelGGL(flash_prefill_kernel<D>, grid, dim3(256), 0, s, (const bf16*)qkv, ld_qkv, (const bf16*)kc,
@@ -1095,11 +1455,12 @@ static int launch_flash(int64_t B, int q_len, int heads, const void* qkv, int64_
     else
 #endif
 #ifdef BT_DEBUG_HOOKS
-    if ((g_flash_variant >= 3 && g_flash_variant <= 7) || (g_flash_variant >= 9 && g_flash_variant <= 12)) {   // A/B of the OPT bits: 3 -> 0 (round-1 kernel), 4 -> 1, 5 -> 3, 6 -> 7, 7 -> 15
+    if ((g_flash_variant >= 3 && g_flash_variant <= 7) || (g_flash_variant >= 9 && g_flash_variant <= 13)) {   // A/B of the OPT bits: 3 -> 0 (round-1 kernel), 4 -> 1, 5 -> 3, 6 -> 7, 7 -> 15
         switch (g_flash_variant) {
             case 3: BT_FLASH_OPT(0); break;
             case 9: BT_FLASH_OPT(31); break;    // + scale folded into the exponent FMA
             case 12: BT_FLASH_OPT(95); break;   // 31 + XCD-aware 1-D grid
+            case 13: BT_FLASH_OPT(95); break;   // the non-persistent kernel the production v3 grew out of (A/B)
             case 10: BT_FLASH_OPT(63); break;   // + lazy rescale
             case 11: BT_FLASH_OPT(59); break;   // 63 without setprio
             case 4: BT_FLASH_OPT(1); break;

@@ -687,7 +687,7 @@ def test_attention_rows_mask(dtype):
         assert out.view(B, -1)[1].abs().max() == 0
 
 
-@pytest.fixture(params=[0, 2, 1, 3, 6, 8, 10, 12], ids=["flash_v2_4w2s", "flash_v2_8w4s", "flash_v1", "flash_v2_opt0", "flash_v2_opt7",
+@pytest.fixture(params=[0, 2, 1, 3, 6, 8, 10, 13], ids=["flash_v3_persistent", "flash_v2_8w4s", "flash_v1", "flash_v2_opt0", "flash_v2_opt7",
                                                         "flash_v2_8w_qf1", "flash_v2_opt63", "flash_v2_xcd_grid"])
 def flash_variant(request, dbg_lib):
     """0 = LDS-DMA + ds_read_b64_tr_b16 kernel, 4 waves / 128 query rows / double buffer (default), 2 = the same kernel
@@ -706,7 +706,7 @@ def test_attention_flash_prefill(d, q, pos0, flash_variant):
     assert rel_err(out, ref) <= 2e-2, rel_err(out, ref)
 
 
-@pytest.mark.parametrize("B,heads,q", [(5, 2, 300), (3, 16, 140), (9, 1, 512), (1, 1, 64)])
+@pytest.mark.parametrize("B,heads,q", [(5, 2, 300), (3, 16, 140), (9, 1, 512), (1, 1, 64), (70, 16, 200), (300, 8, 40)])
 def test_attention_flash_prefill_group_mapping(B, heads, q, flash_variant):
     """Sequence-head groups beyond / not a multiple of 8: the XCD-aware 1-D grid (query blocks of one group 8 ids apart, a
     remainder chunk for the last groups % 8) covers every (sequence, head, query block) exactly once."""

@@ -190,8 +190,9 @@ def main():
         names[0] = "production (OPT 11: transposed O accumulators)"
         names.update({9: "OPT 31 (+ scale in the exponent FMA)", 10: "OPT 63 (+ lazy rescale)", 11: "OPT 59 (63 without setprio)"})
         names[12] = "OPT 95 (31 + XCD-aware grid: a sequence-head's query blocks share one L2)"
-        names[0] = "production (OPT 95)"
-        for v in ((0, 2, 8, 9, 0, 2, 8, 9) if args.split == 1 else (3, 4, 5, 6, 7, 0, 3, 4, 5, 6, 7, 0)):
+        names[0] = "production (v3: persistent workgroups)"
+        names[13] = "v2 OPT 95 (one workgroup per query block)"
+        for v in ((13, 0, 13, 0) if args.split == 1 else (3, 4, 5, 6, 7, 0, 3, 4, 5, 6, 7, 0)):
             lib().bt_debug_flash_variant(v)
             r = probe_flash(args.batch, args.keys, args.iters)
             r["variant"] = names[v]
