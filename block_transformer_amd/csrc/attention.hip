@@ -1029,7 +1029,7 @@ __device__ inline void flash_stage_tile_s(const bf16* __restrict__ kbase, const 
 //     chunks XOR-swizzled by row instead of a padded pitch) and leaves as coalesced 16-byte stores under the next item;
 //   * items are assigned XCD-aware like v2's 1-D grid (workgroup p works for XCD p % 8 on groups with group % 8 == XCD, the
 //     query blocks of one group run at the same time on that XCD's workgroups and share its L2), and a workgroup's position
-//     in the per-XCD list rotates by one per round so that it sees every causal block weight (2, 4, 6, 8 tiles) in turn.
+//     in the per-XCD list changes per round so that it alternates heavy and light causal blocks (2 .. 8 tiles).
 template <int D>
 __global__ __launch_bounds__(256, 2) void flash_prefill_v3_kernel(const bf16* __restrict__ qkv, int64_t ld_qkv,
                                                                  const bf16* __restrict__ kc, const bf16* __restrict__ vc,
@@ -1055,7 +1055,11 @@ __global__ __launch_bounds__(256, 2) void flash_prefill_v3_kernel(const bf16* __
 
     // item of round k for this workgroup (false: none left -- and then none in any later round either)
     auto item_of = [&](int k, int& qb, int& head, int64_t& b) -> bool {
-        const int j = k * S + (slot + k) % S;
+        // position inside the round's S consecutive per-XCD items: when whole groups fit (S % nq == 0) odd rounds mirror the
+        // query-block index, so a workgroup alternates heavy / light causal blocks (8, 2, 8, 2 | 6, 4, 6, 4 tiles: equal work
+        // every two rounds -- the workgroups sharing a group's K/V through L2 stay in step); otherwise rotate by one per round
+        const int sl = (S % nq == 0) ? ((k & 1) ? slot - slot % nq + (nq - 1 - slot % nq) : slot) : (slot + k) % S;
+        const int j = k * S + sl;
         if (j >= lim) return false;
         const int gi = j / nq, qi = j - gi * nq;
         const int grp = gi * 8 + xcd;

@@ -192,7 +192,7 @@ def main():
         names[12] = "OPT 95 (31 + XCD-aware grid: a sequence-head's query blocks share one L2)"
         names[0] = "production (v3: persistent workgroups)"
         names[13] = "v2 OPT 95 (one workgroup per query block)"
-        for v in ((13, 0, 13, 0) if args.split == 1 else (3, 4, 5, 6, 7, 0, 3, 4, 5, 6, 7, 0)):
+        for v in ((9, 13, 0, 9, 13, 0) if args.split == 1 else (3, 4, 5, 6, 7, 0, 3, 4, 5, 6, 7, 0)):
             lib().bt_debug_flash_variant(v)
             r = probe_flash(args.batch, args.keys, args.iters)
             r["variant"] = names[v]
