@@ -293,7 +293,6 @@ extern "C" int bt_token_block_enqueue(const bt_engine_desc* e, int32_t t_begin, 
                  "bt_token_block_enqueue: bad step range [%d, %d) / finish %d for L = %d", t_begin, t_end, finish_count, e->L);
     if (e->B == 0) return BT_OK;
     const int64_t B = e->B, Htd = e->td_dims.hidden, Hbd = e->bd_dims.hidden;
-    const size_t es = dtype_size(e->dtype);
     for (int32_t t = t_begin; t < t_end; ++t) {
         if (t == 0) {
             // expansion_layer: Conv1d(k=1) == Linear; ctx [B, H_bd] -> [B, E*H_td] == E prefix rows per sequence
@@ -319,7 +318,6 @@ extern "C" int bt_token_block_enqueue(const bt_engine_desc* e, int32_t t_begin, 
             BT_TRY(bt_argmax(e->dtype, B, e->vocab, e->logits, e->vocab, e->raw + t, e->L, stream));
         }
     }
-    (void)es;
     if (finish_count > 0) {
         BT_CHECK_ARG(e->out_ids && e->n_cur && e->finished && e->finished_prev, "bt_token_block_enqueue: finish needs out_ids / n_cur / finished[_prev]");
         BT_TRY(bt_finish_block(B, e->L, finish_count, e->raw, e->out_ids, e->nb_max, e->n_cur, e->finished, e->finished_prev,
@@ -331,7 +329,7 @@ extern "C" int bt_token_block_enqueue(const bt_engine_desc* e, int32_t t_begin, 
 extern "C" int bt_roll_over_enqueue(const bt_engine_desc* e, bt_stream stream) {
     BT_TRY(check_desc(e, "bt_roll_over_enqueue", false, true));
     if (e->B == 0) return BT_OK;
-    const int64_t B = e->B, Hbd = e->bd_dims.hidden;
+    const int64_t B = e->B;
     // embedder lookup + concat of the block just finished; zero rows for sequences that were finished before it (:419-421)
     BT_TRY(bt_embed_rows(e->dtype, B * e->L, e->emb_width, e->raw, 1, e->vocab, e->emb_table, e->x_blk, e->emb_width,
                          e->finished_prev, e->L, stream));
@@ -355,7 +353,6 @@ extern "C" int bt_roll_over_enqueue(const bt_engine_desc* e, bt_stream stream) {
     a.seq_skip = (e->gen_eos >= 0 && e->finished) ? e->finished : nullptr;
     BT_TRY(bt_decoder_forward(e->dtype, &e->bd_dims, &e->bd_w, B, 1, e->x_blk, &a, 0, e->ctx, e->ws_step, e->ws_step_bytes,
                               stream));
-    (void)Hbd;
     return bt_bump(e->n_cur, 1, stream);
 }
 
