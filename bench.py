@@ -203,7 +203,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--pipeline", choices=["auto", "on", "off"], default="auto",
-                    help="two half-batch shards on two streams (global-attention / GEMM overlap); auto = batch >= 1024")
+                    help="two half-batch shards on two streams (global-attention / GEMM overlap, measured not to pay: DESIGN.md "
+                         "section 3); auto = off unless BT_PIPELINE=1")
     ap.add_argument("--cpu-sample", default="128,128", help="prefill,decode of the CPU baseline sample")
     args = ap.parse_args()
 
@@ -258,6 +259,7 @@ def main():
     elapsed = time.perf_counter() - t0
     assert out.shape == (B, max_length), out.shape
     log(f"{args.steps} timed steps: {elapsed:.3f}s")
+    rank_elapsed = parallel.gather_floats(elapsed)          # every rank's own time for the same K steps (self-diagnosing SCALE runs)
     elapsed = parallel.max_over_ranks(elapsed)
     ms_per_step = elapsed / args.steps * 1e3
     tokens_per_step = parallel.sum_over_ranks(B * D)
@@ -266,6 +268,8 @@ def main():
     result = {
         "metric": "decoded_tokens_per_sec_per_node", "value": value, "unit": "tokens/s", "n_gpus": world,
         "rccl_ranks": world,
+        "per_rank_tokens_per_s": [B * D * args.steps / t for t in rank_elapsed],
+        "rank_time_max_over_min": max(rank_elapsed) / min(rank_elapsed),
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"{args.config} prefill{P}/decode{D}, greedy, EOS disabled, end-to-end generate() "
@@ -325,10 +329,14 @@ def main():
         result["kernel_family_ms"] = fam_ms
         result["kernel_family_launches"] = fam_n
         dominant = max(fam_ms, key=fam_ms.get)
-        pmc = {}
-        pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc_path):
-            pmc = json.load(open(pmc_path))
+        # committed PMC passes, newest round first (each record names the kernel, the shape and the git revision it was
+        # taken on: profiles/r3_pmc_traffic.json is written by tools/gpu_runs/r3_pmc.sh)
+        pmc, pmc_file = {}, None
+        for cand in ("r3_pmc_traffic.json", "pmc_traffic.json"):
+            pmc_path = os.path.join(ROOT, "profiles", cand)
+            if os.path.exists(pmc_path):
+                pmc, pmc_file = json.load(open(pmc_path)), cand
+                break
 
         def traffic(name):
             """Fabric-side bytes per launch from the COMMITTED rocprofv3 PMC pass (FETCH_SIZE x2 gfx950 correction +
@@ -340,9 +348,12 @@ def main():
 
         def traffic_note(name):
             rec = pmc.get(name)
-            return None if not rec else (f"from profiles/pmc_traffic.json (committed rocprofv3 --pmc pass, not this run) on "
-                                         f"{rec['shape']}: {rec['hbm_bytes_corrected'] / 1e6:.1f} MB per launch vs "
-                                         f"{rec['algorithmic_bytes'] / 1e6:.1f} MB algorithmic")
+            if not rec:
+                return None
+            where = f", kernel {rec['kernel']} at git {rec['git']}" if "kernel" in rec else ""
+            return (f"from profiles/{pmc_file} (committed rocprofv3 --pmc pass, not this run{where}) on "
+                    f"{rec['shape']}: {rec['hbm_bytes_corrected'] / 1e6:.1f} MB per launch vs "
+                    f"{rec['algorithmic_bytes'] / 1e6:.1f} MB algorithmic")
 
         def roof(name):
             ms, n = fam[name]

@@ -53,6 +53,11 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
     BT_CHECK_ARG(dtype == BT_F32 || dtype == BT_BF16, "bt_decoder_forward: bad dtype %d", dtype);
     BT_CHECK_ARG(B >= 0 && q_len > 0 && first_out_row >= 0 && first_out_row < q_len, "bt_decoder_forward: bad shape");
     BT_CHECK_ARG(dims->hidden == dims->heads * dims->head_dim, "bt_decoder_forward: hidden != heads*head_dim");
+    // every launch sequence below appends q_len rows at cache row pos0 BEFORE the attention call would notice an overflow
+    // (fused QKV epilogues, mid-batch reduce, few-rows GEMV): reject a bad host position up front
+    BT_CHECK_ARG(attn->pos0_dev || (attn->pos0_host >= 0 && (int64_t)attn->pos0_host + q_len <= attn->n_max),
+                 "bt_decoder_forward: cache overflow (pos0 %d + q_len %d > n_max %lld)", attn->pos0_host, q_len,
+                 (long long)attn->n_max);
     if (B == 0) return BT_OK;
     // finished sequences: their decode-step attention (q_len = 1, row-wise kernel) is skipped, see bt_attn_args.seq_skip
     const int32_t* skip = (q_len == 1 && attn->mode == 0) ? attn->seq_skip : nullptr;
@@ -386,9 +391,11 @@ extern "C" int bt_prefill_enqueue(const bt_engine_desc* e, const int64_t* block_
     a.cos_tab = e->g_cos;
     a.sin_tab = e->g_sin;
     a.mode = (e->dtype == BT_BF16 && nb > 1) ? 1 : 0;
+    // n_split = 1 is a hint: the row-wise kernel (fp32 prefill; the tail-only last row of the last layer) raises it on its own
+    // once a score row would not fit in LDS (g_nmax beyond ~15.8k positions) and then needs the descriptor's workspace
     a.n_split = 1;
-    a.split_ws = nullptr;
-    a.split_ws_bytes = 0;
+    a.split_ws = e->split_ws;
+    a.split_ws_bytes = e->split_ws ? e->split_ws_bytes : 0;
     return bt_decoder_forward(e->dtype, &e->bd_dims, &e->bd_w, nseq, nb, x, &a, nb - 1,
                               reinterpret_cast<char*>(e->ctx) + b0 * Hbd * es, ws, ws_bytes, stream);
 }

@@ -1705,10 +1705,18 @@ struct Mma32 {
 
 struct LoadCursor {   // wave-uniform: the K-tile whose half-tiles are being issued
     int m0, n0, t, j, x;
+    int kt, rot;          // physical K-tile (== t unless the K order is rotated, see PP_FLAG_KROT) and the tile's rotation
     bool valid;
 };
 
-template <int MODE, typename P, bool SEG2 = false>
+// ABL (debug build only; 1..16 are timing ablations with WRONG results): 1 = no LDS-DMA after the prologue, 2 = no fragment
+// ds_reads after the first phase, 4 = no epilogue, 8 = every K-tile reads K-tile 0 (all operand loads hit in L2), 16 = no MFMAs.
+// 32 = K-order rotation (correct results): each workgroup walks the K-tiles of a tile in groups of 8 starting at a
+//   tile-dependent offset ((tn + 2 tm) & 7), so the workgroups of an XCD that share an A / W panel do not all request the
+//   same lines at the same moment (the first toucher pays the fabric latency, the others then hit in L2).  The sum over K
+//   is order-independent up to fp32 rounding; the order is a pure function of the tile.  Needs K % 512 == 0.
+
+template <int MODE, typename P, bool SEG2 = false, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __restrict__ A, int64_t lda,
                                                                  const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
                                                                  int K, int tiles_m, int tiles_n, const Seg2 s2) {
@@ -1741,13 +1749,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
     }
     const int total = 4 * nk * nt;
 
+    const bool krot = !SEG2 && (ABL & 32) && (nk1 & 7) == 0;
     LoadCursor lc;
     lc.t = 0; lc.j = 0; lc.x = 0;
     lc.valid = pp_tile(0, tiles_m, tiles_n, lc.m0, lc.n0);
+    lc.rot = krot ? (((lc.n0 >> 8) + 2 * (lc.m0 >> 8)) & 7) : 0;
+    lc.kt = lc.rot;
     auto issue = [&](int kind) {
+        if ((ABL & 1) && lc.x >= 2) return;
         if (lc.valid) {
             if (!SEG2 || lc.t < nk1)
-                stage_half_at(A, lda, W, ldw, lc.m0, lc.n0, M, N, lc.t * BK, lc.x & 1, kind, smem, wave, lane, voff_a, voff_w);
+                stage_half_at(A, lda, W, ldw, lc.m0, lc.n0, M, N, ((ABL & 8) ? 0 : lc.kt) * BK, lc.x & 1, kind, smem, wave, lane, voff_a, voff_w);
             else
                 stage_half_at(s2.x, s2.ldx, s2.w, s2.ldw, lc.m0, lc.n0, M, N, (lc.t - nk1) * BK, lc.x & 1, kind, smem, wave,
                               lane, voff_a2, voff_w2);
@@ -1769,7 +1781,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
             lc.t = 0;
             ++lc.j;
             lc.valid = lc.j < nt && pp_tile(lc.j, tiles_m, tiles_n, lc.m0, lc.n0);
+            if (krot) lc.rot = ((lc.n0 >> 8) + 2 * (lc.m0 >> 8)) & 7;
         }
+        lc.kt = krot ? ((lc.t & ~7) | ((lc.t + lc.rot) & 7)) : lc.t;
     };
     // prologue: K-tile 0 (4 half-tiles) + K-tile 1 (A0, W0) = PD2 loads
     issue_bias();
@@ -1800,24 +1814,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
             for (int p = 0; p < 2; ++p, ++g) {
                 if (!grp1) wait_for_phase_pp(g, total, prev_full && t == 0);
                 cbarrier();
+                const bool do_reads = !(ABL & 2) || g == 0;
                 if (p == 0) {
                     // new tile: accumulators start at the bias (LDS row j & 1, landed before this barrier)
                     if (t == 0) P::init(acc, ep.bias != nullptr, SEG2 && s2.bias != nullptr, lds_addr(smem + PP_BIAS_OFF + (j & 1) * 1024), wcol, lane);
+                    if (do_reads) {
 #pragma unroll
-                    for (int ks = 0; ks < P::KS; ++ks) {
+                        for (int ks = 0; ks < P::KS; ++ks) {
 #pragma unroll
-                        for (int nb = 0; nb < P::NB; ++nb)
-                            wf[nb][ks] = P::read_w(buf + (2 + wh) * HALF_BYTES, wrow, nb, ks, lane);
+                            for (int nb = 0; nb < P::NB; ++nb)
+                                wf[nb][ks] = P::read_w(buf + (2 + wh) * HALF_BYTES, wrow, nb, ks, lane);
 #pragma unroll
-                        for (int i = 0; i < P::MI; ++i) af[i][ks] = P::read_a(buf, wm, i, ks, lane);
+                            for (int i = 0; i < P::MI; ++i) af[i][ks] = P::read_a(buf, wm, i, ks, lane);
+                        }
                     }
                     issue(2); issue(3);
                     advance();
                 } else {
+                    if (!(ABL & 2)) {
 #pragma unroll
-                    for (int ks = 0; ks < P::KS; ++ks)
+                        for (int ks = 0; ks < P::KS; ++ks)
 #pragma unroll
-                        for (int i = 0; i < P::MI; ++i) af[i][ks] = P::read_a(buf + HALF_BYTES, wm, i, ks, lane);
+                            for (int i = 0; i < P::MI; ++i) af[i][ks] = P::read_a(buf + HALF_BYTES, wm, i, ks, lane);
+                    }
                     if (lc.t == 0) issue_bias();
                     issue(0); issue(1);
                 }
@@ -1825,15 +1844,32 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
                 cbarrier();
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_setprio(1);
+                if (!(ABL & 16)) {
 #pragma unroll
-                for (int ks = 0; ks < P::KS; ++ks)
+                    for (int ks = 0; ks < P::KS; ++ks)
 #pragma unroll
-                    for (int i = 0; i < P::MI; ++i)
+                        for (int i = 0; i < P::MI; ++i)
 #pragma unroll
-                        for (int nb = 0; nb < P::NB; ++nb)
-                            acc[p * P::MI + i][nb] = P::mma(wf[nb][ks], af[i][ks], acc[p * P::MI + i][nb]);
+                            for (int nb = 0; nb < P::NB; ++nb)
+                                acc[p * P::MI + i][nb] = P::mma(wf[nb][ks], af[i][ks], acc[p * P::MI + i][nb]);
+                } else {
+#pragma unroll
+                    for (int ks = 0; ks < P::KS; ++ks) {
+#pragma unroll
+                        for (int i = 0; i < P::MI; ++i) asm volatile("" ::"v"(af[i][ks]));
+#pragma unroll
+                        for (int nb = 0; nb < P::NB; ++nb) asm volatile("" ::"v"(wf[nb][ks]));
+                    }
+                }
                 __builtin_amdgcn_s_setprio(0);
             }
+        }
+        if (ABL & 4) {   // timing ablation: keep the accumulators live, no epilogue (no stores: prev_full stays false)
+#pragma unroll
+            for (int i = 0; i < 2 * P::MI; ++i)
+#pragma unroll
+                for (int nb = 0; nb < P::NB; ++nb) asm volatile("" ::"v"(acc[i][nb][0]));   // (one element keeps the MFMA chain live)
+            continue;
         }
         // the epilogue's lane-derived addresses must not be hoisted out of the tile loop (they would sit in VGPRs through
         // the K-loop, which has none to spare): hand it an opaque copy of the lane id
@@ -2585,6 +2621,33 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
 #else
 #define BT_PP_MMA32_AB(MODE_)
 #endif
+#ifdef BT_DEBUG_HOOKS   /* timing ablations of the production kernel (wrong results): variants 30 + ABL bits */
+#define BT_PP_ABL(MODE_, ABL_)                                                                                      \
+    hipLaunchKernelGGL((gemm_bf16_mfma256pp_kernel<MODE_, Mma16, false, ABL_>), dim3(n_wg), dim3(512), 0, s,          \
+                       (const bf16*)A, lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n, Seg2{})
+#define BT_PP_ABL_AB(MODE_)                                                                                         \
+    if (g_gemm_variant >= 31 && g_gemm_variant <= 93) {                                                             \
+        switch (g_gemm_variant - 30) {                                                                              \
+            case 1: BT_PP_ABL(MODE_, 1); break;    /* no DMA */                                                     \
+            case 2: BT_PP_ABL(MODE_, 2); break;    /* no ds_reads */                                                \
+            case 3: BT_PP_ABL(MODE_, 3); break;    /* MFMA + barriers (+ epilogue) */                               \
+            case 4: BT_PP_ABL(MODE_, 4); break;    /* no epilogue */                                                \
+            case 7: BT_PP_ABL(MODE_, 7); break;    /* MFMA + barriers only */                                       \
+            case 8: BT_PP_ABL(MODE_, 8); break;    /* all operand loads hit L2 */                                   \
+            case 12: BT_PP_ABL(MODE_, 12); break;  /* L2 hits + no epilogue */                                      \
+            case 16: BT_PP_ABL(MODE_, 16); break;  /* no MFMA */                                                    \
+            case 18: BT_PP_ABL(MODE_, 18); break;  /* DMA ring only (+ epilogue) */                                 \
+            case 22: BT_PP_ABL(MODE_, 22); break;  /* DMA ring only */                                              \
+            case 30: BT_PP_ABL(MODE_, 30); break;  /* ring only, L2 hits */                                         \
+            case 32: BT_PP_ABL(MODE_, 32); break;  /* K-order rotation (correct results) */                         \
+            case 36: BT_PP_ABL(MODE_, 36); break;  /* K-order rotation, no epilogue */                              \
+            case 54: BT_PP_ABL(MODE_, 54); break;  /* K-order rotation, ring only */                                \
+            default: BT_PP_ABL(MODE_, 0); break;                                                                    \
+        }                                                                                                           \
+    } else
+#else
+#define BT_PP_ABL_AB(MODE_)
+#endif
 #define BT_LAUNCH_PP(MODE_)                                                                                           \
     do {                                                                                                              \
         BT_PP_MMA32_AB(MODE_)                                                                                       \
@@ -2600,9 +2663,13 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                         else if (ep.q.enabled) BT_LAUNCH_PP(PP_QKV);
                         else if (act == BT_ACT_GELU && !residual) BT_LAUNCH_PP(PP_GELU);
                         else if (act == BT_ACT_NONE && residual) BT_LAUNCH_PP(PP_RES);
-                        else if (act == BT_ACT_NONE) BT_LAUNCH_PP(PP_PLAIN);
+                        else if (act == BT_ACT_NONE) {   // (timing ablations are instantiated for the plain mode only)
+                            BT_PP_ABL_AB(PP_PLAIN)
+                            BT_LAUNCH_PP(PP_PLAIN);
+                        }
                         else BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<true>));   // GELU + residual: one-tile kernel
 #undef BT_LAUNCH_PP
+#undef BT_PP_ABL_AB
 #undef BT_LAUNCH_PP2
 #undef BT_PP_MMA32_AB
                     } else {

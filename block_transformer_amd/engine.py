@@ -425,6 +425,11 @@ class PipelinedEngine:
         gen_eos = -1
         for s in self.shards:
             gen_eos = s.configure(gen, cfg_pad, use_mask)
+        if gen_eos >= 0:
+            # HF stops a block once EVERY row has produced EOS -- a whole-batch condition the shards cannot evaluate
+            # independently, and the per-block look at finished[] would have to be ordered behind every shard's stream
+            raise _lib.BtError("EOS handling runs on the single-stream engine (BlockTransformer picks it when "
+                               "generation_config.eos_token_id is set); PipelinedEngine needs eos_token_id = None")
         per_iter = timers is not None and timers.per_iteration
         main = self.stream
         main.wait_stream(torch.cuda.current_stream())
@@ -465,8 +470,6 @@ class PipelinedEngine:
             first = False
             n_blocks += 1
             if n_blocks * L >= max_length:
-                break
-            if gen_eos >= 0 and all(bool(s.finished.all()) for s in self.shards):   # host sync per block (reference :415)
                 break
             for i, s in enumerate(self.shards):
                 with torch.cuda.stream(streams[i]):

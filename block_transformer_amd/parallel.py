@@ -77,7 +77,17 @@ def sum_over_ranks(value: float) -> float:
     return float(t.item())
 
 
-def gather_ids(local_ids: torch.Tensor, n_total: int, pad_token_id: int = 0) -> Optional[torch.Tensor]:
+def gather_floats(value: float) -> List[float]:
+    """Every rank's value, in rank order, on every rank ([value] without a process group)."""
+    if not dist.is_initialized():
+        return [float(value)]
+    t = torch.zeros(dist.get_world_size(), dtype=torch.float64, device=_device_for_collectives())
+    t[dist.get_rank()] = float(value)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) for v in t.tolist()]
+
+
+def gather_ids(local_ids: torch.Tensor, n_total: int, pad_token_id: int) -> Optional[torch.Tensor]:
     """Concatenate every rank's generated ids (shard order == request order); returned on every rank.
 
     Shards may come back with different widths: with EOS handling enabled each shard's generate() stops as soon as all
@@ -104,8 +114,18 @@ def gather_ids(local_ids: torch.Tensor, n_total: int, pad_token_id: int = 0) -> 
     return torch.cat(out, dim=0)
 
 
-def generate_sharded(generate_fn, input_ids: torch.Tensor, pad_token_id: int = 0, **kw) -> torch.Tensor:
-    """Run ``generate_fn`` on this rank's request shard and gather the full result (right-padded to the widest shard)."""
+def model_pad_token_id(model) -> int:
+    """The id a single-process ``BlockTransformer.generate`` writes behind a finished sequence: whole blocks of
+    ``token_decoder.config.pad_token_id`` (reference model/block_transformer.py:384) -- what a narrower shard must be
+    right-padded with so that the sharded result equals the unsharded one."""
+    return int(model.token_decoder.config.pad_token_id)
+
+
+def generate_sharded(generate_fn, input_ids: torch.Tensor, *, pad_token_id: int, **kw) -> torch.Tensor:
+    """Run ``generate_fn`` on this rank's request shard and gather the full result (right-padded to the widest shard).
+
+    ``pad_token_id`` is required: shards stop independently under EOS handling, and the tail of a narrower
+    shard must carry the id the unsharded generate() would have written there -- ``model_pad_token_id(model)``."""
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
     lo, hi = shard_bounds(input_ids.shape[0], rank, world)
     local = generate_fn(input_ids[lo:hi], **kw) if hi > lo else input_ids.new_zeros(0, 0)

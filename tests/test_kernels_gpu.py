@@ -578,7 +578,19 @@ def test_qkv_rope_append_fused_persistent_full_tiles(B, q, pos0, heads, d, use_d
     run_qkv_fused(B, q, pos0, heads, d, use_dev_pos, use_table, True, kernel, max_wg)
 
 
-def run_qkv_fused(B, q, pos0, heads, d, use_dev_pos, use_table, fused, kernel, max_wg):
+@pytest.mark.parametrize("B,q,pos0", [(4096, 1, 6), (4096, 2, 0), (64, 512, 0)])
+@pytest.mark.parametrize("use_dev_pos,use_table", [(False, False), (True, True)])
+def test_qkv_rope_append_product_library_benchmark_shapes(B, q, pos0, use_dev_pos, use_table):
+    """The fused QKV / RoPE / KV-append GEMM at the shapes bench.py runs, through the PRODUCT binary libbt_hip.so (no debug
+    hooks, the dispatch the engine gets): B = 4096 q = 1 (decode: M = 4096 -> 128^2 kernel), B = 4096 q = 2 (token step 0:
+    M = 8192 -> persistent 256^2 kernel), B = 64 q = 512 (one prefill chunk: M = 32768, persistent kernel, 3 rounds of
+    256 workgroups) -- 1.2B geometry (16 heads x 128, H = 2048, N = 6144) against an fp64 reference."""
+    from block_transformer_amd import _lib as L_
+    assert not L_._debug_active, "this test must run on libbt_hip.so"
+    run_qkv_fused(B, q, pos0, 16, 128, use_dev_pos, use_table, True, 0, 0, product=True)
+
+
+def run_qkv_fused(B, q, pos0, heads, d, use_dev_pos, use_table, fused, kernel, max_wg, product=False):
     rot = 32
     H = heads * d
     n_max = pos0 + q + 2
@@ -592,19 +604,24 @@ def run_qkv_fused(B, q, pos0, heads, d, use_dev_pos, use_table, fused, kernel, m
     kc = torch.zeros(B, heads, n_max, d, dtype=torch.bfloat16, device=DEV)
     vc = torch.zeros_like(kc)
     xd, wd, bd = x.to(DEV), w.to(DEV), bias.to(DEV)
-    lib().bt_debug_no_qkv_fusion(0 if fused else 1)
-    lib().bt_debug_gemm_variant(kernel)     # 0 heuristic (128^2 tiles at these sizes), 9 one-tile 256^2, 12 persistent 256^2
-    lib().bt_debug_gemm_max_wg(max_wg)
+    if not product:
+        lib().bt_debug_no_qkv_fusion(0 if fused else 1)
+        lib().bt_debug_gemm_variant(kernel)     # 0 heuristic (128^2 tiles at these sizes), 9 one-tile 256^2, 12 persistent 256^2
+        lib().bt_debug_gemm_max_wg(max_wg)
     try:
         check(lib().bt_qkv_rope_append(_lib.BT_BF16, B, q, heads, d, rot, ptr(xd), H, ptr(wd), ptr(bd), ptr(qkv), 3 * H,
                                        ptr(kc), ptr(vc), n_max, ptr(pos_dev), 0 if use_dev_pos else pos0, ptr(table),
                                        ptr(tab[0]), ptr(tab[1]), None, 0, current_stream()))
         torch.cuda.synchronize()
     finally:
-        lib().bt_debug_no_qkv_fusion(0)
-        lib().bt_debug_gemm_variant(0)
-        lib().bt_debug_gemm_max_wg(0)
-    ref = (x.double() @ w.double().T + bias.double()).view(B, q, heads, 3, d)
+        if not product:
+            lib().bt_debug_no_qkv_fusion(0)
+            lib().bt_debug_gemm_variant(0)
+            lib().bt_debug_gemm_max_wg(0)
+    if B * q * 3 * H * H > 1 << 34:   # large shapes: fp64 reference GEMM on the GPU (torch), the rest on the host
+        ref = (xd.double() @ wd.double().T + bd.double()).cpu().view(B, q, heads, 3, d)
+    else:
+        ref = (x.double() @ w.double().T + bias.double()).view(B, q, heads, 3, d)
     rows = torch.arange(pos0, pos0 + q)
     rp = table.cpu()[rows].long() if use_table else rows
     pos = rp.view(1, q, 1).expand(B, q, heads)

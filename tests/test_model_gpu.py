@@ -24,6 +24,36 @@ def maxabs(a, b):
     return (a.detach().float().cpu() - b.float()).abs().max().item()
 
 
+def oracle_block_logits(o, prompt, block_tokens):
+    """fp32 oracle logits of ONE generated block along the GPU's own tokens: context of `prompt` (+ earlier generated
+    blocks already appended by the caller), token decoder teacher-forced on block_tokens[:, :-1] at the RoPE positions of
+    cached generation.  Returns (ctx [B, H], logits [B, n, V]) with n = block_tokens.shape[1]."""
+    d = o.preprocess_inputs_for_generation(prompt, None)
+    ids, bm = d["input_ids"], d["block_attention_mask"]
+    B, nb, L = ids.shape
+    hidden, _ = o.block_decoder(o.embed(ids).view(B, nb, -1), bm)
+    ctx = hidden[:, -1]
+    n = block_tokens.shape[1]
+    lg = o.token_decoder_teacher_forced(ctx, block_tokens[:, :n - 1], positions=o.td_pos)
+    return ctx, lg
+
+
+def assert_tokens_within_noise(ref_logits, tokens, rel, abs_, what=""):
+    """Margin-aware greedy check (replaces "at least x % of the tokens agree"): every emitted token must be the oracle's
+    argmax or lie inside the bf16 noise band below it -- oracle_logit[argmax] - oracle_logit[token] <= 2 * budget with
+    budget = rel * max|logit| + abs_ (the logit error budget of the instantiation under test).  A wrong kernel emits
+    tokens many budgets below the maximum; a bf16 near-tie stays inside the band.  Returns the fraction of exact matches."""
+    budget = rel * ref_logits.abs().max().item() + abs_
+    best = ref_logits.max(dim=-1).values
+    chosen = ref_logits.gather(-1, tokens.unsqueeze(-1)).squeeze(-1)
+    gap = (best - chosen)
+    worst = gap.max().item()
+    exact = (ref_logits.argmax(-1) == tokens).float().mean().item()
+    print(f"[margin-aware {what}] worst gap {worst:.4f} vs band {2 * budget:.4f}; exact argmax agreement {exact:.3f}")
+    assert worst <= 2 * budget, f"{what}: emitted token {worst:.4f} below the oracle's best logit (noise band {2 * budget:.4f})"
+    return exact
+
+
 @pytest.mark.parametrize("name", GOLDEN_CONFIGS)
 def test_embedder_g1(gpu_model, name):
     model, dims, sd, fx = gpu_model(name)
@@ -324,8 +354,13 @@ def test_bf16_generate_tracks_fp32_oracle(gpu_model, name):
     ctx = model._engine.ctx.float().cpu()
     ref = trace["ctx"][0]
     assert (ctx - ref).abs().max() <= 6e-2 * ref.abs().max() + 2e-2, (ctx - ref).abs().max()
-    agree = (got[:, -L:] == want[:, -L:]).float().mean().item()
-    assert agree >= 0.5, agree
+    # margin-aware: along the GPU's own tokens every emitted token is the oracle's argmax or inside the bf16 noise band
+    # (same relative budget as the context bound above), and the engine's last-step logits are inside that budget
+    ref_ctx, ref_lg = oracle_block_logits(o, prompt, got[:, -L:])
+    assert torch.allclose(ref_ctx, ref, atol=1e-5)
+    assert_tokens_within_noise(ref_lg, got[:, -L:], 6e-2, 2e-2, f"{name} first block")
+    e_lg = (model._engine.tok.logits.float().cpu() - ref_lg[:, -1]).abs().max().item()
+    assert e_lg <= 6e-2 * ref_lg.abs().max().item() + 2e-2, e_lg
 
 
 def test_real_dims_one_layer_bf16_logits():
@@ -600,7 +635,13 @@ def test_mid_batch_streamer_stack_matches_unfused(B, dbg_lib):
         lib().bt_debug_skinny_rows(16)
         model._engine = None
     assert torch.equal(fused[:, :32], prompt.cpu())
-    assert (fused == unfused).all(dim=1).float().mean() >= 0.6, (fused == unfused).float().mean()
+    # margin-aware instead of "x % of the rows agree": BOTH launch sequences must emit, at every step of the first block, the
+    # fp32 oracle's argmax or a token inside the bf16 noise band below it (2-layer bf16 stack: 3 % of max|logit| + 0.01)
+    sd16 = {k: v.bfloat16().float() for k, v in sd.items()}
+    o = oracle_from_dims(dims, sd16)
+    for name, out in (("fused", fused), ("unfused", unfused)):
+        _, ref_lg = oracle_block_logits(o, prompt.cpu(), out[:, 32:36])
+        assert_tokens_within_noise(ref_lg, out[:, 32:36], 3e-2, 1e-2, f"streamer B={B} {name}")
     assert (fused[:, 32] == unfused[:, 32]).float().mean() >= 0.8
 
 
@@ -674,6 +715,113 @@ def test_full_depth_1p2b_bf16_first_block_logits_vs_oracle(B):
         assert int(got[r, P]) == int(logits[i].argmax())               # the emitted token is the argmax of the engine's logits
     assert torch.equal(got[:, :P], prompt)
     model.release_buffers()
+
+
+def test_full_depth_1p2b_bf16_benchmark_batch_decode_dispatch_vs_oracle():
+    """The benchmark's own dispatch: BASELINE configs[1] at FULL depth, bf16, **B = 4096** (the batch
+    bench.py runs), short prompt (P = 64 -> 16 block positions, so the oracle and the KV cache stay small).  At this batch
+    the decode runs gemm_bf16_mfma_kernel<128,128> with the fused QKV / RoPE / append epilogue (M = 4096, N = 6144), the 128^2
+    residual GEMMs (N = 2048), the persistent 256^2 kernel for h->4h / logits and -- token step 0, q = 2 -> M = 8192 -- for
+    everything; prefill = 65536 rows through the persistent kernel + flash.  Three checkpoints, each against the fp32 CPU
+    oracle on the same bf16 weights for 3 rows (rows are independent), same margin-aware budget as the B = 2 / 64 test
+    (3 % of max + 0.01):
+      (1) max_length = P + 1: context embedding + first-token logits (token step 0: q = 2, M = 8192);
+      (2) max_length = P + 2: logits of token step 1 (q = 1, M = 4096: the 128^2 fused-QKV path), oracle teacher-forced on
+          the GPU's own first token;
+      (3) max_length = P + L + 1: context + logits of the SECOND block (block-decoder decode step: q = 1, M = 4096 against
+          the global KV written by the prefill + roll-over embedding), oracle prefilled on prompt + the GPU's own first block."""
+    model, dims, o = _full_1p2b()
+    model.pipeline = False
+    model.use_graphs = True
+    B, P, L = 4096, 64, dims.L
+    prompt = torch.randint(0, dims.vocab, (B, P), generator=torch.Generator().manual_seed(4096))
+    rows = [0, 1777, B - 1]
+    dev_prompt = prompt.to(DEV)
+
+    def budget(ref):
+        return 3e-2 * ref.abs().max().item() + 1e-2
+
+    # (1) first block, token step 0
+    got = model.generate(dev_prompt, max_length=P + 1).cpu()
+    eng = model._engine
+    ctx, lg = eng.ctx.float().cpu()[rows], eng.tok.logits.float().cpu()[rows]
+    ref_ctx, ref_lg = _oracle_first_token(o, prompt[rows])
+    e_ctx, e_lg = (ctx - ref_ctx).abs().max().item(), (lg - ref_lg).abs().max().item()
+    print(f"[B=4096 step 0] ctx err {e_ctx:.4f} / {budget(ref_ctx):.4f}, logit err {e_lg:.4f} / {budget(ref_lg):.4f}")
+    assert e_ctx <= budget(ref_ctx) and e_lg <= budget(ref_lg)
+    assert torch.equal(got[rows, P], lg.argmax(-1))
+    assert_tokens_within_noise(ref_lg[:, None], got[rows, P:P + 1], 3e-2, 1e-2, "B=4096 step 0")
+    assert torch.equal(got[:, :P], prompt)
+    # (2) token step 1 (q = 1): teacher-forced oracle along the GPU's first token
+    got2 = model.generate(dev_prompt, max_length=P + 2).cpu()
+    assert torch.equal(got2[:, :P + 1], got), "first token changed between two runs"
+    lg1 = model._engine.tok.logits.float().cpu()[rows]
+    _, ref_blk = oracle_block_logits(o, prompt[rows], got2[rows, P:P + 2])
+    e1 = (lg1 - ref_blk[:, 1]).abs().max().item()
+    print(f"[B=4096 step 1] logit err {e1:.4f} / {budget(ref_blk[:, 1]):.4f}")
+    assert e1 <= budget(ref_blk[:, 1])
+    assert torch.equal(got2[rows, P + 1], lg1.argmax(-1))
+    assert_tokens_within_noise(ref_blk, got2[rows, P:P + 2], 3e-2, 1e-2, "B=4096 steps 0-1")
+    # (3) second block: block-decoder decode step over the global KV
+    got3 = model.generate(dev_prompt, max_length=P + L + 1).cpu()
+    assert torch.equal(got3[:, :P + 2], got2)
+    eng = model._engine
+    ctx2, lg2 = eng.ctx.float().cpu()[rows], eng.tok.logits.float().cpu()[rows]
+    ref_ctx2, ref_lg2 = _oracle_first_token(o, got3[rows, :P + L])
+    e_ctx2, e_lg2 = (ctx2 - ref_ctx2).abs().max().item(), (lg2 - ref_lg2).abs().max().item()
+    print(f"[B=4096 block 2] ctx err {e_ctx2:.4f} / {budget(ref_ctx2):.4f}, logit err {e_lg2:.4f} / {budget(ref_lg2):.4f}")
+    assert e_ctx2 <= budget(ref_ctx2) and e_lg2 <= budget(ref_lg2)
+    assert torch.equal(got3[rows, P + L], lg2.argmax(-1))
+    _, ref_blk1 = oracle_block_logits(o, prompt[rows], got3[rows, P:P + L])
+    assert_tokens_within_noise(ref_blk1, got3[rows, P:P + L], 3e-2, 1e-2, "B=4096 first block")
+    # every row was decoded (not just the sampled three): ids in range, rows differ
+    assert int(got3.min()) >= 0 and int(got3.max()) < dims.vocab
+    assert len({tuple(r.tolist()) for r in got3[:64, P:]}) > 8
+    model.release_buffers()
+
+
+def test_full_size_1p2b_p2048_d2048_per_gpu_properties():
+    """BASELINE configs[3] per GPU (the 8x line shards requests, one shard per GPU: what ONE rank runs): block_main_b4_1.2b
+    bf16, B = 8, P = 2048, D = 2048 -> n_max = 1024 block positions: the flash prefill v3 <-> v2 switch (prompts <= 1024
+    positions take v3; here 512) with a cache sized for 1024, 512 block-step replays with the global attention growing
+    512 -> 1023 keys and the split-N factor re-chosen for n_max = 1024.  Size-independent properties: prompt preserved, ids in
+    range, deterministic replay, graphs on == graphs off bit for bit."""
+    model, dims, _ = _full_1p2b()
+    model.pipeline = None
+    model.use_graphs = True
+    B, P, D = 8, 2048, 2048
+    prompt = torch.randint(0, dims.vocab, (B, P), generator=torch.Generator().manual_seed(33)).to(DEV)
+    a = model.generate(prompt, max_length=P + D).cpu()
+    assert a.shape == (B, P + D) and torch.equal(a[:, :P], prompt.cpu())
+    assert int(a.min()) >= 0 and int(a.max()) < dims.vocab
+    eng = model._engine
+    assert eng.n_max >= 1024 and eng.n_split > 1, (eng.n_max, eng.n_split)
+    b = model.generate(prompt, max_length=P + D).cpu()
+    assert torch.equal(a, b), "graph replay is not deterministic / state leaked between runs"
+    model.use_graphs = False
+    try:
+        c = model.generate(prompt, max_length=P + D).cpu()
+    finally:
+        model.use_graphs = True
+    assert torch.equal(a, c), "captured graphs differ from the eager launch sequence"
+    assert len({tuple(r.tolist()) for r in a[:, P:P + 64]}) > 1
+    model.release_buffers()
+
+
+def test_long_prompt_long_decode_fp32_tokens_vs_oracle(gpu_model):
+    """configs[3]-class shape in fp32 against the oracle: micro128 (d = 128, rot = 32), P = 2048 (512 prompt positions through
+    the flash prefill), D = 1024 (256 block steps: cache grows 512 -> 767 of n_max = 768, split-N attention under graph
+    replay): greedy tokens bit-exact."""
+    model, dims, sd, fx = gpu_model("micro128")
+    o = oracle_from_dims(dims, sd)
+    B, P, D = 2, 2048, 1024
+    prompt = torch.randint(1, dims.vocab, (B, P), generator=torch.Generator().manual_seed(77))
+    want = o.generate(prompt, max_length=P + D)
+    model.use_graphs = True
+    got = model.generate(prompt.to(DEV), max_length=P + D).cpu()
+    assert model._engine.n_max >= (P + D) // dims.L and model._engine.n_split > 1
+    first_bad = (got != want).any(0).nonzero()
+    assert torch.equal(got, want), f"first differing column {int(first_bad[0]) if len(first_bad) else None}"
 
 
 def test_fp32_production_dims_one_layer_logits_within_1e3():
@@ -1009,11 +1157,14 @@ def test_mid_batch_generate_matches_unfused(B, dbg_lib):
         model._engine = None
     assert torch.equal(fused[:, :32], prompt.cpu())
     assert (fused[:, 32] == unfused[:, 32]).float().mean() >= 0.9, (fused[:, 32] == unfused[:, 32]).float().mean()
-    assert (fused == unfused).all(dim=1).float().mean() >= 0.5, (fused == unfused).float().mean()
+    # margin-aware (8 rows spread over the batch, both launch sequences): every token of the first block is the fp32 oracle's
+    # argmax or inside the bf16 noise band below it
     sd16 = {k: v.bfloat16().float() for k, v in sd.items()}
     o = oracle_from_dims(dims, sd16)
-    want = o.generate(prompt[:3].cpu(), max_length=36)
-    assert (fused[:3, 32:36] == want[:, 32:36]).float().mean() >= 0.5
+    rows = torch.linspace(0, B - 1, 8).long()
+    for name, out in (("fused", fused), ("unfused", unfused)):
+        _, ref_lg = oracle_block_logits(o, prompt.cpu()[rows], out[rows, 32:36])
+        assert_tokens_within_noise(ref_lg, out[rows, 32:36], 3e-2, 1e-2, f"mid-batch B={B} {name}")
     del model
     torch.cuda.empty_cache()
 

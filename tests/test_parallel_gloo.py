@@ -41,9 +41,10 @@ def _worker(rank, world, port, n_req, ret):
     assert dist.get_world_size() == world
     ids = torch.randint(1, 500, (n_req, 6), generator=torch.Generator().manual_seed(0))
     parallel.barrier()
-    full = parallel.generate_sharded(_fake_generate, ids, max_length=11)
+    full = parallel.generate_sharded(_fake_generate, ids, pad_token_id=0, max_length=11)
     mx = parallel.max_over_ranks(1.0 + rank)
     sm = parallel.sum_over_ranks(10.0 * (rank + 1))
+    assert parallel.gather_floats(1.5 + rank) == [1.5 + r for r in range(world)]
     shard = parallel.shard_requests(ids, rank, world)
     ret[rank] = (full, mx, sm, shard.shape[0])
     parallel.barrier()
@@ -103,6 +104,54 @@ def test_gather_ids_ragged_widths_and_empty_shard(n_req):
     want = torch.cat([torch.nn.functional.pad(sh, (0, width - sh.shape[1]), value=1) for sh in shards])
     for r in (0, 1):
         assert torch.equal(ret[r], want), (r, ret[r], want)
+
+
+EOS_PAD = 5   # a NON-zero pad id (token_decoder.config.pad_token_id of the stand-in "model")
+
+
+def _eos_generate(ids, max_length):
+    """Stand-in for generate() with EOS handling: request i is finished after len_i = 6 + ids[i, 0] % 5 columns, the batch
+    stops at the longest request, earlier finishers carry EOS_PAD behind their text (what BlockTransformer.generate writes)."""
+    B, P = ids.shape
+    lens = [min(max_length, 6 + int(ids[i, 0]) % 5) for i in range(B)]
+    width = max(lens) if B else 0
+    out = torch.full((B, width), EOS_PAD, dtype=torch.int64)
+    for i in range(B):
+        out[i, :P] = ids[i]
+        out[i, P:lens[i]] = (ids[i].sum() + torch.arange(P, lens[i])) % 977 + 10
+    return out
+
+
+def _eos_worker(rank, world, port, n_req, pad, ret):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    parallel.init_distributed("gloo")
+    ids = torch.arange(n_req * 4, dtype=torch.int64).view(n_req, 4) * 3 + 1
+    ret[rank] = parallel.generate_sharded(_eos_generate, ids, pad_token_id=pad, max_length=12)
+    parallel.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_eos_output_equals_unsharded_with_nonzero_pad():
+    """with the model's pad id the gathered result of two independently stopping shards is exactly what ONE process
+    generating all requests returns; with another id (the old default 0) the padded tail differs -- hence the required
+    ``pad_token_id`` argument."""
+    n_req = 5
+    ids = torch.arange(n_req * 4, dtype=torch.int64).view(n_req, 4) * 3 + 1
+    want = _eos_generate(ids, 12)
+    results = {}
+    for pad in (EOS_PAD, 0):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        mgr = mp.Manager()
+        ret = mgr.dict()
+        mp.spawn(_eos_worker, args=(2, port, n_req, pad, ret), nprocs=2, join=True)
+        results[pad] = (ret[0], ret[1])
+    assert torch.equal(results[EOS_PAD][0], want) and torch.equal(results[EOS_PAD][1], want)
+    assert results[0][0].shape == want.shape and not torch.equal(results[0][0], want)
+    with pytest.raises(TypeError):
+        parallel.generate_sharded(_eos_generate, ids, max_length=12)     # pad_token_id is required
 
 
 def test_self_launch_under_torchrun(tmp_path):

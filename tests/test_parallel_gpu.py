@@ -30,7 +30,8 @@ def _rank_main(rank, world, port, ret):
     model.token_decoder.generation_config.eos_token_id = None
     prompt = torch.randint(1, dims.vocab, (7, 12), generator=torch.Generator().manual_seed(5))
     parallel.barrier()
-    full = parallel.generate_sharded(lambda ids, **kw: model.generate(ids.to(f"cuda:{rank}"), **kw), prompt, max_length=28)
+    full = parallel.generate_sharded(lambda ids, **kw: model.generate(ids.to(f"cuda:{rank}"), **kw), prompt,
+                                    pad_token_id=parallel.model_pad_token_id(model), max_length=28)
     ret[rank] = full.cpu()
     parallel.barrier()
     dist.destroy_process_group()

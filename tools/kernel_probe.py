@@ -151,7 +151,7 @@ def probe_copy(nbytes, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=["gemm", "attn", "flash", "suite", "copy", "ab", "abl", "skinny", "decode", "vendor", "pitch",
-                                     "local", "lin2", "ln"])
+                                     "local", "lin2", "ln", "ppabl"])
     ap.add_argument("--m", type=int, default=32768)
     ap.add_argument("--n", type=int, default=6144)
     ap.add_argument("--k", type=int, default=2048)
@@ -275,6 +275,35 @@ def main():
                     r["variant"] = "no_gemv"
                     res.append(r)
                     lib().bt_debug_gemm_variant(0)
+    elif args.what == "ppabl":
+        # timing ablations of the PRODUCTION persistent kernel (plain epilogue; results of the ablated variants are wrong by design):
+        # where do the cycles between the MFMA skeleton and the full kernel go?  variant = 30 + ABL bits
+        # (1 no DMA, 2 no ds_reads, 4 no epilogue, 8 every K-tile reads K-tile 0 = all L2 hits, 16 no MFMA, 32 K-order rotation)
+        names = {0: "production", 31: "no DMA", 32: "no ds_reads", 33: "MFMA + barriers + epilogue", 34: "no epilogue",
+                 37: "MFMA + barriers only", 38: "operand loads all hit L2", 42: "L2 hits, no epilogue", 46: "no MFMA",
+                 48: "DMA ring + epilogue", 52: "DMA ring only", 60: "DMA ring only, L2 hits", 62: "K-order rotation",
+                 66: "K-order rotation, no epilogue", 84: "K-order rotation, DMA ring only"}
+        order = [0, 62, 38, 34, 66, 42, 31, 32, 37, 46, 52, 84, 60]
+        for (M, N, K) in ((32768, 6144, 2048), (32768, 2048, 8192), (32768, 8192, 2048), (32768, 2048, 2048), (8192, 6144, 2048)):
+            x = torch.randn(M, K, device=DEV).bfloat16()
+            w = (torch.randn(N, K, device=DEV) * K ** -0.5).bfloat16()
+            b = torch.randn(N, device=DEV).bfloat16()
+            out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+            for rep in range(2):
+                for v in order:
+                    lib().bt_debug_gemm_variant(v)
+                    ms = timed(lambda: ops.linear(x, w, b, out=out), 10)
+                    res.append({"op": "pp_ablation", "M": M, "N": N, "K": K, "variant": v, "what": names[v], "us": round(ms * 1e3, 1),
+                                "TF_equiv": round(2.0 * M * N * K / ms / 1e9, 1)})
+            lib().bt_debug_gemm_variant(62)          # the rotated K order is a correct kernel: check it
+            ops.linear(x, w, b, out=out)
+            lib().bt_debug_gemm_variant(0)
+            ref = torch.empty_like(out)
+            ops.linear(x, w, b, out=ref)
+            res.append({"op": "pp_krot_check", "M": M, "N": N, "K": K,
+                        "max_abs_diff_vs_production": float((out.float() - ref.float()).abs().max()),
+                        "max_abs": float(ref.float().abs().max())})
+        lib().bt_debug_gemm_variant(0)
     elif args.what == "abl":
         for (M, N, K) in ((32768, 6144, 2048), (32768, 2048, 8192)):
             for v in (0, 3, 20, 21, 8, 0, 3, 20, 21, 8):   # production / 4-phase one-tile kernel: full, no MFMA, DMA only, MFMA+barriers only
