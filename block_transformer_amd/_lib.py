@@ -122,6 +122,7 @@ _DEBUG_SIGS = {
     "bt_debug_force_generic_gemm": (None, [c_int]),
     "bt_debug_gemm_variant": (None, [c_int]),
     "bt_debug_gemm_max_wg": (None, [c_int]),
+    "bt_debug_pp_dbg": (None, [c_int]),
     "bt_debug_skinny_rows": (None, [c_int]),
     "bt_debug_small_stages": (None, [c_int]),
     "bt_debug_mid_rows": (None, [c_int]),

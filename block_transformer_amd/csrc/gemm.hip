@@ -96,6 +96,10 @@ struct EpiArgs {
     int64_t ldo;
     int M, N, act;
     QkvEpi q;
+#ifdef BT_DEBUG_HOOKS
+    int dbg;   // persistent-kernel experiments (bt_debug_pp_dbg): bit 0 = stores go to an L2-resident dummy region (WRONG results,
+               // timing only), bit 1 = non-temporal stores, bits 8.. = start-up stagger (units of ~1 us per stagger group)
+#endif
 };
 
 __device__ inline void epi_store4(const EpiArgs& e, int m, int n, float (&v)[4], bool vec_ok) {
@@ -1416,6 +1420,15 @@ __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x
                     dst = part == 0 ? e.out + (int64_t)m * e.ldo + n
                                     : cache + ((b * e.q.heads + head) * e.q.n_max + pos0 + t) * D + el;
                 }
+#ifdef BT_DEBUG_HOOKS
+                if (e.dbg & 1)   // timing experiment: every workgroup rewrites one of 32 tiles (4 MiB, stays dirty in L2)
+                    dst = e.out + (int64_t)((m - cm0) + (blockIdx.x & 31) * 256) * e.ldo + ((n - n_wave) + (n_wave & 255));
+                if (e.dbg & 2) {
+                    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+                    __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(dst));
+                    continue;
+                }
+#endif
                 *reinterpret_cast<uint4*>(dst) = v;
             }
         }
@@ -1729,6 +1742,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
     const int wrow = (wn & 1) * 64;              // its 64-row slab inside the half == 64 contiguous output columns
     const int wcol = wh * 128 + wrow;            // column offset of the wave's output inside the tile
     const bool grp1 = wave >= 4;
+#ifdef BT_DEBUG_HOOKS
+    // start-up stagger experiment: the workgroups of an XCD that share an A panel (local id & 3) start together, the four groups
+    // ~ (dbg >> 8) us apart, so the per-tile store bursts of the groups do not coincide
+    for (int i = ((blockIdx.x >> 3) & 3) * (ep.dbg >> 8); i > 0; --i) __builtin_amdgcn_s_sleep(32);
+#endif
     char* stage = smem + PP_EPI_OFF + wave * P::PATCH_BYTES;
     const uint32_t lane_slot = (uint32_t)(((lane & 7) ^ ((lane >> 3) & 7)) * 16);
     const uint32_t voff_a = (uint32_t)(lane >> 3) * (uint32_t)(lda * 2) + lane_slot;
@@ -1873,6 +1891,250 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
         }
         // the epilogue's lane-derived addresses must not be hoisted out of the tile loop (they would sit in VGPRs through
         // the K-loop, which has none to spare): hand it an opaque copy of the lane id
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        P::template epilogue<MODE>(ep, pos0, stage, acc, cm0, cn0 + wcol, wm, lane_e);
+        prev_full = (cm0 + BM2 <= M) && (cn0 + BN2 <= N);
+    }
+    if (!grp1) cbarrier();
+}
+
+// ---- persistent kernel, second generation of the K-loop (round 3) --------------------------------------------------------------
+// Same tile walk, LDS ring, fragment mapping, MFMA order, per-wave epilogue and -- phase for phase -- the same vmcnt values as
+// gemm_bf16_mfma256pp_kernel; what changes is the SCALAR code around them.  The round-3 timing ablations
+// (profiles/r3_pp_ablation.md) showed the MFMA + barrier skeleton of that kernel at 1.63 PF and the full kernel at 1.07-1.25 PF,
+// and its ISA showed why: every phase ran a ~30-instruction SALU branch tree to pick its s_waitcnt immediate BETWEEN the MFMA
+// cluster and the barrier the partner wave group is parked at (pure matrix-pipe idle time, four times per K-tile), and each
+// half-tile issue recomputed a 64-bit row address with s_mul_hi / s_mul chains (~25 SALU per half-tile).  Here:
+//   * the K-loop is split by position in the load stream: K-tile 0 of a tile (the only place the store-count waits apply),
+//     the steady state (constant immediates: vmcnt(6) opens phase 0, vmcnt(8) phase 1 -- what wait_for_phase_pp evaluates to
+//     whenever the issue count is not clipped by the end of the stream; tests/test_gemm_ring_schedule.py checks the
+//     equality) and the last two K-tiles of the workgroup's LAST tile (the generic function, as before);
+//   * a full tile's half-tiles are addressed as (SGPR base of the tile's half) + (per-lane 32-bit offset that advances by
+//     128 B per K-tile): one s_add into M0 + the DMA per instruction, four v_add per K-tile, no multiplies; tiles cut by the
+//     matrix edge keep the per-lane clamped path (stage_half_at).
+// Bit-identical results to the first-generation kernel (same operand order, same accumulation order).
+constexpr int PP2_WAIT_P0 = 6, PP2_WAIT_P1 = 8;   // steady-state vmcnt immediates (+ PP_STORES for K-tile 0 behind a full tile)
+
+template <int OFF>
+__device__ inline void glds16_sbase_off(const char* base_uniform, uint32_t voff, uint32_t lds_base_uniform) {
+    // M0 = LDS base + OFF in one SALU op; the s_nop covers the SALU-writes-M0 -> LDS-DMA wait state
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :
+                 : "v"(voff), "s"(base_uniform), "s"(lds_base_uniform), "n"(OFF)
+                 : "memory", "scc");
+}
+
+template <int MODE, int ABL = 0>
+__global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* __restrict__ A, int64_t lda,
+                                                                  const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
+                                                                  int K, int tiles_m, int tiles_n) {
+    typedef Mma16 P;
+    const int M = ep.M, N = ep.N;
+    __shared__ __attribute__((aligned(16))) char smem[PP_SMEM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int wh = wn >> 1;
+    const int wrow = (wn & 1) * 64;
+    const int wcol = wh * 128 + wrow;
+    const bool grp1 = wave >= 4;
+    char* stage = smem + PP_EPI_OFF + wave * P::PATCH_BYTES;
+    const uint32_t lane_slot = (uint32_t)(((lane & 7) ^ ((lane >> 3) & 7)) * 16);
+    // lane part of a DMA address inside its 16-row group: row (lane >> 3) of rows 0..7 / 8..15, swizzled 16-byte slot
+    const uint32_t voff_a_0 = (uint32_t)(lane >> 3) * (uint32_t)(lda * 2) + lane_slot;
+    const uint32_t voff_w_0 = (uint32_t)(lane >> 3) * (uint32_t)(ldw * 2) + lane_slot;
+    const uint32_t row8_a = (uint32_t)(8 * lda * 2), row8_w = (uint32_t)(8 * ldw * 2);
+    uint32_t voff_a = voff_a_0, voff_w = voff_w_0;          // + 128 B per K-tile of the load cursor
+    const uint32_t ring_lds = lds_addr(smem) + (uint32_t)wave * 2048u;
+
+    const int nk = K / BK;
+    const int nwg = tiles_m * tiles_n;
+    const int G = gridDim.x;
+    int nt = nwg / G;
+    {
+        int mm, nn;
+        if (nwg % G != 0 && pp_tile(nt, tiles_m, tiles_n, mm, nn)) ++nt;
+    }
+    const int total = 4 * nk * nt;
+
+    // ---- load cursor (wave-uniform) ----
+    int lm0 = 0, ln0 = 0, lt = 0, lj = 0, lx = 0;
+    bool lvalid = pp_tile(0, tiles_m, tiles_n, lm0, ln0);
+    bool lfull = false;
+    const char *pa0 = nullptr, *pa1 = nullptr, *pw0 = nullptr, *pw1 = nullptr;
+    auto enter_tile = [&]() {   // the cursor stands at K-tile 0 of tile (lm0, ln0)
+        lfull = (lm0 + BM2 <= M) && (ln0 + BN2 <= N);
+        pa0 = reinterpret_cast<const char*>(A) + (int64_t)(lm0 + wave * 16) * lda * 2;
+        pa1 = pa0 + (int64_t)128 * lda * 2;
+        pw0 = reinterpret_cast<const char*>(W) + (int64_t)(ln0 + wave * 16) * ldw * 2;
+        pw1 = pw0 + (int64_t)128 * ldw * 2;
+        voff_a = voff_a_0;
+        voff_w = voff_w_0;
+    };
+    if (lvalid) enter_tile();
+    // half-tiles `k0` and `k1` (consumption order A0, W0, W1, A1) of the cursor's K-tile
+    auto issue2 = [&](auto k0c, auto k1c, bool check_valid) {
+        if ((ABL & 1) && lx >= 2) return;
+        if (check_valid && !lvalid) return;
+        const uint32_t ring = ring_lds + (uint32_t)(lx & 1) * (4u * HALF_BYTES);
+        auto one = [&](auto kc) {
+            constexpr int kind = decltype(kc)::value;
+            constexpr bool is_a = (kind == 0) || (kind == 3);
+            constexpr int half = (kind >= 2) ? 1 : 0;
+            constexpr int off = ((is_a ? 0 : 2) + half) * HALF_BYTES;
+            const char* base = is_a ? (half ? pa1 : pa0) : (half ? pw1 : pw0);
+            const uint32_t v0 = is_a ? voff_a : voff_w;
+            glds16_sbase_off<off>(base, v0, ring);
+            glds16_sbase_off<off + 1024>(base, v0 + (is_a ? row8_a : row8_w), ring);
+        };
+        if (__builtin_expect(lfull, 1)) {
+            one(k0c);
+            one(k1c);
+        } else {   // tile cut by the matrix edge: per-lane clamped rows
+            stage_half_at(A, lda, W, ldw, lm0, ln0, M, N, lt * BK, lx & 1, decltype(k0c)::value, smem, wave, lane, voff_a_0, voff_w_0);
+            stage_half_at(A, lda, W, ldw, lm0, ln0, M, N, lt * BK, lx & 1, decltype(k1c)::value, smem, wave, lane, voff_a_0, voff_w_0);
+        }
+    };
+    auto issue_bias = [&]() {
+        if (wave == 0 && ep.bias && lvalid) {
+            int col = ln0 + (lane & 31) * 8;
+            col = col <= N - 8 ? col : N - 8;
+            glds16_vaddr(ep.bias + col, lds_addr(smem + PP_BIAS_OFF + (lj & 1) * 1024));
+        }
+    };
+    auto advance = [&]() {
+        ++lx;
+        voff_a += 128;
+        voff_w += 128;
+        if (++lt == nk) {
+            lt = 0;
+            ++lj;
+            lvalid = lj < nt && pp_tile(lj, tiles_m, tiles_n, lm0, ln0);
+            if (lvalid) enter_tile();
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    // prologue: K-tile 0 (4 half-tiles) + K-tile 1 (A0, W0) = PD2 loads
+    issue_bias();
+    issue2(I0{}, I1{}, true);
+    issue2(I2{}, I3{}, true);
+    advance();
+    if (lt == 0) issue_bias();
+    issue2(I0{}, I1{}, true);
+
+    typename P::Acc acc[2 * P::MI][P::NB];
+    bf16x8_t af[P::MI][P::KS];
+    bf16x8_t wf[P::NB][P::KS];
+    int pos0 = 0;
+    if (MODE == PP_QKV) pos0 = __builtin_amdgcn_readfirstlane(ep.q.pos0_dev ? *ep.q.pos0_dev : ep.q.pos0_host);
+
+    if (grp1) {
+        wait_for_phase_pp(0, total, false);
+        cbarrier();
+    }
+    int g = 0;
+    int cm0 = 0, cn0 = 0;
+    bool prev_full = false;
+    // one phase.  PM: 0 = K-tile 0 of a tile, 1 = steady state, 2 = generic (stream tail)
+    auto phase = [&](auto pc, auto pmc, int t, int j) {
+        constexpr int p = decltype(pc)::value, PM = decltype(pmc)::value;
+        if (!grp1) {
+            if constexpr (PM == 2) {
+                wait_for_phase_pp(g, total, prev_full && t == 0);
+            } else if constexpr (PM == 0) {
+                if (prev_full) wait_vmcnt_pp<(p ? PP2_WAIT_P1 : PP2_WAIT_P0) + PP_STORES>();
+                else wait_vmcnt<(p ? PP2_WAIT_P1 : PP2_WAIT_P0)>();
+            } else {
+                wait_vmcnt<(p ? PP2_WAIT_P1 : PP2_WAIT_P0)>();
+            }
+        }
+        cbarrier();
+        const char* buf = smem + (g & 2) * 2 * HALF_BYTES;
+        const bool do_reads = !(ABL & 2) || g == 0;
+        if constexpr (p == 0) {
+            if constexpr (PM == 0)
+                P::init(acc, ep.bias != nullptr, false, lds_addr(smem + PP_BIAS_OFF + (j & 1) * 1024), wcol, lane);
+            if (do_reads) {
+#pragma unroll
+                for (int ks = 0; ks < P::KS; ++ks) {
+#pragma unroll
+                    for (int nb = 0; nb < P::NB; ++nb) wf[nb][ks] = P::read_w(buf + (2 + wh) * HALF_BYTES, wrow, nb, ks, lane);
+#pragma unroll
+                    for (int i = 0; i < P::MI; ++i) af[i][ks] = P::read_a(buf, wm, i, ks, lane);
+                }
+            }
+            issue2(I2{}, I3{}, PM == 2);
+            advance();
+        } else {
+            if (!(ABL & 2)) {
+#pragma unroll
+                for (int ks = 0; ks < P::KS; ++ks)
+#pragma unroll
+                    for (int i = 0; i < P::MI; ++i) af[i][ks] = P::read_a(buf + HALF_BYTES, wm, i, ks, lane);
+            }
+            if (lt == 0) issue_bias();
+            issue2(I0{}, I1{}, PM == 2);
+        }
+        if (grp1) {   // group 1 waits for the data of phase g + 1 before the barrier that opens it for group 0
+            if constexpr (PM == 2) {
+                wait_for_phase_pp(g + 1, total, prev_full && t == 0 && p == 0);
+            } else if constexpr (PM == 0 && p == 0) {
+                if (prev_full) wait_vmcnt_pp<PP2_WAIT_P1 + PP_STORES>();
+                else wait_vmcnt<PP2_WAIT_P1>();
+            } else {
+                wait_vmcnt<(p == 0 ? PP2_WAIT_P1 : PP2_WAIT_P0)>();
+            }
+        }
+        cbarrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        if (!(ABL & 16)) {
+#pragma unroll
+            for (int ks = 0; ks < P::KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < P::MI; ++i)
+#pragma unroll
+                    for (int nb = 0; nb < P::NB; ++nb)
+                        acc[p * P::MI + i][nb] = P::mma(wf[nb][ks], af[i][ks], acc[p * P::MI + i][nb]);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < P::KS; ++ks) {
+#pragma unroll
+                for (int i = 0; i < P::MI; ++i) asm volatile("" ::"v"(af[i][ks]));
+#pragma unroll
+                for (int nb = 0; nb < P::NB; ++nb) asm volatile("" ::"v"(wf[nb][ks]));
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+        ++g;
+    };
+    for (int j = 0; j < nt; ++j) {
+        pp_tile(j, tiles_m, tiles_n, cm0, cn0);
+        // the generic waits are only needed where the end of the load stream clips the issue count: the last two K-tiles of
+        // the workgroup's last tile (nk >= 4 is a launch precondition, so K-tile 0 is never among them)
+        const int t_gen = (j == nt - 1) ? nk - 2 : nk;
+        phase(I0{}, I0{}, 0, j);
+        phase(I1{}, I0{}, 0, j);
+        int t = 1;
+        for (; t < t_gen; ++t) {
+            phase(I0{}, I1{}, t, j);
+            phase(I1{}, I1{}, t, j);
+        }
+        for (; t < nk; ++t) {
+            phase(I0{}, I2{}, t, j);
+            phase(I1{}, I2{}, t, j);
+        }
+        if (ABL & 4) {
+#pragma unroll
+            for (int i = 0; i < 2 * P::MI; ++i)
+#pragma unroll
+                for (int nb = 0; nb < P::NB; ++nb) asm volatile("" ::"v"(acc[i][nb][0]));
+            continue;
+        }
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         P::template epilogue<MODE>(ep, pos0, stage, acc, cm0, cn0 + wcol, wm, lane_e);
@@ -2518,6 +2780,9 @@ BT_KNOB int g_mid_fuse = 1;
 BT_KNOB bool g_mid_rows = true;   // 17..256-row stacks take the slab + fused-reduce path (false: A/B against the unfused launches)
 BT_KNOB bool g_few_dual = true;   // <= 4 rows: QKV and h->4h GEMVs of a layer in one launch (false: two launches, A/B)
 BT_KNOB int g_small_stages = 0;   // LDS ring depth of the 128^2 / 128x64 / 64x64 kernels: 0 = per-tile default, 2..4 forced (A/B)
+#ifdef BT_DEBUG_HOOKS
+static int g_pp_dbg = 0;          // EpiArgs::dbg of the persistent kernel
+#endif
 BT_KNOB int g_gemm_variant = 0;   // 0 auto; 1 force 128^2; 2/3 256^2 four-phase ring (plain/staggered); 4-8 timing ablations; 9/10 256^2
 // two-phase ring, one tile per workgroup (staggered/plain); 14 persistent on 32x32x16 MFMA; default: persistent two-phase ring.
 
@@ -2555,6 +2820,9 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
         ep.M = (int)M;
         ep.N = (int)N;
         ep.act = act;
+#ifdef BT_DEBUG_HOOKS
+        ep.dbg = g_pp_dbg;
+#endif
         ep.q = QkvEpi{};
         Seg2 s2{};
         if (seg2) {
@@ -2576,12 +2844,14 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
             if (fused_out) *fused_out = true;
         }
         const int64_t tiles256 = ceil_div(M, BM2) * ceil_div(N, BN2);
-        // big-tile kernel: one 8-wave workgroup per CU -> needs >= ~1 full wave of 256 tiles and little tail quantisation
+        // big-tile kernel: one 8-wave workgroup per CU -> needs >= ~3/4 of a wave of 256 tiles and little tail quantisation
+        // (round 3, profiles/r3_decode_shapes.jsonl + r3_ppv2.jsonl: M = 4096, N = 6144 = 384 tiles runs 94 us on the persistent
+        //  kernel vs 130 us on the 128^2 kernel, M = 2048, N = 6144 = 192 tiles 57 vs 70 us; 128 tiles lose: 54 vs 44 us)
         const bool pp_ok = (N % 8 == 0) && (ldo % 8 == 0) && aligned16(out) && (K + s2.K) / BK >= 4 &&
                            (!residual || (ldr % 8 == 0 && aligned16(residual))) && (!bias || aligned16(bias));
         const bool use256 = mfma_ok && g_gemm_variant != 1 && (N % 4 == 0) &&
-                            (g_gemm_variant >= 2 || (tiles256 >= 240 && (tiles256 % 256 == 0 || tiles256 >= 1024 ||
-                                                                         (tiles256 % 256) >= 160))) &&
+                            (g_gemm_variant >= 2 || (tiles256 >= 192 && (tiles256 % 256 == 0 || tiles256 >= 1024 ||
+                                                                         (tiles256 % 256) >= 96))) &&
                             (!seg2 || (pp_ok && (g_gemm_variant == 0 || g_gemm_variant == 14)));
         if (use256) {
             ProfScope ps(BT_PROF_LINEAR_MFMA, s);
@@ -2648,11 +2918,36 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
 #else
 #define BT_PP_ABL_AB(MODE_)
 #endif
+#ifdef BT_DEBUG_HOOKS   /* A/B: 16 = first-generation K-loop (scalar wait trees, per-half-tile address math) */
+#define BT_PP_V1_AB(MODE_)                                                                                          \
+    if (g_gemm_variant == 16)                                                                                       \
+        hipLaunchKernelGGL((gemm_bf16_mfma256pp_kernel<MODE_, Mma16>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,   \
+                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n, Seg2{});                           \
+    else
+#define BT_PP2_ABL(MODE_, ABL_)                                                                                     \
+    hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, ABL_>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A, lda,  \
+                       (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n)
+#define BT_PP2_ABL_AB(MODE_)                                                                                        \
+    if (g_gemm_variant >= 101 && g_gemm_variant <= 131) {                                                           \
+        switch (g_gemm_variant - 100) {                                                                             \
+            case 1: BT_PP2_ABL(MODE_, 1); break;    /* no DMA */                                                    \
+            case 2: BT_PP2_ABL(MODE_, 2); break;    /* no ds_reads */                                               \
+            case 4: BT_PP2_ABL(MODE_, 4); break;    /* no epilogue */                                               \
+            case 7: BT_PP2_ABL(MODE_, 7); break;    /* MFMA + barriers only */                                      \
+            case 22: BT_PP2_ABL(MODE_, 22); break;  /* DMA ring only */                                             \
+            default: BT_PP2_ABL(MODE_, 0); break;                                                                   \
+        }                                                                                                           \
+    } else
+#else
+#define BT_PP_V1_AB(MODE_)
+#define BT_PP2_ABL_AB(MODE_)
+#endif
 #define BT_LAUNCH_PP(MODE_)                                                                                           \
     do {                                                                                                              \
         BT_PP_MMA32_AB(MODE_)                                                                                       \
-        hipLaunchKernelGGL((gemm_bf16_mfma256pp_kernel<MODE_, Mma16>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,     \
-                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n, Seg2{});                             \
+        BT_PP_V1_AB(MODE_)                                                                                          \
+        hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A, lda,      \
+                           (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                          \
     } while (0)
 #define BT_LAUNCH_PP2(MODE_)                                                                                          \
     hipLaunchKernelGGL((gemm_bf16_mfma256pp_kernel<MODE_, Mma16, true>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,   \
@@ -2665,10 +2960,14 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                         else if (act == BT_ACT_NONE && residual) BT_LAUNCH_PP(PP_RES);
                         else if (act == BT_ACT_NONE) {   // (timing ablations are instantiated for the plain mode only)
                             BT_PP_ABL_AB(PP_PLAIN)
+                            BT_PP2_ABL_AB(PP_PLAIN)
                             BT_LAUNCH_PP(PP_PLAIN);
                         }
                         else BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<true>));   // GELU + residual: one-tile kernel
 #undef BT_LAUNCH_PP
+#undef BT_PP_V1_AB
+#undef BT_PP2_ABL
+#undef BT_PP2_ABL_AB
 #undef BT_PP_ABL_AB
 #undef BT_LAUNCH_PP2
 #undef BT_PP_MMA32_AB
@@ -3265,6 +3564,7 @@ int mid_res_ln(hipStream_t s, int64_t M, int64_t N, int64_t K1, const void* x1, 
 extern "C" void bt_debug_force_generic_gemm(int on) { g_force_generic = on != 0; }
 extern "C" void bt_debug_gemm_variant(int v) { g_gemm_variant = v; }
 extern "C" void bt_debug_gemm_max_wg(int n) { g_max_wg = n; }
+extern "C" void bt_debug_pp_dbg(int f) { g_pp_dbg = f; }
 extern "C" void bt_debug_skinny_rows(int n) { g_skinny_rows = n; }
 extern "C" void bt_debug_small_stages(int n) { g_small_stages = n; }
 extern "C" void bt_debug_mid_rows(int on) { g_mid_rows = on != 0; }

@@ -216,3 +216,29 @@ def test_persistent_model_detects_miscounted_stores():
     with pytest.raises(AssertionError, match="WAR"):
         pp_model(8, 3, [True] * 3, [PP_STORES] * 3, pd=8)
 
+
+
+# ---- second-generation K-loop (gemm_bf16_mfma256pp2_kernel): constant vmcnt immediates outside the stream tail -----------------
+PP2_WAIT = [int(v) for v in re.search(r"constexpr int PP2_WAIT_P0 = (\d+), PP2_WAIT_P1 = (\d+);", SRC).groups()]
+
+
+@pytest.mark.parametrize("nk", [4, 5, 8, 32, 128])
+@pytest.mark.parametrize("nt", [1, 2, 3, 12])
+def test_pp2_constant_waits_equal_the_generic_function(nk, nt):
+    """The v2 kernel hard-codes vmcnt(PP2_WAIT_P0 / P1) (+ PP_STORES in K-tile 0 behind a full tile) for every phase except the
+    last two K-tiles of the workgroup's last tile, where it calls the generic function.  For exactly those phases the
+    generic function (the one the hazard model above verifies) must evaluate to the same immediates -- for group 0's wait
+    for its own phase and for group 1's wait for the next phase."""
+    total = 4 * nk * nt
+    g = 0
+    for j in range(nt):
+        t_gen = nk - 2 if j == nt - 1 else nk
+        for t in range(nk):
+            for p in (0, 1):
+                if t < t_gen:
+                    for prev_full in (False, True):
+                        sy0 = prev_full and t == 0
+                        assert _pp_wait_imm(g, total, sy0, PD2) == PP2_WAIT[p] + (PP_STORES if sy0 else 0), (nk, nt, j, t, p)
+                        sy1 = prev_full and t == 0 and p == 0
+                        assert _pp_wait_imm(g + 1, total, sy1, PD2) == PP2_WAIT[1 - p] + (PP_STORES if sy1 else 0), (nk, nt, j, t, p)
+                g += 1

@@ -127,7 +127,7 @@ def test_gelu_epilogue_accuracy(kernel, dbg_lib):
 @pytest.mark.parametrize("M,N,K", [(512, 768, 2048), (1000, 776, 448), (300, 520, 256), (2048, 1024, 512), (256, 2304, 320)])
 @pytest.mark.parametrize("variant", ["plain", "bias", "bias_gelu", "bias_res", "res"])
 @pytest.mark.parametrize("max_wg", [0, 1, 4, 5])
-@pytest.mark.parametrize("kernel", [12, 14])
+@pytest.mark.parametrize("kernel", [12, 14, 16])   # 12 = production (second-generation K-loop), 16 = first generation, 14 = 32x32 MFMA
 def test_linear_persistent_kernel(M, N, K, variant, max_wg, kernel, dbg_lib):
     """The persistent 256x256 kernel (forced; grid capped so workgroups walk 1..many tiles incl. a partial last round)
     against fp64: bias folded into the accumulator init, per-wave LDS-patch epilogue, residual joined in fp32, M/N edge
@@ -572,7 +572,7 @@ def test_qkv_rope_append_fused_head_dims(d, heads, kernel, max_wg, dbg_lib):
 @pytest.mark.parametrize("B,q,pos0,heads,d", [(4, 64, 3, 2, 128), (2, 256, 0, 2, 128), (8, 32, 1, 8, 32), (1, 512, 0, 4, 64)])
 @pytest.mark.parametrize("use_dev_pos,use_table", [(False, False), (True, True)])
 @pytest.mark.parametrize("max_wg", [0, 2])
-@pytest.mark.parametrize("kernel", [12, 14])
+@pytest.mark.parametrize("kernel", [12, 14, 16])
 def test_qkv_rope_append_fused_persistent_full_tiles(B, q, pos0, heads, d, use_dev_pos, use_table, max_wg, kernel, dbg_lib):
     """Fused RoPE + KV append epilogue of the persistent kernels on full 256 x 256 tiles (the fast store-count waits)."""
     run_qkv_fused(B, q, pos0, heads, d, use_dev_pos, use_table, True, kernel, max_wg)

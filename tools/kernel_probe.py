@@ -151,7 +151,7 @@ def probe_copy(nbytes, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=["gemm", "attn", "flash", "suite", "copy", "ab", "abl", "skinny", "decode", "vendor", "pitch",
-                                     "local", "lin2", "ln", "ppabl"])
+                                     "local", "lin2", "ln", "ppabl", "ppstore", "ppv2"])
     ap.add_argument("--m", type=int, default=32768)
     ap.add_argument("--n", type=int, default=6144)
     ap.add_argument("--k", type=int, default=2048)
@@ -304,6 +304,65 @@ def main():
                         "max_abs_diff_vs_production": float((out.float() - ref.float()).abs().max()),
                         "max_abs": float(ref.float().abs().max())})
         lib().bt_debug_gemm_variant(0)
+    elif args.what == "ppstore":
+        # where does the epilogue's cost come from?  (profiles/r3_pp_ablation.md: removing the epilogue saves 10-17 % although
+        # its instructions are few): dbg 1 = the same stores into an L2-resident dummy region (no HBM write burst), 2 =
+        # non-temporal stores, 0xN00 = start-up stagger of the A-panel groups by N us, variant 34 = no epilogue at all
+        cases = [("production", 0, 0), ("no epilogue", 34, 0), ("stores to L2-resident dummy", 0, 1), ("nt stores", 0, 2),
+                 ("stagger 1 us", 0, 0x100), ("stagger 2 us", 0, 0x200), ("stagger 4 us", 0, 0x400), ("stagger 2 us + nt", 0, 0x202)]
+        for (M, N, K) in ((32768, 6144, 2048), (32768, 2048, 8192), (32768, 8192, 2048), (32768, 2048, 2048), (8192, 6144, 2048),
+                          (4096, 8192, 2048)):
+            x = torch.randn(M, K, device=DEV).bfloat16()
+            w = (torch.randn(N, K, device=DEV) * K ** -0.5).bfloat16()
+            b = torch.randn(N, device=DEV).bfloat16()
+            out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+            for rep in range(3):
+                for (name, v, dbg) in cases:
+                    lib().bt_debug_gemm_variant(v)
+                    lib().bt_debug_pp_dbg(dbg)
+                    ms = timed(lambda: ops.linear(x, w, b, out=out), 10)
+                    res.append({"op": "pp_store_path", "M": M, "N": N, "K": K, "case": name, "us": round(ms * 1e3, 1),
+                                "TF_equiv": round(2.0 * M * N * K / ms / 1e9, 1)})
+            lib().bt_debug_gemm_variant(0)
+            lib().bt_debug_pp_dbg(0x200)         # staggered start is a correct kernel: check it
+            ops.linear(x, w, b, out=out)
+            lib().bt_debug_pp_dbg(0)
+            ref = torch.empty_like(out)
+            ops.linear(x, w, b, out=ref)
+            res.append({"op": "pp_stagger_check", "M": M, "N": N, "K": K, "bit_identical": bool(torch.equal(out, ref))})
+    elif args.what == "ppv2":
+        # second-generation K-loop of the persistent kernel (variant 0 = production) vs the first generation (16), interleaved,
+        # every epilogue mode; bit-identity of the two; timing ablations of the new kernel (100 + ABL bits, plain mode)
+        shapes = ((32768, 6144, 2048), (32768, 2048, 8192), (32768, 8192, 2048), (32768, 2048, 2048), (8192, 6144, 2048),
+                  (8192, 2048, 8192), (4096, 8192, 2048), (4096, 6144, 2048), (4096, 50304, 2048))
+        for (M, N, K) in shapes:
+            x = torch.randn(M, K, device=DEV).bfloat16()
+            w = (torch.randn(N, K, device=DEV) * K ** -0.5).bfloat16()
+            b = torch.randn(N, device=DEV).bfloat16()
+            r = torch.randn(M, N, device=DEV).bfloat16()
+            out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+            modes = (("plain", {}), ("gelu", {"act": "gelu"}), ("res", {"residual": r})) if N != 50304 else (("plain", {}),)
+            for name, kw in modes:
+                rec = {"op": "pp_v1_vs_v2", "M": M, "N": N, "K": K, "mode": name}
+                outs = {}
+                for rep in range(3):
+                    for v in (16, 12):     # 12 = force the persistent kernel family (production K-loop), 16 = first generation
+                        lib().bt_debug_gemm_variant(v)
+                        ms = timed(lambda: ops.linear(x, w, b, kw.get("residual"), act=kw.get("act", "none"), out=out), 10)
+                        rec.setdefault("v1_us" if v == 16 else "v2_us", []).append(round(ms * 1e3, 1))
+                        outs[v] = out.clone()
+                rec["bit_identical"] = bool(torch.equal(outs[16], outs[12]))
+                rec["v2_TF"] = round(2.0 * M * N * K / min(rec["v2_us"]) / 1e6, 1)
+                rec["v1_TF"] = round(2.0 * M * N * K / min(rec["v1_us"]) / 1e6, 1)
+                res.append(rec)
+            if (M, N, K) in shapes[:3]:
+                for v, what in ((101, "no DMA"), (102, "no ds_reads"), (104, "no epilogue"), (107, "MFMA + barriers only"),
+                                (122, "DMA ring only")):
+                    lib().bt_debug_gemm_variant(v)
+                    ms = min(timed(lambda: ops.linear(x, w, b, out=out), 10) for _ in range(2))
+                    res.append({"op": "pp2_ablation", "M": M, "N": N, "K": K, "what": what, "us": round(ms * 1e3, 1),
+                                "TF_equiv": round(2.0 * M * N * K / ms / 1e9, 1)})
+            lib().bt_debug_gemm_variant(0)
     elif args.what == "abl":
         for (M, N, K) in ((32768, 6144, 2048), (32768, 2048, 8192)):
             for v in (0, 3, 20, 21, 8, 0, 3, 20, 21, 8):   # production / 4-phase one-tile kernel: full, no MFMA, DMA only, MFMA+barriers only
