@@ -53,7 +53,7 @@ class bt_engine_desc(Structure):
                 ("ws_tok", c_void_p), ("ws_tok_bytes", c_int64), ("ws_step", c_void_p), ("ws_step_bytes", c_int64),
                 ("exp_scratch", c_void_p), ("exp_scratch_bytes", c_int64),
                 ("n_split", c_int32), ("top_k", c_int32), ("split_ws", c_void_p), ("split_ws_bytes", c_int64),
-                ("temperature", c_float), ("reserved0", c_int32), ("sample_row0", c_int64), ("seed", c_uint64), ("sample_step", c_void_p),
+                ("temperature", c_float), ("skip_logits", c_int32), ("sample_row0", c_int64), ("seed", c_uint64), ("sample_step", c_void_p),
                 ("config_pad", c_int64), ("gen_eos", c_int64), ("gen_pad", c_int64)]
 
 
@@ -93,6 +93,9 @@ _SIGS = {
                              c_int64, c_void_p]),
     "bt_attention_split_count": (c_int32, [c_int32, c_int64, c_int32]),
     "bt_argmax": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "bt_logits_argmax_workspace_bytes": (c_int64, [c_int64, c_int64]),
+    "bt_logits_argmax": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int32,
+                                 c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "bt_topk_sample": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_float, c_int32, c_uint64, c_void_p, c_int64,
                                c_void_p, c_int64, c_void_p]),
     "bt_decoder_forward": (c_int, [c_int, POINTER(bt_decoder_dims), POINTER(bt_decoder_weights), c_int64, c_int32,
@@ -122,7 +125,6 @@ _DEBUG_SIGS = {
     "bt_debug_force_generic_gemm": (None, [c_int]),
     "bt_debug_gemm_variant": (None, [c_int]),
     "bt_debug_gemm_max_wg": (None, [c_int]),
-    "bt_debug_pp_dbg": (None, [c_int]),
     "bt_debug_skinny_rows": (None, [c_int]),
     "bt_debug_small_stages": (None, [c_int]),
     "bt_debug_mid_rows": (None, [c_int]),

@@ -313,14 +313,17 @@ extern "C" int bt_token_block_enqueue(const bt_engine_desc* e, int32_t t_begin, 
             BT_TRY(bt_decoder_forward(e->dtype, &e->td_dims, &e->td_w, B, 1, e->x_tok, &a, 0, e->hid, e->ws_tok,
                                       e->ws_tok_bytes, stream));
         }
-        BT_TRY(bt_linear(e->dtype, B, e->vocab, Htd, e->hid, Htd, e->embed_out, nullptr, nullptr, 0, e->logits, e->vocab,
-                         BT_ACT_NONE, stream));
         if (e->do_sample) {
+            BT_TRY(bt_linear(e->dtype, B, e->vocab, Htd, e->hid, Htd, e->embed_out, nullptr, nullptr, 0, e->logits, e->vocab,
+                             BT_ACT_NONE, stream));
             BT_TRY(bt_topk_sample(e->dtype, B, e->vocab, e->logits, e->vocab, e->temperature, e->top_k, e->seed,
                                   e->sample_step, e->sample_row0, e->raw + t, e->L, stream));
             BT_TRY(bt_bump(e->sample_step, 1, stream));
         } else {
-            BT_TRY(bt_argmax(e->dtype, B, e->vocab, e->logits, e->vocab, e->raw + t, e->L, stream));
+            // logits GEMM + argmax; the token decoder's workspace is idle between its forward and the next step: it holds the
+            // (value, column) pairs of the fused reduction
+            BT_TRY(bt_logits_argmax(e->dtype, B, e->vocab, Htd, e->hid, Htd, e->embed_out, e->logits, e->vocab,
+                                    e->skip_logits ? 0 : 1, e->raw + t, e->L, e->ws_tok, e->ws_tok_bytes, stream));
         }
     }
     if (finish_count > 0) {

@@ -96,10 +96,8 @@ struct EpiArgs {
     int64_t ldo;
     int M, N, act;
     QkvEpi q;
-#ifdef BT_DEBUG_HOOKS
-    int dbg;   // persistent-kernel experiments (bt_debug_pp_dbg): bit 0 = stores go to an L2-resident dummy region (WRONG results,
-               // timing only), bit 1 = non-temporal stores, bits 8.. = start-up stagger (units of ~1 us per stagger group)
-#endif
+    uint2* amax;      // PP_ARGMAX: per (row, 64-column slab) {bits of the largest bf16-rounded value, its column}; [M][amax_ld]
+    int amax_ld;
 };
 
 __device__ inline void epi_store4(const EpiArgs& e, int m, int n, float (&v)[4], bool vec_ok) {
@@ -1290,9 +1288,25 @@ __device__ inline void stage_half_at(const bf16* __restrict__ A, int64_t lda, co
 // Per-wave epilogue of the persistent kernel: the wave's 128 rows x 64 columns (8 fragments of 16 rows), bias already in
 // the accumulators.  Sweep A issues EVERY load the epilogue needs (RoPE table rows / residual chunks) before sweep B
 // issues the first store: with in-order vmcnt retirement a load waited for after a store would wait for that store too.
-enum { PP_PLAIN = 0, PP_GELU = 1, PP_RES = 2, PP_QKV = 3 };   // epilogue flavour (bias is orthogonal: accumulator init)
+enum { PP_PLAIN = 0, PP_GELU = 1, PP_RES = 2, PP_QKV = 3, PP_ARGMAX = 4 };   // epilogue flavour (bias is orthogonal: accumulator init)
+// PP_ARGMAX (bt_logits_argmax, round 3): the logits GEMM of a greedy token step.  Every wave reduces its 128 x 64 block to one
+// (value, column) pair per row -- over the bf16-ROUNDED values, lowest column on ties, exactly what bt_argmax sees in a
+// materialised logits row -- and writes 8 bytes per row; the logits tile itself is only stored when e.out != nullptr.  A
+// [4096, 50304] bf16 logits matrix is 412 MB written and read back per token step; the partials are 26 MB.
 
-template <int MODE>
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+// raw (untyped, unbounded) buffer descriptor whose base is a wave-uniform pointer: offsets are 32-bit, so the base is the
+// origin of the tile being written, not of the tensor
+__device__ inline __amdgpu_buffer_rsrc_t tile_rsrc(const char* base_uniform) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base_uniform);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
+
+// EABL (debug timing ablations, wrong results): 1 = no global stores, 2 = no LDS transposes (the packed registers are stored as is)
+template <int MODE, int EABL = 0>
 __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x4_t (&acc)[8][4], int cm0, int n_wave, int wm,
                                    int lane) {
     const int M = e.M, N = e.N;
@@ -1348,35 +1362,40 @@ __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x
                 }
             }
         }
-    } else if (MODE == PP_RES) {   // residual joins the fp32 accumulators (accumulator layout: 4 consecutive columns of one row)
+    }
+    // PP_RES: the residual tile is read in the STORE layout (rows of 128 B: 16 bytes per lane, 8 lanes per row, the same bytes the
+    // lane writes later -- an in-place x += ... is safe) and joins the bf16-rounded result after the transposition, exactly like
+    // the small-tile kernels' LDS-staged epilogue (store_tile_from_lds).  Round 3: the accumulator-layout version (32 gathers of
+    // 8 bytes per lane in 32-byte row segments) cost ~7 us per tile on top of the plain epilogue; these are 16 full-line loads, all in
+    // flight before the first store (the K-loop's fragment registers are dead here).
+    uint4 rres[8][2];
+    if (MODE == PP_RES) {
+        const __amdgpu_buffer_rsrc_t res_rsrc = tile_rsrc(reinterpret_cast<const char*>(e.res) + ((int64_t)cm0 * e.ldr + n_wave) * 2);
+        const uint32_t res_voff = ((uint32_t)(lane >> 3) * (uint32_t)e.ldr + (uint32_t)(lane & 7) * 8u) * 2u;
 #pragma unroll
-        for (int hb = 0; hb < 2; ++hb) {
-            uint2 rv[4][4];
+        for (int ai = 0; ai < 8; ++ai) {
+            const int row_l = (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = cm0 + hb * 128 + wm * 64 + i * 16 + (lane & 15);
-#pragma unroll
-                for (int jf = 0; jf < 4; ++jf) {
-                    const int n = n_wave + jf * 16 + (lane >> 4) * 4;
-                    rv[i][jf] = (m < M && n < N) ? *reinterpret_cast<const uint2*>(e.res + (int64_t)m * e.ldr + n)
-                                                 : uint2{0, 0};
-                }
+            for (int h = 0; h < 2; ++h) {
+                const int m = cm0 + row_l + h * 8 + (lane >> 3);
+                const int n = n_wave + (lane & 7) * 8;
+                u32x4_t r4 = u32x4_t{0, 0, 0, 0};
+                if (m < M && n < N)
+                    r4 = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, res_voff, (uint32_t)(row_l + h * 8) * (uint32_t)e.ldr * 2u, 0);
+                rres[ai][h] = uint4{r4.x, r4.y, r4.z, r4.w};
             }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int jf = 0; jf < 4; ++jf) {
-                    acc[hb * 4 + i][jf][0] += __uint_as_float(rv[i][jf].x << 16);
-                    acc[hb * 4 + i][jf][1] += __uint_as_float(rv[i][jf].x & 0xffff0000u);
-                    acc[hb * 4 + i][jf][2] += __uint_as_float(rv[i][jf].y << 16);
-                    acc[hb * 4 + i][jf][3] += __uint_as_float(rv[i][jf].y & 0xffff0000u);
-                }
         }
     }
     asm volatile("" ::: "memory");
     // ---- sweep B ----
     const uint32_t patch_w = lds_addr(stage) + (lane & 15) * EPI_PITCH + (lane >> 4) * 8;
     const uint32_t patch_r = lds_addr(stage) + (lane >> 3) * EPI_PITCH + (lane & 7) * 16;
+    // plain output rows: buffer stores addressed as (tile-origin descriptor) + (uniform row offset in an SGPR) + (ONE lane offset
+    // VGPR).  A vector-memory instruction costs the CU's memory pipe ~16 cycles per VGPR operand it reads (round-3 store
+    // ablations: a tile's 128 stores of 4 data + 2 address registers drain at ~10 B/clk and stall the load ring behind them);
+    // the descriptor form reads 4 + 1.
+    const __amdgpu_buffer_rsrc_t out_rsrc = tile_rsrc(reinterpret_cast<const char*>(e.out) + ((int64_t)cm0 * e.ldo + n_wave) * 2);
+    const uint32_t out_voff = ((uint32_t)(lane >> 3) * (uint32_t)e.ldo + (uint32_t)(lane & 7) * 8u) * 2u;
 #pragma unroll
     for (int ai = 0; ai < 8; ++ai) {
         const int row_l = (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16;
@@ -1388,26 +1407,66 @@ __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x
             o[jf].x = pack_bf16x2(v[0], v[1]);
             o[jf].y = pack_bf16x2(v[2], v[3]);
         }
+        if (MODE == PP_ARGMAX) {
+            // the lane's 16 columns of output row (lane & 15) in increasing column order, then the 4 lanes that share the row
+            const int mrow = cm0 + row_l + (lane & 15);
+            float best = -INFINITY;
+            int bidx = 0x7fffffff;
+#pragma unroll
+            for (int jf = 0; jf < 4; ++jf) {
+                const int n = n_wave + jf * 16 + (lane >> 4) * 4;
+                const float v[4] = {__uint_as_float(o[jf].x << 16), __uint_as_float(o[jf].x & 0xffff0000u),
+                                    __uint_as_float(o[jf].y << 16), __uint_as_float(o[jf].y & 0xffff0000u)};
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < N && (v[r] > best || bidx == 0x7fffffff)) { best = v[r]; bidx = n + r; }
+            }
+#pragma unroll
+            for (int off = 16; off <= 32; off <<= 1) {
+                const float ov = __shfl_xor(best, off, 64);
+                const int oi = __shfl_xor(bidx, off, 64);
+                if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+            }
+            if ((lane >> 4) == 0 && mrow < M && n_wave < N)
+                e.amax[(int64_t)mrow * e.amax_ld + (n_wave >> 6)] = uint2{__float_as_uint(best), (uint32_t)bidx};
+            if (e.out == nullptr) continue;
+        }
         // registers -> wave-private patch -> registers, transposed to 16 B per lane along rows (inline asm: the compiler
         // must not see LDS traffic here, it would fence it against the in-flight LDS-DMA with vmcnt(0))
         uint4 v0, v1;
-        asm volatile("ds_write_b64 %2, %4\n\tds_write_b64 %2, %5 offset:32\n\t"
-                     "ds_write_b64 %2, %6 offset:64\n\tds_write_b64 %2, %7 offset:96\n\t"
-                     "s_waitcnt lgkmcnt(0)\n\t"
-                     "ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:%8\n\t"
-                     "s_waitcnt lgkmcnt(0)"
-                     : "=&v"(v0), "=&v"(v1)
-                     : "v"(patch_w), "v"(patch_r), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "n"(8 * EPI_PITCH)
-                     : "memory");
+        if (EABL & 2) {
+            v0 = uint4{o[0].x, o[0].y, o[1].x, o[1].y};
+            v1 = uint4{o[2].x, o[2].y, o[3].x, o[3].y};
+        } else {
+            asm volatile("ds_write_b64 %2, %4\n\tds_write_b64 %2, %5 offset:32\n\t"
+                         "ds_write_b64 %2, %6 offset:64\n\tds_write_b64 %2, %7 offset:96\n\t"
+                         "s_waitcnt lgkmcnt(0)\n\t"
+                         "ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:%8\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(v0), "=&v"(v1)
+                         : "v"(patch_w), "v"(patch_r), "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "n"(8 * EPI_PITCH)
+                         : "memory");
+        }
+        if ((EABL & 1) || ((EABL & 8) && ai > 0)) {   // EABL 8: only the first fragment's stores (2 per wave and tile)
+            asm volatile("" ::"v"(v0.x), "v"(v0.y), "v"(v0.z), "v"(v0.w), "v"(v1.x), "v"(v1.y), "v"(v1.z), "v"(v1.w));
+            continue;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+            if ((EABL & 4) && h == 1) {                // EABL 4: half of the stores (8 per wave and tile)
+                asm volatile("" ::"v"(v1.x), "v"(v1.y), "v"(v1.z), "v"(v1.w));
+                continue;
+            }
             uint4 v = h ? v1 : v0;
+            if (MODE == PP_RES) v = add_bf16x8(v, rres[ai][h]);
             const int m = cm0 + row_l + h * 8 + (lane >> 3);
             const int n = n_wave + (lane & 7) * 8;
             if (m < M && n < N) {
                 bf16* dst;
                 if (!qkv) {
-                    dst = e.out + (int64_t)m * e.ldo + n;
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{v.x, v.y, v.z, v.w}, out_rsrc, out_voff,
+                                                           (uint32_t)(row_l + h * 8) * (uint32_t)e.ldo * 2u, 0);
+                    continue;
                 } else {
                     const int D = e.q.head_dim;
                     const int head = n / (3 * D);
@@ -1420,15 +1479,6 @@ __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x
                     dst = part == 0 ? e.out + (int64_t)m * e.ldo + n
                                     : cache + ((b * e.q.heads + head) * e.q.n_max + pos0 + t) * D + el;
                 }
-#ifdef BT_DEBUG_HOOKS
-                if (e.dbg & 1)   // timing experiment: every workgroup rewrites one of 32 tiles (4 MiB, stays dirty in L2)
-                    dst = e.out + (int64_t)((m - cm0) + (blockIdx.x & 31) * 256) * e.ldo + ((n - n_wave) + (n_wave & 255));
-                if (e.dbg & 2) {
-                    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-                    __builtin_nontemporal_store(u32x4_t{v.x, v.y, v.z, v.w}, reinterpret_cast<u32x4_t*>(dst));
-                    continue;
-                }
-#endif
                 *reinterpret_cast<uint4*>(dst) = v;
             }
         }
@@ -1506,10 +1556,10 @@ struct Mma16 {
                 for (int jf = 0; jf < 4; ++jf) acc[i][jf] = f32x4_t{0.f, 0.f, 0.f, 0.f};
         }
     }
-    template <int MODE>
+    template <int MODE, int EABL = 0>
     __device__ static inline void epilogue(const EpiArgs& e, int pos0, char* stage, Acc (&acc)[8][4], int cm0, int n_wave,
                                            int wm, int lane) {
-        pp_epilogue<MODE>(e, pos0, stage, acc, cm0, n_wave, wm, lane);
+        pp_epilogue<MODE, EABL>(e, pos0, stage, acc, cm0, n_wave, wm, lane);
     }
 };
 
@@ -1742,11 +1792,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
     const int wrow = (wn & 1) * 64;              // its 64-row slab inside the half == 64 contiguous output columns
     const int wcol = wh * 128 + wrow;            // column offset of the wave's output inside the tile
     const bool grp1 = wave >= 4;
-#ifdef BT_DEBUG_HOOKS
-    // start-up stagger experiment: the workgroups of an XCD that share an A panel (local id & 3) start together, the four groups
-    // ~ (dbg >> 8) us apart, so the per-tile store bursts of the groups do not coincide
-    for (int i = ((blockIdx.x >> 3) & 3) * (ep.dbg >> 8); i > 0; --i) __builtin_amdgcn_s_sleep(32);
-#endif
     char* stage = smem + PP_EPI_OFF + wave * P::PATCH_BYTES;
     const uint32_t lane_slot = (uint32_t)(((lane & 7) ^ ((lane >> 3) & 7)) * 16);
     const uint32_t voff_a = (uint32_t)(lane >> 3) * (uint32_t)(lda * 2) + lane_slot;
@@ -1913,8 +1958,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
 //   * a full tile's half-tiles are addressed as (SGPR base of the tile's half) + (per-lane 32-bit offset that advances by
 //     128 B per K-tile): one s_add into M0 + the DMA per instruction, four v_add per K-tile, no multiplies; tiles cut by the
 //     matrix edge keep the per-lane clamped path (stage_half_at).
+//   * tile boundary: a tile's 128 output stores (16 per wave) occupy the CU's vector-memory pipe for ~5 us (~16 cycles per VGPR
+//     operand of a VMEM instruction; profiles/r3_pp_epilogue_parts.md: the cost scales with the NUMBER of stores, whatever their
+//     destination), and everything issued behind them queues.  So the two half-tiles the next tile's first phase would issue
+//     (W1, A1 of its K-tile 1) go out BEFORE the epilogue's stores, behind one extra barrier per tile (their slots were last read
+//     in the tile's final phase): the ring then holds two full K-tiles = four phases of MFMA work that do not depend on anything
+//     queued behind the stores, and the store-count waits (+ PP_STORES) extend over K-tiles 0 and 1.
 // Bit-identical results to the first-generation kernel (same operand order, same accumulation order).
-constexpr int PP2_WAIT_P0 = 6, PP2_WAIT_P1 = 8;   // steady-state vmcnt immediates (+ PP_STORES for K-tile 0 behind a full tile)
+constexpr int PP2_WAIT_P0 = 6, PP2_WAIT_P1 = 8;   // steady-state vmcnt immediates (+ PP_STORES in K-tiles 0 / 1 behind a full tile)
 
 template <int OFF>
 __device__ inline void glds16_sbase_off(const char* base_uniform, uint32_t voff, uint32_t lds_base_uniform) {
@@ -1925,6 +1976,9 @@ __device__ inline void glds16_sbase_off(const char* base_uniform, uint32_t voff,
                  : "memory", "scc");
 }
 
+// (Measured and rejected, round 3, profiles/r3_ppab_dmac.jsonl: issuing the second half-tile of each phase in the middle of the
+//  phase's MFMA cluster -- shorter load segment, two DMA issues among the MFMAs -- is 3-8 % SLOWER on every shape: the MFMA
+//  cluster, not the load segment, is the critical resource of a phase.)
 template <int MODE, int ABL = 0>
 __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* __restrict__ A, int64_t lda,
                                                                   const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
@@ -1973,13 +2027,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
         voff_w = voff_w_0;
     };
     if (lvalid) enter_tile();
-    // half-tiles `k0` and `k1` (consumption order A0, W0, W1, A1) of the cursor's K-tile
-    auto issue2 = [&](auto k0c, auto k1c, bool check_valid) {
+    // half-tile `kind` (consumption order A0, W0, W1, A1) of the cursor's K-tile
+    auto issue1 = [&](auto kc, bool check_valid) {
         if ((ABL & 1) && lx >= 2) return;
         if (check_valid && !lvalid) return;
-        const uint32_t ring = ring_lds + (uint32_t)(lx & 1) * (4u * HALF_BYTES);
-        auto one = [&](auto kc) {
-            constexpr int kind = decltype(kc)::value;
+        constexpr int kind = decltype(kc)::value;
+        if (__builtin_expect(lfull, 1)) {
+            const uint32_t ring = ring_lds + (uint32_t)(lx & 1) * (4u * HALF_BYTES);
             constexpr bool is_a = (kind == 0) || (kind == 3);
             constexpr int half = (kind >= 2) ? 1 : 0;
             constexpr int off = ((is_a ? 0 : 2) + half) * HALF_BYTES;
@@ -1987,14 +2041,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
             const uint32_t v0 = is_a ? voff_a : voff_w;
             glds16_sbase_off<off>(base, v0, ring);
             glds16_sbase_off<off + 1024>(base, v0 + (is_a ? row8_a : row8_w), ring);
-        };
-        if (__builtin_expect(lfull, 1)) {
-            one(k0c);
-            one(k1c);
         } else {   // tile cut by the matrix edge: per-lane clamped rows
-            stage_half_at(A, lda, W, ldw, lm0, ln0, M, N, lt * BK, lx & 1, decltype(k0c)::value, smem, wave, lane, voff_a_0, voff_w_0);
-            stage_half_at(A, lda, W, ldw, lm0, ln0, M, N, lt * BK, lx & 1, decltype(k1c)::value, smem, wave, lane, voff_a_0, voff_w_0);
+            stage_half_at(A, lda, W, ldw, lm0, ln0, M, N, lt * BK, lx & 1, kind, smem, wave, lane, voff_a_0, voff_w_0);
         }
+    };
+    auto issue2 = [&](auto k0c, auto k1c, bool check_valid) {
+        issue1(k0c, check_valid);
+        issue1(k1c, check_valid);
     };
     auto issue_bias = [&]() {
         if (wave == 0 && ep.bias && lvalid) {
@@ -2038,13 +2091,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
     }
     int g = 0;
     int cm0 = 0, cn0 = 0;
-    bool prev_full = false;
-    // one phase.  PM: 0 = K-tile 0 of a tile, 1 = steady state, 2 = generic (stream tail)
+    bool prev_full = false;   // the previous tile's epilogue issued PP_STORES stores per wave (a full tile) ...
+    bool pre_issued = false;  // ... behind the half-tiles phase (0, 0) of this tile would have issued
+    // one phase.  PM: 0 = K-tiles 0 and 1 of a tile (store-count waits behind a full tile), 1 = steady state, 2 = generic (stream tail)
     auto phase = [&](auto pc, auto pmc, int t, int j) {
         constexpr int p = decltype(pc)::value, PM = decltype(pmc)::value;
         if (!grp1) {
             if constexpr (PM == 2) {
-                wait_for_phase_pp(g, total, prev_full && t == 0);
+                wait_for_phase_pp(g, total, false);
             } else if constexpr (PM == 0) {
                 if (prev_full) wait_vmcnt_pp<(p ? PP2_WAIT_P1 : PP2_WAIT_P0) + PP_STORES>();
                 else wait_vmcnt<(p ? PP2_WAIT_P1 : PP2_WAIT_P0)>();
@@ -2056,8 +2110,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
         const char* buf = smem + (g & 2) * 2 * HALF_BYTES;
         const bool do_reads = !(ABL & 2) || g == 0;
         if constexpr (p == 0) {
-            if constexpr (PM == 0)
-                P::init(acc, ep.bias != nullptr, false, lds_addr(smem + PP_BIAS_OFF + (j & 1) * 1024), wcol, lane);
+            if constexpr (PM == 0 && !(ABL & 128)) {
+                if (t == 0) P::init(acc, ep.bias != nullptr, false, lds_addr(smem + PP_BIAS_OFF + (j & 1) * 1024), wcol, lane);
+            }
             if (do_reads) {
 #pragma unroll
                 for (int ks = 0; ks < P::KS; ++ks) {
@@ -2067,8 +2122,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
                     for (int i = 0; i < P::MI; ++i) af[i][ks] = P::read_a(buf, wm, i, ks, lane);
                 }
             }
-            issue2(I2{}, I3{}, PM == 2);
-            advance();
+            if (PM == 0 && t == 0 && pre_issued) {
+                pre_issued = false;          // issued at the tile boundary, ahead of the previous tile's stores
+            } else {
+                issue2(I2{}, I3{}, PM == 2);
+                advance();
+            }
         } else {
             if (!(ABL & 2)) {
 #pragma unroll
@@ -2081,10 +2140,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
         }
         if (grp1) {   // group 1 waits for the data of phase g + 1 before the barrier that opens it for group 0
             if constexpr (PM == 2) {
-                wait_for_phase_pp(g + 1, total, prev_full && t == 0 && p == 0);
-            } else if constexpr (PM == 0 && p == 0) {
-                if (prev_full) wait_vmcnt_pp<PP2_WAIT_P1 + PP_STORES>();
-                else wait_vmcnt<PP2_WAIT_P1>();
+                wait_for_phase_pp(g + 1, total, false);
+            } else if constexpr (PM == 0) {
+                // phase g + 1 is (0, 1), (1, 0) or (1, 1): its half-tiles are older than the previous tile's stores; (2, 0) is not
+                if (prev_full && !(t == 1 && p == 1)) wait_vmcnt_pp<(p == 0 ? PP2_WAIT_P1 : PP2_WAIT_P0) + PP_STORES>();
+                else wait_vmcnt<(p == 0 ? PP2_WAIT_P1 : PP2_WAIT_P0)>();
             } else {
                 wait_vmcnt<(p == 0 ? PP2_WAIT_P1 : PP2_WAIT_P0)>();
             }
@@ -2119,7 +2179,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
         const int t_gen = (j == nt - 1) ? nk - 2 : nk;
         phase(I0{}, I0{}, 0, j);
         phase(I1{}, I0{}, 0, j);
-        int t = 1;
+        phase(I0{}, I0{}, 1, j);
+        phase(I1{}, I0{}, 1, j);
+        int t = 2;
         for (; t < t_gen; ++t) {
             phase(I0{}, I1{}, t, j);
             phase(I1{}, I1{}, t, j);
@@ -2135,10 +2197,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
                 for (int nb = 0; nb < P::NB; ++nb) asm volatile("" ::"v"(acc[i][nb][0]));
             continue;
         }
+        prev_full = (cm0 + BM2 <= M) && (cn0 + BN2 <= N) && !(ABL & (32 | 256 | 512));
+        if (MODE == PP_ARGMAX && ep.out == nullptr) prev_full = false;   // 8 partial stores per wave instead of >= PP_STORES
+        if (j + 1 < nt) {
+            // tile boundary: W1 / A1 of the next tile's K-tile 1 go out ahead of this tile's stores.  Their slots were last read in
+            // the final phase: one barrier after those reads were issued, the margin every other refill of the ring has
+            // (group 0's barrier here pairs with group 1's second barrier of the final phase and vice versa).
+            cbarrier();
+            issue2(I2{}, I3{}, false);
+            advance();
+            pre_issued = true;
+        } else {
+            prev_full = false;
+        }
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
-        P::template epilogue<MODE>(ep, pos0, stage, acc, cm0, cn0 + wcol, wm, lane_e);
-        prev_full = (cm0 + BM2 <= M) && (cn0 + BN2 <= N);
+        P::template epilogue<MODE, (ABL >> 5) & 3 | ((ABL >> 6) & 12)>(ep, pos0, stage, acc, cm0, cn0 + wcol, wm, lane_e);
     }
     if (!grp1) cbarrier();
 }
@@ -2780,9 +2854,6 @@ BT_KNOB int g_mid_fuse = 1;
 BT_KNOB bool g_mid_rows = true;   // 17..256-row stacks take the slab + fused-reduce path (false: A/B against the unfused launches)
 BT_KNOB bool g_few_dual = true;   // <= 4 rows: QKV and h->4h GEMVs of a layer in one launch (false: two launches, A/B)
 BT_KNOB int g_small_stages = 0;   // LDS ring depth of the 128^2 / 128x64 / 64x64 kernels: 0 = per-tile default, 2..4 forced (A/B)
-#ifdef BT_DEBUG_HOOKS
-static int g_pp_dbg = 0;          // EpiArgs::dbg of the persistent kernel
-#endif
 BT_KNOB int g_gemm_variant = 0;   // 0 auto; 1 force 128^2; 2/3 256^2 four-phase ring (plain/staggered); 4-8 timing ablations; 9/10 256^2
 // two-phase ring, one tile per workgroup (staggered/plain); 14 persistent on 32x32x16 MFMA; default: persistent two-phase ring.
 
@@ -2790,10 +2861,13 @@ BT_KNOB int g_gemm_variant = 0;   // 0 auto; 1 force 128^2; 2/3 256^2 four-phase
 
 using namespace bt;
 
+// amax (bt_logits_argmax): when the persistent kernel takes the problem, run its PP_ARGMAX epilogue (per-slab argmax partials
+// into amax[M][amax_ld]; the logits tile is stored only if store_out) and report it through *amax_done
 static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* W,
                        const void* bias, const void* residual, int64_t ldr, void* out, int64_t ldo, int act,
                        const QkvEpi* qkv, bool* fused_out, bt_stream stream, void* scratch = nullptr,
-                       int64_t scratch_bytes = 0, const Seg2* seg2 = nullptr) {
+                       int64_t scratch_bytes = 0, const Seg2* seg2 = nullptr, uint2* amax = nullptr, int amax_ld = 0,
+                       bool store_out = true, bool* amax_done = nullptr) {
     // seg2 (bt_linear2, > 64 rows): a second (x2, W2, bias2) operand pair accumulated into the same output tiles; only
     // the persistent 256^2 kernel and the non-split small-tile family take it -> BT_ERR_UNSUPPORTED otherwise
     BT_CHECK_ARG(dtype == BT_F32 || dtype == BT_BF16, "bt_linear: bad dtype %d", dtype);
@@ -2820,9 +2894,6 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
         ep.M = (int)M;
         ep.N = (int)N;
         ep.act = act;
-#ifdef BT_DEBUG_HOOKS
-        ep.dbg = g_pp_dbg;
-#endif
         ep.q = QkvEpi{};
         Seg2 s2{};
         if (seg2) {
@@ -2851,7 +2922,10 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                            (!residual || (ldr % 8 == 0 && aligned16(residual))) && (!bias || aligned16(bias));
         const bool use256 = mfma_ok && g_gemm_variant != 1 && (N % 4 == 0) &&
                             (g_gemm_variant >= 2 || (tiles256 >= 192 && (tiles256 % 256 == 0 || tiles256 >= 1024 ||
-                                                                         (tiles256 % 256) >= 96))) &&
+                                                                         (tiles256 % 256) >= 96) &&
+                                                     // ... and the 256 x 256 tiles must be mostly real work (M = 64 rows against the
+                                                     // vocabulary is 197 tiles too, three quarters of them padding)
+                                                     4 * M * N >= 3 * tiles256 * (int64_t)(BM2 * BN2))) &&
                             (!seg2 || (pp_ok && (g_gemm_variant == 0 || g_gemm_variant == 14)));
         if (use256) {
             ProfScope ps(BT_PROF_LINEAR_MFMA, s);
@@ -2928,13 +3002,19 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
     hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, ABL_>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A, lda,  \
                        (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n)
 #define BT_PP2_ABL_AB(MODE_)                                                                                        \
-    if (g_gemm_variant >= 101 && g_gemm_variant <= 131) {                                                           \
+    if (g_gemm_variant >= 101 && g_gemm_variant <= 700) {                                                           \
         switch (g_gemm_variant - 100) {                                                                             \
             case 1: BT_PP2_ABL(MODE_, 1); break;    /* no DMA */                                                    \
             case 2: BT_PP2_ABL(MODE_, 2); break;    /* no ds_reads */                                               \
             case 4: BT_PP2_ABL(MODE_, 4); break;    /* no epilogue */                                               \
             case 7: BT_PP2_ABL(MODE_, 7); break;    /* MFMA + barriers only */                                      \
             case 22: BT_PP2_ABL(MODE_, 22); break;  /* DMA ring only */                                             \
+            case 32: BT_PP2_ABL(MODE_, 32); break;  /* epilogue without global stores */                            \
+            case 64: BT_PP2_ABL(MODE_, 64); break;  /* epilogue without LDS transposes */                           \
+            case 96: BT_PP2_ABL(MODE_, 96); break;  /* epilogue = cvt only */                                       \
+            case 128: BT_PP2_ABL(MODE_, 128); break; /* no accumulator init from the bias row */                    \
+            case 256: BT_PP2_ABL(MODE_, 256); break; /* half of the stores */                                       \
+            case 512: BT_PP2_ABL(MODE_, 512); break; /* two stores per wave and tile */                             \
             default: BT_PP2_ABL(MODE_, 0); break;                                                                   \
         }                                                                                                           \
     } else
@@ -2958,6 +3038,13 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                         else if (ep.q.enabled) BT_LAUNCH_PP(PP_QKV);
                         else if (act == BT_ACT_GELU && !residual) BT_LAUNCH_PP(PP_GELU);
                         else if (act == BT_ACT_NONE && residual) BT_LAUNCH_PP(PP_RES);
+                        else if (act == BT_ACT_NONE && amax && g_gemm_variant == 0) {
+                            ep.amax = amax;
+                            ep.amax_ld = amax_ld;
+                            if (!store_out) ep.out = nullptr;
+                            BT_LAUNCH_PP(PP_ARGMAX);
+                            if (amax_done) *amax_done = true;
+                        }
                         else if (act == BT_ACT_NONE) {   // (timing ablations are instantiated for the plain mode only)
                             BT_PP_ABL_AB(PP_PLAIN)
                             BT_PP2_ABL_AB(PP_PLAIN)
@@ -3079,6 +3166,54 @@ extern "C" int bt_linear(int dtype, int64_t M, int64_t N, int64_t K, const void*
                          const void* bias, const void* residual, int64_t ldr, void* out, int64_t ldo, int act,
                          bt_stream stream) {
     return linear_impl(dtype, M, N, K, A, lda, W, bias, residual, ldr, out, ldo, act, nullptr, nullptr, stream);
+}
+
+// ---- bt_logits_argmax: greedy token step = logits GEMM + argmax --------------------------------------------------------------
+// one wave per row: (value, column) partials of the row's 64-column slabs -> the row's argmax (larger value wins, lowest column on ties)
+__global__ __launch_bounds__(256) void argmax_partials_kernel(const uint2* __restrict__ part, int ld, int slabs, int M,
+                                                             int64_t* __restrict__ ids_out, int64_t ids_stride) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int c = lane; c < slabs; c += 64) {
+        const uint2 p = part[(int64_t)m * ld + c];
+        const float v = __uint_as_float(p.x);
+        const int i = (int)p.y;
+        if (i != 0x7fffffff && (v > best || bidx == 0x7fffffff || (v == best && i < bidx))) { best = v; bidx = i; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best, o, 64);
+        const int oi = __shfl_xor(bidx, o, 64);
+        if (oi != 0x7fffffff && (ov > best || bidx == 0x7fffffff || (ov == best && oi < bidx))) { best = ov; bidx = oi; }
+    }
+    if (lane == 0) ids_out[(int64_t)m * ids_stride] = bidx == 0x7fffffff ? 0 : bidx;
+}
+
+extern "C" int64_t bt_logits_argmax_workspace_bytes(int64_t M, int64_t V) {
+    return M < 0 || V <= 0 ? -1 : M * ceil_div(V, 64) * (int64_t)sizeof(uint2);
+}
+
+extern "C" int bt_logits_argmax(int dtype, int64_t M, int64_t V, int64_t K, const void* hid, int64_t ldh, const void* W,
+                                void* logits, int64_t ld_logits, int32_t store_logits, int64_t* ids_out, int64_t ids_stride,
+                                void* ws, int64_t ws_bytes, bt_stream stream) {
+    BT_CHECK_ARG(logits && ids_out, "bt_logits_argmax: null pointer (the logits buffer is required: shapes the fused kernel does not "
+                                    "take run bt_linear + bt_argmax through it)");
+    bool fused = false;
+    uint2* part = nullptr;
+    if (dtype == BT_BF16 && ws && aligned16(ws) && ws_bytes >= bt_logits_argmax_workspace_bytes(M, V) && V < (1ll << 31))
+        part = reinterpret_cast<uint2*>(ws);
+    BT_TRY(linear_impl(dtype, M, V, K, hid, ldh, W, nullptr, nullptr, 0, logits, ld_logits, BT_ACT_NONE, nullptr, nullptr, stream,
+                       nullptr, 0, nullptr, part, (int)ceil_div(V, 64), store_logits != 0, &fused));
+    if (M == 0) return BT_OK;
+    if (!fused) return bt_argmax(dtype, M, V, logits, ld_logits, ids_out, ids_stride, stream);
+    ProfScope ps(BT_PROF_ARGMAX, (hipStream_t)stream);
+    hipLaunchKernelGGL(argmax_partials_kernel, dim3((unsigned)ceil_div(M, 4)), dim3(256), 0, (hipStream_t)stream, part,
+                       (int)ceil_div(V, 64), (int)ceil_div(V, 64), (int)M, ids_out, ids_stride);
+    BT_LAUNCH_CHECK("bt_logits_argmax reduce launch");
+    return BT_OK;
 }
 
 extern "C" int bt_linear_ws(int dtype, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* W,
@@ -3564,7 +3699,6 @@ int mid_res_ln(hipStream_t s, int64_t M, int64_t N, int64_t K1, const void* x1, 
 extern "C" void bt_debug_force_generic_gemm(int on) { g_force_generic = on != 0; }
 extern "C" void bt_debug_gemm_variant(int v) { g_gemm_variant = v; }
 extern "C" void bt_debug_gemm_max_wg(int n) { g_max_wg = n; }
-extern "C" void bt_debug_pp_dbg(int f) { g_pp_dbg = f; }
 extern "C" void bt_debug_skinny_rows(int n) { g_skinny_rows = n; }
 extern "C" void bt_debug_small_stages(int n) { g_small_stages = n; }
 extern "C" void bt_debug_mid_rows(int on) { g_mid_rows = on != 0; }

@@ -255,7 +255,11 @@ class DecodeEngine:
         self.refresh_desc()
         fields = TokenBlockState.set_gen(self.desc, gen, cfg_pad)
         self.desc.mask = self.mask.data_ptr() if use_mask else None
-        key = (use_mask, int(cfg_pad)) + fields
+        # greedy steps hand the row maxima straight from the logits GEMM's epilogue to the argmax reduction; the [B, V] logits
+        # matrix is only written when the caller asked to keep it (BlockTransformer.keep_logits, HF's output_scores analogue)
+        skip = not bool(getattr(self.model, "keep_logits", False))
+        self.desc.skip_logits = int(skip)
+        key = (use_mask, int(cfg_pad), skip) + fields
         if key != self._graph_key:
             self.graphs = {}
             self._graph_key = key

@@ -77,6 +77,10 @@ class BlockTransformer(nn.Module):
         self.use_graphs = True
         self.pipeline = None          # None = off unless BT_PIPELINE=1 (see _want_pipeline)
         self.collect_timers = False  # bench.py: record phase events without the benchmark printout
+        # greedy generate() keeps only token ids, like HF generate with output_scores=False: the logits GEMM reduces each row to
+        # its argmax in its epilogue (bt_logits_argmax) and the [B, vocab] matrix is never written.  True = also materialise the
+        # last step's logits in ``_engine.tok.logits`` (tests, debugging); the tokens are the same bit for bit either way.
+        self.keep_logits = False
         self._engine: Optional[DecodeEngine] = None
         self.last_timers: Optional[_Timers] = None
 

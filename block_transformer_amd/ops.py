@@ -93,6 +93,24 @@ def argmax(logits: torch.Tensor, out: Optional[torch.Tensor] = None):
     return out
 
 
+def logits_argmax(hid: torch.Tensor, weight: torch.Tensor, logits: torch.Tensor, store_logits: bool = True,
+                  out: Optional[torch.Tensor] = None, ws: Optional[torch.Tensor] = None):
+    """ids = argmax(hid @ weight.T) (greedy token step): the logits GEMM with the argmax in its epilogue where the persistent MFMA
+    kernel applies (``logits`` is then only written when ``store_logits``), bt_linear + bt_argmax through ``logits`` otherwise."""
+    h2, ldh = _rows(hid)
+    M, K = h2.shape
+    V = weight.shape[0]
+    l2, ldl = _rows(logits)
+    if out is None:
+        out = torch.empty(M, dtype=torch.int64, device=hid.device)
+    if ws is None:
+        ws = torch.empty(max(int(lib().bt_logits_argmax_workspace_bytes(M, V)), 16), dtype=torch.uint8, device=hid.device)
+    check(lib().bt_logits_argmax(dtype_code(hid.dtype), M, V, K, ptr(h2), ldh, ptr(weight), ptr(l2), ldl, int(bool(store_logits)),
+                                 ptr(out), out.stride(0) if out.dim() else 1, ptr(ws), ws.numel() * ws.element_size(),
+                                 current_stream()), "bt_logits_argmax")
+    return out
+
+
 def topk_sample(logits: torch.Tensor, temperature: float = 1.0, top_k: int = 50, seed: int = 0,
                 step: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, row0: int = 0):
     l2, ld = _rows(logits)

@@ -183,6 +183,19 @@ int bt_attention(int dtype, int mode, int64_t B, int32_t q_len, int32_t heads, i
 int bt_argmax(int dtype, int64_t M, int64_t V, const void* logits, int64_t ld, int64_t* ids_out, int64_t ids_stride,
               bt_stream stream);
 
+/* Greedy token step in one call: logits = hid[M, K] . W[V, K]^T (token_decoder.embed_out, no bias;
+ * model/token_decoder/gpt_neo_x.py:73-74, base.py:349) and ids_out[r*ids_stride] = argmax_j logits[r, j] (HF greedy_search, C11 +
+ * C12).  When the persistent MFMA GEMM takes the shape (bf16, >= ~192 output tiles of 256 x 256) its epilogue reduces every
+ * 64-column slab of a row to one (value, column) pair -- over the bf16-rounded logits, lowest column on ties: the token
+ * bt_linear + bt_argmax produce, bit for bit -- and a second small kernel reduces the pairs; the [M, V] logits matrix is then
+ * written only if store_logits != 0.  `ws`: >= bt_logits_argmax_workspace_bytes(M, V) bytes (16-byte aligned) for the pairs;
+ * without it, or for any other shape / dtype, the call is bt_linear into `logits` followed by bt_argmax.  `logits` must
+ * always be a valid [M, ld_logits] buffer. */
+int64_t bt_logits_argmax_workspace_bytes(int64_t M, int64_t V);
+int bt_logits_argmax(int dtype, int64_t M, int64_t V, int64_t K, const void* hid, int64_t ldh, const void* W, void* logits,
+                     int64_t ld_logits, int32_t store_logits, int64_t* ids_out, int64_t ids_stride, void* ws, int64_t ws_bytes,
+                     bt_stream stream);
+
 /* HF sample(): logits/temperature -> top-k filter -> softmax -> multinomial, one draw per row with a counter-based
  * RNG keyed by (seed, *step_dev, row) -- deterministic for a given key: the kept set is compacted in vocabulary order
  * (every score above the k-th largest + the lowest-index ties, at most 1024 candidates; top_k in (1024, V) is
@@ -252,7 +265,7 @@ typedef struct bt_engine_desc {
     bt_decoder_weights td_w;
     const void* emb_table;   /* embedder.embeddings.weight [vocab, emb_width], emb_width * L == bd_dims.hidden */
     int32_t emb_width;
-    int32_t do_sample;       /* 0 greedy (bt_argmax), 1 temperature + top-k multinomial (bt_topk_sample) */
+    int32_t do_sample;       /* 0 greedy (bt_logits_argmax), 1 temperature + top-k multinomial (bt_topk_sample) */
     const void* exp_w;       /* token_decoder.expansion_layer.weight [E * H_td, H_bd] (Conv1d k=1 == Linear) */
     const void* exp_b;       /* [E * H_td] or NULL */
     const void* embed_in;    /* token_decoder.gpt_neox.embed_in.weight [vocab, H_td] */
@@ -284,7 +297,8 @@ typedef struct bt_engine_desc {
     int32_t top_k;
     void* split_ws; int64_t split_ws_bytes;
     float temperature;
-    int32_t reserved0;
+    int32_t skip_logits;     /* != 0: greedy steps need not materialise `logits` (HF generate's output_scores = False): the logits
+                                GEMM's epilogue hands bt_logits_argmax's pair reduction the row maxima instead */
     int64_t sample_row0;     /* RNG row index of this engine's sequence 0 (shards of one batch; 0 otherwise) */
     uint64_t seed;
     int32_t* sample_step;    /* device counter of sampling draws (RNG stream position); required when do_sample */

@@ -70,6 +70,7 @@ def gpu_model():
             # the golden vectors were generated without EOS handling (benchmark protocol,
             # measure_generation_time.py:90); tests that exercise EOS set it explicitly
             model.token_decoder.generation_config.eos_token_id = None
+            model.keep_logits = True    # tests look at the engine's last logits (default: greedy steps never write them)
             cache[key] = (model, dims, sd, fx)
         return cache[key]
 

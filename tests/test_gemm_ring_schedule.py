@@ -173,11 +173,12 @@ def _pp_analyse(ev):
     return issue_bar, done_bar, reads, bars
 
 
-def pp_model(nk, nt, full, stores, pd=None, has_bias=True):
+def pp_model(nk, nt, full, stores, pd=None, has_bias=True, stream=None):
     pd = PD2 if pd is None else pd
+    stream = stream or _pp_stream
     waves = {(0, True): None, (0, False): None, (1, False): None}   # wave 0 (issues the bias DMA), other group-0 waves, group 1
     for (grp, w0) in waves:
-        waves[(grp, w0)] = _pp_analyse(_pp_stream(grp, w0, nk, nt, full, stores, pd, has_bias))
+        waves[(grp, w0)] = _pp_analyse(stream(grp, w0, nk, nt, full, stores, pd, has_bias))
     nbars = {v[3] for v in waves.values()}
     assert len(nbars) == 1, "barrier counts differ between wave groups"
     last_read = {}
@@ -242,3 +243,112 @@ def test_pp2_constant_waits_equal_the_generic_function(nk, nt):
                         sy1 = prev_full and t == 0 and p == 0
                         assert _pp_wait_imm(g + 1, total, sy1, PD2) == PP2_WAIT[1 - p] + (PP_STORES if sy1 else 0), (nk, nt, j, t, p)
                 g += 1
+
+
+def _pp2_stream(grp, wave0, nk, nt, full, stores, pd, has_bias, bad=None, dmac=False):
+    """Program-order event list of one wave of gemm_bf16_mfma256pp2_kernel: constant waits in K-tiles >= 2, store-count waits in
+    K-tiles 0 / 1 behind a full tile, W1 / A1 of the next tile's K-tile 1 issued at the tile boundary behind one extra barrier and
+    AHEAD of the tile's stores; generic waits in the last two K-tiles of the last tile.  `bad` injects a deliberate error."""
+    assert pd == PD2
+    total = 4 * nk * nt
+    ev = []
+    cursor = [0]                                  # next half-tile load to issue (consumption order)
+
+    def dma2(n=2):                                # the next n half-tiles
+        for _ in range(n):
+            sidx = cursor[0]
+            cursor[0] += 1
+            if sidx < total:
+                if has_bias and wave0 and sidx % (4 * nk) == 0:
+                    ev.append(("vm", ("bias", sidx // (4 * nk))))
+                ev.append(("vm", ("ld", sidx)))
+                ev.append(("vm", ("ld", sidx)))
+
+    for _ in range(3):
+        dma2()                                    # prologue: PD2 = 6 half-tiles
+    if grp == 1:
+        n = _pp_wait_imm(0, total, False, pd)
+        if n is not None:
+            ev.append(("wait", n))
+        ev.append(("bar",))
+    g = 0
+    prev_full = False
+    pre_issued = False
+    for j in range(nt):
+        t_gen = nk - 2 if j == nt - 1 else nk
+        for t in range(nk):
+            pm = 0 if t < 2 else (1 if t < t_gen else 2)
+            for p in (0, 1):
+                if grp == 0:
+                    if pm == 2:
+                        n = _pp_wait_imm(g, total, False, pd)
+                    else:
+                        n = PP2_WAIT[p] + (PP_STORES if (pm == 0 and prev_full) else 0)
+                    if n is not None:
+                        ev.append(("wait", n))
+                ev.append(("bar",))
+                if p == 0 and t == 0 and has_bias:
+                    ev.append(("read", ("bias", j)))
+                x = g >> 1
+                for sidx in ([4 * x, 4 * x + 1, 4 * x + 2] if p == 0 else [4 * x + 3]):
+                    ev.append(("read", ("ld", sidx)))
+                late = False
+                if p == 0 and t == 0 and pre_issued:
+                    pre_issued = False
+                elif dmac:
+                    dma2(1)
+                    late = True
+                else:
+                    dma2()
+                if grp == 1:
+                    if pm == 2:
+                        n = _pp_wait_imm(g + 1, total, False, pd)
+                        if n is not None and dmac:
+                            n = max(n - 2, 0)
+                    else:
+                        sy = pm == 0 and prev_full and not (t == 1 and p == 1)
+                        if bad == "late_store_wait":
+                            sy = pm == 0 and prev_full
+                        n = PP2_WAIT[1 - p] + (PP_STORES if sy else 0) - (2 if dmac else 0)
+                    if n is not None:
+                        ev.append(("wait", n))
+                ev.append(("bar",))
+                if late:
+                    dma2(1)                        # inside the MFMA cluster, after the barrier that opens it
+                g += 1
+        prev_full = full[j]
+        if j + 1 < nt:
+            if bad != "no_boundary_barrier":
+                ev.append(("bar",))
+            dma2()
+            pre_issued = True
+        else:
+            prev_full = False
+        for _ in range(stores[j]):
+            ev.append(("vm", ("st", j)))
+    if grp == 0:
+        ev.append(("bar",))
+    return ev
+
+
+@pytest.mark.parametrize("nk", [4, 5, 8, 32])
+@pytest.mark.parametrize("nt", [1, 2, 3, 5])
+def test_persistent_gemm_v2_schedule(nk, nt):
+    """RAW / WAR of the second-generation kernel's literal program order (both wave groups, the bias-issuing wave): interior
+    tiles, more stores than assumed, edge tiles (no store-count waits), mixed."""
+    pp_model(nk, nt, [True] * nt, [PP_STORES] * nt, stream=_pp2_stream)
+    pp_model(nk, nt, [True] * nt, [2 * PP_STORES] * nt, stream=_pp2_stream)
+    pp_model(nk, nt, [False] * nt, [0] * nt, stream=_pp2_stream)
+    pp_model(nk, nt, [False] * nt, [PP_STORES] * nt, stream=_pp2_stream)
+    pp_model(nk, nt, [j % 2 == 0 for j in range(nt)], [PP_STORES if j % 2 == 0 else 3 for j in range(nt)], has_bias=False,
+             stream=_pp2_stream)
+
+
+def test_persistent_v2_model_detects_errors():
+    import functools
+    with pytest.raises(AssertionError, match="RAW"):      # fewer stores than the waits assume
+        pp_model(8, 3, [True] * 3, [PP_STORES - 8] * 3, stream=_pp2_stream)
+    with pytest.raises(AssertionError, match="RAW"):      # store-count wait kept one phase too long (K-tile 2's loads are younger)
+        pp_model(8, 3, [True] * 3, [PP_STORES] * 3, stream=functools.partial(_pp2_stream, bad="late_store_wait"))
+    with pytest.raises(AssertionError):                   # boundary refill without its barrier: barrier counts / WAR break
+        pp_model(8, 3, [True] * 3, [PP_STORES] * 3, stream=functools.partial(_pp2_stream, bad="no_boundary_barrier"))

@@ -775,6 +775,43 @@ def test_argmax(dtype, V):
     assert torch.equal(buf[:, 2].cpu(), x.float().argmax(-1)) and int(buf[:, [0, 1, 3]].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("M,V,K", [(4096, 50304, 2048), (256, 50304, 512), (1000, 8256, 256), (300, 2048 + 64, 448), (8, 50304, 2048),
+                                   (64, 1000, 128)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_logits_argmax_equals_linear_then_argmax(M, V, K, dtype):
+    """bt_logits_argmax == bt_linear + bt_argmax, bit for bit: same tokens with the logits stored and not stored; stored logits equal
+    bt_linear's; ties (duplicated vocabulary rows) resolve to the lowest index; shapes the fused kernel does not take (few rows, fp32,
+    small vocabularies) fall back to the two-call sequence.  M = 4096, V = 50304, K = 2048 is the benchmark's token step (vocabulary
+    not a multiple of 256: the last tile is half padding)."""
+    x = rnd(M, K, seed=1).to(dtype).to(DEV)
+    w = rnd(V, K, seed=2, scale=K ** -0.5).to(dtype)
+    w[7] = w[V - 3]                       # identical logits in columns 7 and V - 3 ...
+    w[V // 2 + 5] = w[70]                 # ... and in 70 and V / 2 + 5
+    x[5 % M] = w[7].to(DEV) * 3.0         # make the duplicated pair the row maximum for some rows
+    x[9 % M] = w[70].to(DEV) * 3.0
+    w = w.to(DEV)
+    ref_logits = ops.linear(x, w)
+    ref_ids = ops.argmax(ref_logits)
+    lg = torch.full((M, V), float("nan"), dtype=dtype, device=DEV)
+    ids = ops.logits_argmax(x, w, lg, store_logits=True)
+    assert torch.equal(ids, ref_ids)
+    assert torch.equal(lg, ref_logits)
+    assert int(ids[5 % M]) == 7 and int(ids[9 % M]) == 70
+    lg2 = torch.full((M, V), float("nan"), dtype=dtype, device=DEV)
+    ids2 = ops.logits_argmax(x, w, lg2, store_logits=False)
+    assert torch.equal(ids2, ref_ids)
+    fused = bool(torch.isnan(lg2.float()).all())              # nothing written: the fused epilogue ran
+    assert fused or torch.equal(lg2, ref_logits)              # otherwise the fallback wrote every logit
+    if dtype == torch.bfloat16 and M >= 256 and V >= 50000:
+        assert fused, "the benchmark's token step must take the fused epilogue"
+    if dtype == torch.float32 or M <= 8:
+        assert not fused
+    # strided ids output (the engine writes column t of the [B, L] block buffer)
+    blk = torch.full((M, 4), -1, dtype=torch.int64, device=DEV)
+    ops.logits_argmax(x, w, lg, store_logits=False, out=blk[:, 2])
+    assert torch.equal(blk[:, 2], ref_ids) and int(blk[:, [0, 1, 3]].max()) == -1
+
+
 def test_topk_sample_distribution():
     """Distributional check: draws stay inside the top-k set and their frequencies follow softmax(logits/T)[top-k]."""
     V, k, T, n = 1000, 5, 0.7, 4000

@@ -674,6 +674,7 @@ def _full_1p2b():
                 if n.endswith(".bias"):
                     p.normal_(0.0, 0.02)
         model.token_decoder.generation_config.eos_token_id = None
+        model.keep_logits = True
         sd16 = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
         _FULL["m"] = (model, dims, oracle_from_dims(dims, sd16))
     return _FULL["m"]
@@ -822,6 +823,42 @@ def test_long_prompt_long_decode_fp32_tokens_vs_oracle(gpu_model):
     assert model._engine.n_max >= (P + D) // dims.L and model._engine.n_split > 1
     first_bad = (got != want).any(0).nonzero()
     assert torch.equal(got, want), f"first differing column {int(first_bad[0]) if len(first_bad) else None}"
+
+
+def test_greedy_tokens_do_not_depend_on_keeping_logits():
+    """BlockTransformer.keep_logits = False (the default: the logits GEMM's epilogue feeds the argmax reduction, no [B, V] matrix is
+    written) == keep_logits = True, bit for bit, graphs on and off, on the 2-layer 1.2B-shaped bf16 model at B = 512 (fused
+    epilogue) and B = 5 (fallback: GEMV + argmax); with keep_logits = False the engine's logits buffer is never touched."""
+    import dataclasses
+    base = named_dims("block_main_b4_1.2b")
+    dims = dataclasses.replace(base, name="b4_1.2b_2layer", bd=dataclasses.replace(base.bd, layers=2),
+                               td=dataclasses.replace(base.td, layers=2))
+    sd = random_state_dict(dims, seed=6, include_unused_embed_in=False)
+    model = load_block_transformer_from_dims(dims, "fp32", keep_unused_embed_in=False)
+    model.load_state_dict(sd, strict=True)
+    model = model.bfloat16().to(DEV)
+    model.token_decoder.generation_config.eos_token_id = None
+    assert model.keep_logits is False
+    for B in (512, 5):
+        prompt = torch.randint(0, dims.vocab, (B, 32), generator=torch.Generator().manual_seed(B)).to(DEV)
+        outs = {}
+        for keep in (True, False):
+            for graphs in (True, False):
+                model.keep_logits, model.use_graphs = keep, graphs
+                model._engine = None
+                out = model.generate(prompt, max_length=48).cpu()
+                outs[(keep, graphs)] = out
+                if not keep and B == 512:
+                    eng = model._engine
+                    eng.tok.logits.fill_(float("nan"))
+                    again = model.generate(prompt, max_length=48).cpu()
+                    assert torch.equal(again, out)
+                    assert bool(torch.isnan(eng.tok.logits.float()).all()), "logits were written although keep_logits is False"
+        first = outs[(True, True)]
+        assert all(torch.equal(v, first) for v in outs.values())
+    model.keep_logits, model.use_graphs = False, True
+    del model
+    torch.cuda.empty_cache()
 
 
 def test_fp32_production_dims_one_layer_logits_within_1e3():

@@ -151,7 +151,7 @@ def probe_copy(nbytes, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=["gemm", "attn", "flash", "suite", "copy", "ab", "abl", "skinny", "decode", "vendor", "pitch",
-                                     "local", "lin2", "ln", "ppabl", "ppstore", "ppv2"])
+                                     "local", "lin2", "ln", "ppabl", "ppstore", "ppv2", "ppepi", "ppab"])
     ap.add_argument("--m", type=int, default=32768)
     ap.add_argument("--n", type=int, default=6144)
     ap.add_argument("--k", type=int, default=2048)
@@ -363,6 +363,50 @@ def main():
                     res.append({"op": "pp2_ablation", "M": M, "N": N, "K": K, "what": what, "us": round(ms * 1e3, 1),
                                 "TF_equiv": round(2.0 * M * N * K / ms / 1e9, 1)})
             lib().bt_debug_gemm_variant(0)
+    elif args.what == "ppepi":
+        # what the per-tile epilogue of the persistent kernel costs, piece by piece (plain mode; ablated variants are wrong by design)
+        cases = [(12, "production"), (104, "no epilogue"), (132, "epilogue without global stores"), (164, "epilogue without LDS transposes"),
+                 (196, "epilogue = convert only"), (228, "no accumulator init from the bias row"), (101, "no DMA"), (107, "MFMA + barriers only"),
+                 (356, "half of the stores (conservative waits)"), (612, "2 of 16 stores (conservative waits)")]
+        if args.split == 2:
+            cases = [(12, "production"), (104, "no epilogue"), (132, "epilogue without global stores"),
+                     (356, "half of the stores (conservative waits)"), (612, "2 of 16 stores (conservative waits)")]
+        for (M, N, K) in ((32768, 6144, 2048), (32768, 8192, 2048), (32768, 2048, 2048), (32768, 2048, 8192), (4096, 8192, 2048)):
+            x = torch.randn(M, K, device=DEV).bfloat16()
+            w = (torch.randn(N, K, device=DEV) * K ** -0.5).bfloat16()
+            b = torch.randn(N, device=DEV).bfloat16()
+            out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+            for rep in range(3):
+                for v, what in cases:
+                    lib().bt_debug_gemm_variant(v)
+                    ms = timed(lambda: ops.linear(x, w, b, out=out), 10)
+                    res.append({"op": "pp2_epilogue_parts", "M": M, "N": N, "K": K, "what": what, "us": round(ms * 1e3, 1)})
+            lib().bt_debug_gemm_variant(0)
+    elif args.what == "ppab":
+        # interleaved A/B of persistent-kernel variants (--variant A, --ab-other B) on the bench shapes, every epilogue mode
+        va, vb = (args.variant or 12), args.ab_other
+        for (M, N, K) in ((32768, 6144, 2048), (32768, 2048, 8192), (32768, 8192, 2048), (32768, 2048, 2048), (8192, 6144, 2048),
+                          (8192, 2048, 8192), (4096, 8192, 2048), (4096, 6144, 2048), (4096, 50304, 2048)):
+            x = torch.randn(M, K, device=DEV).bfloat16()
+            w = (torch.randn(N, K, device=DEV) * K ** -0.5).bfloat16()
+            b = torch.randn(N, device=DEV).bfloat16()
+            r = torch.randn(M, N, device=DEV).bfloat16()
+            out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+            modes = (("plain", {}), ("gelu", {"act": "gelu"}), ("res", {"residual": r})) if N != 50304 else (("plain", {}),)
+            for name, kw in modes:
+                rec = {"op": "pp_ab", "M": M, "N": N, "K": K, "mode": name, "a": va, "b": vb, "a_us": [], "b_us": []}
+                outs = {}
+                for rep in range(3):
+                    for v in (va, vb):
+                        lib().bt_debug_gemm_variant(v)
+                        ms = timed(lambda: ops.linear(x, w, b, kw.get("residual"), act=kw.get("act", "none"), out=out), 10)
+                        rec["a_us" if v == va else "b_us"].append(round(ms * 1e3, 1))
+                        outs[v] = out.clone()
+                rec["bit_identical"] = bool(torch.equal(outs[va], outs[vb]))
+                rec["a_TF"] = round(2.0 * M * N * K / min(rec["a_us"]) / 1e6, 1)
+                rec["b_TF"] = round(2.0 * M * N * K / min(rec["b_us"]) / 1e6, 1)
+                res.append(rec)
+        lib().bt_debug_gemm_variant(0)
     elif args.what == "abl":
         for (M, N, K) in ((32768, 6144, 2048), (32768, 2048, 8192)):
             for v in (0, 3, 20, 21, 8, 0, 3, 20, 21, 8):   # production / 4-phase one-tile kernel: full, no MFMA, DMA only, MFMA+barriers only
