@@ -206,6 +206,9 @@ def main():
                     help="two half-batch shards on two streams (global-attention / GEMM overlap, measured not to pay: DESIGN.md "
                          "section 3); auto = off unless BT_PIPELINE=1")
     ap.add_argument("--cpu-sample", default="128,128", help="prefill,decode of the CPU baseline sample")
+    ap.add_argument("--keep-logits", action="store_true",
+                    help="materialise the [B, vocab] logits of every greedy step (A/B: the default feeds the argmax from the logits "
+                         "GEMM's epilogue and never writes them, like HF generate with output_scores=False)")
     args = ap.parse_args()
 
     if not torch.cuda.is_available():
@@ -239,6 +242,7 @@ def main():
     log("model built")
     model.use_graphs = not args.no_graphs
     model.pipeline = {"auto": None, "on": True, "off": False}[args.pipeline]
+    model.keep_logits = bool(args.keep_logits)
     gen = torch.Generator().manual_seed(args.seed + 1000 * rank)
     input_ids = torch.randint(0, dims.vocab, (B, P), generator=gen).to(device)
 
@@ -277,7 +281,8 @@ def main():
                    "batch_per_gpu": B, "global_batch": B * world, "prefill": P, "decode": D, "block_length": L,
                    "batch_sizing": "fixed (--batch)" if args.batch > 0 else "auto: free HBM / bytes per sequence, cap 4096",
                    "parallelism": f"dp{world} request shards", "hipgraph": model.use_graphs,
-                   "half_batch_pipeline": bool(model._engine is not None and model._engine.pipelined)},
+                   "half_batch_pipeline": bool(model._engine is not None and model._engine.pipelined),
+                   "logits_materialised": bool(model.keep_logits)},
     }
 
     if rank == 0:

@@ -850,7 +850,8 @@ def test_greedy_tokens_do_not_depend_on_keeping_logits():
                 outs[(keep, graphs)] = out
                 if not keep and B == 512:
                     eng = model._engine
-                    eng.tok.logits.fill_(float("nan"))
+                    with torch.inference_mode():
+                        eng.tok.logits.fill_(float("nan"))
                     again = model.generate(prompt, max_length=48).cpu()
                     assert torch.equal(again, out)
                     assert bool(torch.isnan(eng.tok.logits.float()).all()), "logits were written although keep_logits is False"

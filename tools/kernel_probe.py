@@ -22,10 +22,23 @@ from block_transformer_amd import _lib, ops  # noqa: E402
 from block_transformer_amd._lib import check, current_stream, lib, ptr  # noqa: E402
 
 # the A/B and ablation variants (bt_debug_*) exist only in the debug build; --product times libbt_hip.so itself
-if "--product" in sys.argv:
+PRODUCT = "--product" in sys.argv
+if PRODUCT:
     sys.argv.remove("--product")
 else:
     _lib.use_debug_library(True)
+
+
+class _Hooks:
+    """bt_debug_* setters; no-ops on the product library (which has none: its dispatch is fixed)."""
+
+    def __getattr__(self, name):
+        if name.startswith("bt_debug_") and PRODUCT:
+            return lambda *a: None
+        return getattr(lib(), name)
+
+
+hooks = _Hooks()
 
 DEV = "cuda"
 
@@ -161,11 +174,13 @@ def main():
     ap.add_argument("--split", type=int, default=1)
     ap.add_argument("--ab-other", type=int, default=9, help="GEMM variant compared with production in `ab`")
     ap.add_argument("--variant", type=int, default=0, help="bt_debug_gemm_variant: 0 auto, 1 128^2 kernel, 2 256^2 kernel")
+    ap.add_argument("--act", default="none", choices=["none", "gelu"], help="`gemm`: epilogue activation")
+    ap.add_argument("--res", action="store_true", help="`gemm`: residual epilogue")
     args = ap.parse_args()
     res = []
-    lib().bt_debug_gemm_variant(args.variant)
+    hooks.bt_debug_gemm_variant(args.variant)
     if args.what == "gemm":
-        res.append(probe_gemm(args.m, args.n, args.k, args.iters))
+        res.append(probe_gemm(args.m, args.n, args.k, args.iters, act=args.act, res=args.res))
     elif args.what == "lin2":    # the residual-stream projections of block_main_b4_1.2b at decode / prefill stack heights
         for M in (4096, 8192, 16384, 32768):
             res.append(probe_lin2(M, 2048, 8192, 2048, args.iters))
@@ -174,12 +189,12 @@ def main():
         for pos0 in (2, 3, 4):
             res.append(probe_local(args.batch, 1, pos0, args.iters))
     elif args.what == "attn":
-        for nt in (0, 1, 0, 1):
-            lib().bt_debug_attn_nt(nt)
+        for nt in ((0,) if PRODUCT else (0, 1, 0, 1)):
+            hooks.bt_debug_attn_nt(nt)
             r = probe_attn(args.batch, args.keys, args.iters, n_split=args.split)
             r["nontemporal"] = nt
             res.append(r)
-        lib().bt_debug_attn_nt(0)
+        hooks.bt_debug_attn_nt(0)
     elif args.what == "flash":
         names = {0: "production", 2: "v2 <8 waves, 4-deep ring>", 1: "v1", 3: "OPT 0 (round-1 kernel)", 4: "OPT 1 (K/V DMA before Q)",
                  5: "OPT 3 (+ heaviest block first)", 6: "OPT 7 (+ setprio)", 7: "OPT 5 (DMA first + setprio)"}
@@ -192,12 +207,12 @@ def main():
         names[12] = "OPT 95 (31 + XCD-aware grid: a sequence-head's query blocks share one L2)"
         names[0] = "production (v3: persistent workgroups)"
         names[13] = "v2 OPT 95 (one workgroup per query block)"
-        for v in ((9, 13, 0, 9, 13, 0) if args.split == 1 else (3, 4, 5, 6, 7, 0, 3, 4, 5, 6, 7, 0)):
-            lib().bt_debug_flash_variant(v)
+        for v in ((0,) if PRODUCT else (9, 13, 0, 9, 13, 0) if args.split == 1 else (3, 4, 5, 6, 7, 0, 3, 4, 5, 6, 7, 0)):
+            hooks.bt_debug_flash_variant(v)
             r = probe_flash(args.batch, args.keys, args.iters)
             r["variant"] = names[v]
             res.append(r)
-        lib().bt_debug_flash_variant(0)
+        hooks.bt_debug_flash_variant(0)
     elif args.what == "ln":      # dual LayerNorm at H = 2048: register-resident kernel vs the three-pass streaming kernel
         for M in (4096, 32768, 131072):
             x = torch.randn(M, 2048, device=DEV).bfloat16()
@@ -206,12 +221,12 @@ def main():
             st = current_stream()
             rec = {"op": "layernorm_dual", "M": M, "H": 2048}
             for tag, flag in (("streaming", 1), ("register", 0), ("streaming_b", 1), ("register_b", 0)):
-                lib().bt_debug_ln_streaming(flag)
+                hooks.bt_debug_ln_streaming(flag)
                 ms = timed(lambda: check(lib().bt_layernorm(_lib.BT_BF16, M, 2048, ptr(x), 2048, ptr(w[0]), ptr(w[1]), ptr(o1), 2048,
                                                             ptr(w[2]), ptr(w[3]), ptr(o2), 2048, 1e-5, st)), args.iters)
                 rec[tag + "_us"] = round(ms * 1e3, 2)
                 rec[tag + "_GBps"] = round(3 * M * 2048 * 2 / (ms * 1e-3) / 1e9, 1)
-            lib().bt_debug_ln_streaming(0)
+            hooks.bt_debug_ln_streaming(0)
             res.append(rec)
     elif args.what == "copy":
         res.append(probe_copy(1 << 30, args.iters))
@@ -220,23 +235,23 @@ def main():
         for (M, N, K) in ((32768, 6144, 2048), (32768, 2048, 2048), (32768, 8192, 2048), (32768, 2048, 8192),
                           (4096, 8192, 2048), (16384, 2048, 2048), (8192, 8192, 2048)):
             for v in (args.ab_other, 0, args.ab_other, 0):   # e.g. 9 = one tile per workgroup, 14 = 32x32x16 MFMA; 0 = production
-                lib().bt_debug_gemm_variant(v)
+                hooks.bt_debug_gemm_variant(v)
                 for kw in ({}, {"act": "gelu"}, {"res": True}):
                     r = probe_gemm(M, N, K, 10 if M > 8000 else 20, **kw)
                     r["variant"] = v
                     r["res"] = bool(kw.get("res"))
                     res.append(r)
-        lib().bt_debug_gemm_variant(0)
+        hooks.bt_debug_gemm_variant(0)
     elif args.what == "decode":
         # decode-regime GEMMs (M = batch): dispatch heuristic (0) vs forced persistent 256^2 (12) vs forced 128^2 (1)
         for (M, N, K) in ((4096, 6144, 2048), (4096, 2048, 2048), (4096, 8192, 2048), (4096, 2048, 8192),
                           (4096, 50304, 2048), (2048, 6144, 2048), (2048, 8192, 2048), (1024, 8192, 2048)):
             for v in (0, 12, 1, 0, 12, 1):
-                lib().bt_debug_gemm_variant(v)
+                hooks.bt_debug_gemm_variant(v)
                 r = probe_gemm(M, N, K, 20, bias=(N != 50304))
                 r["variant"] = v
                 res.append(r)
-        lib().bt_debug_gemm_variant(0)
+        hooks.bt_debug_gemm_variant(0)
     elif args.what == "vendor":
         # calibration: this library's bt_linear vs torch's bf16 F.linear (hipBLASLt / rocBLAS under PyTorch-ROCm), same box,
         # same inputs, interleaved.  Not part of the product path -- a yardstick for the MFMA roofline fraction.
@@ -270,11 +285,11 @@ def main():
                 for sc in (False, True):
                     res.append(probe_gemm(M, N, K, 30, scratch=sc))
                 if M <= 8:   # GEMV off: the split-K MFMA path it replaces
-                    lib().bt_debug_gemm_variant(22)
+                    hooks.bt_debug_gemm_variant(22)
                     r = probe_gemm(M, N, K, 30, scratch=True)
                     r["variant"] = "no_gemv"
                     res.append(r)
-                    lib().bt_debug_gemm_variant(0)
+                    hooks.bt_debug_gemm_variant(0)
     elif args.what == "ppabl":
         # timing ablations of the PRODUCTION persistent kernel (plain epilogue; results of the ablated variants are wrong by design):
         # where do the cycles between the MFMA skeleton and the full kernel go?  variant = 30 + ABL bits
@@ -291,19 +306,19 @@ def main():
             out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
             for rep in range(2):
                 for v in order:
-                    lib().bt_debug_gemm_variant(v)
+                    hooks.bt_debug_gemm_variant(v)
                     ms = timed(lambda: ops.linear(x, w, b, out=out), 10)
                     res.append({"op": "pp_ablation", "M": M, "N": N, "K": K, "variant": v, "what": names[v], "us": round(ms * 1e3, 1),
                                 "TF_equiv": round(2.0 * M * N * K / ms / 1e9, 1)})
-            lib().bt_debug_gemm_variant(62)          # the rotated K order is a correct kernel: check it
+            hooks.bt_debug_gemm_variant(62)          # the rotated K order is a correct kernel: check it
             ops.linear(x, w, b, out=out)
-            lib().bt_debug_gemm_variant(0)
+            hooks.bt_debug_gemm_variant(0)
             ref = torch.empty_like(out)
             ops.linear(x, w, b, out=ref)
             res.append({"op": "pp_krot_check", "M": M, "N": N, "K": K,
                         "max_abs_diff_vs_production": float((out.float() - ref.float()).abs().max()),
                         "max_abs": float(ref.float().abs().max())})
-        lib().bt_debug_gemm_variant(0)
+        hooks.bt_debug_gemm_variant(0)
     elif args.what == "ppstore":
         # where does the epilogue's cost come from?  (profiles/r3_pp_ablation.md: removing the epilogue saves 10-17 % although
         # its instructions are few): dbg 1 = the same stores into an L2-resident dummy region (no HBM write burst), 2 =
@@ -318,15 +333,15 @@ def main():
             out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
             for rep in range(3):
                 for (name, v, dbg) in cases:
-                    lib().bt_debug_gemm_variant(v)
-                    lib().bt_debug_pp_dbg(dbg)
+                    hooks.bt_debug_gemm_variant(v)
+                    hooks.bt_debug_pp_dbg(dbg)
                     ms = timed(lambda: ops.linear(x, w, b, out=out), 10)
                     res.append({"op": "pp_store_path", "M": M, "N": N, "K": K, "case": name, "us": round(ms * 1e3, 1),
                                 "TF_equiv": round(2.0 * M * N * K / ms / 1e9, 1)})
-            lib().bt_debug_gemm_variant(0)
-            lib().bt_debug_pp_dbg(0x200)         # staggered start is a correct kernel: check it
+            hooks.bt_debug_gemm_variant(0)
+            hooks.bt_debug_pp_dbg(0x200)         # staggered start is a correct kernel: check it
             ops.linear(x, w, b, out=out)
-            lib().bt_debug_pp_dbg(0)
+            hooks.bt_debug_pp_dbg(0)
             ref = torch.empty_like(out)
             ops.linear(x, w, b, out=ref)
             res.append({"op": "pp_stagger_check", "M": M, "N": N, "K": K, "bit_identical": bool(torch.equal(out, ref))})
@@ -347,7 +362,7 @@ def main():
                 outs = {}
                 for rep in range(3):
                     for v in (16, 12):     # 12 = force the persistent kernel family (production K-loop), 16 = first generation
-                        lib().bt_debug_gemm_variant(v)
+                        hooks.bt_debug_gemm_variant(v)
                         ms = timed(lambda: ops.linear(x, w, b, kw.get("residual"), act=kw.get("act", "none"), out=out), 10)
                         rec.setdefault("v1_us" if v == 16 else "v2_us", []).append(round(ms * 1e3, 1))
                         outs[v] = out.clone()
@@ -358,11 +373,11 @@ def main():
             if (M, N, K) in shapes[:3]:
                 for v, what in ((101, "no DMA"), (102, "no ds_reads"), (104, "no epilogue"), (107, "MFMA + barriers only"),
                                 (122, "DMA ring only")):
-                    lib().bt_debug_gemm_variant(v)
+                    hooks.bt_debug_gemm_variant(v)
                     ms = min(timed(lambda: ops.linear(x, w, b, out=out), 10) for _ in range(2))
                     res.append({"op": "pp2_ablation", "M": M, "N": N, "K": K, "what": what, "us": round(ms * 1e3, 1),
                                 "TF_equiv": round(2.0 * M * N * K / ms / 1e9, 1)})
-            lib().bt_debug_gemm_variant(0)
+            hooks.bt_debug_gemm_variant(0)
     elif args.what == "ppepi":
         # what the per-tile epilogue of the persistent kernel costs, piece by piece (plain mode; ablated variants are wrong by design)
         cases = [(12, "production"), (104, "no epilogue"), (132, "epilogue without global stores"), (164, "epilogue without LDS transposes"),
@@ -378,10 +393,10 @@ def main():
             out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
             for rep in range(3):
                 for v, what in cases:
-                    lib().bt_debug_gemm_variant(v)
+                    hooks.bt_debug_gemm_variant(v)
                     ms = timed(lambda: ops.linear(x, w, b, out=out), 10)
                     res.append({"op": "pp2_epilogue_parts", "M": M, "N": N, "K": K, "what": what, "us": round(ms * 1e3, 1)})
-            lib().bt_debug_gemm_variant(0)
+            hooks.bt_debug_gemm_variant(0)
     elif args.what == "ppab":
         # interleaved A/B of persistent-kernel variants (--variant A, --ab-other B) on the bench shapes, every epilogue mode
         va, vb = (args.variant or 12), args.ab_other
@@ -398,7 +413,7 @@ def main():
                 outs = {}
                 for rep in range(3):
                     for v in (va, vb):
-                        lib().bt_debug_gemm_variant(v)
+                        hooks.bt_debug_gemm_variant(v)
                         ms = timed(lambda: ops.linear(x, w, b, kw.get("residual"), act=kw.get("act", "none"), out=out), 10)
                         rec["a_us" if v == va else "b_us"].append(round(ms * 1e3, 1))
                         outs[v] = out.clone()
@@ -406,15 +421,15 @@ def main():
                 rec["a_TF"] = round(2.0 * M * N * K / min(rec["a_us"]) / 1e6, 1)
                 rec["b_TF"] = round(2.0 * M * N * K / min(rec["b_us"]) / 1e6, 1)
                 res.append(rec)
-        lib().bt_debug_gemm_variant(0)
+        hooks.bt_debug_gemm_variant(0)
     elif args.what == "abl":
         for (M, N, K) in ((32768, 6144, 2048), (32768, 2048, 8192)):
             for v in (0, 3, 20, 21, 8, 0, 3, 20, 21, 8):   # production / 4-phase one-tile kernel: full, no MFMA, DMA only, MFMA+barriers only
-                lib().bt_debug_gemm_variant(v)
+                hooks.bt_debug_gemm_variant(v)
                 r = probe_gemm(M, N, K, 10, bias=False)
                 r["variant"] = v
                 res.append(r)
-        lib().bt_debug_gemm_variant(0)
+        hooks.bt_debug_gemm_variant(0)
     else:
         res.append(probe_copy(1 << 30, 10))
         for M in (32768, 4096, 2048, 1024, 256, 64, 1):

@@ -83,6 +83,10 @@ def traffic(args):
     rec = {"shape": args.shape, "fetch_size_KiB_raw": f["FETCH_SIZE"], "write_size_KiB": w["WRITE_SIZE"],
            "hbm_bytes_corrected": 2 * f["FETCH_SIZE"] * 1024 + w["WRITE_SIZE"] * 1024,
            "algorithmic_bytes": args.algorithmic_bytes, "avg_duration_us": dur}
+    if args.kernel_name:
+        rec["kernel"] = args.kernel_name
+    if args.git:
+        rec["git"] = args.git
     if args.update:
         data = json.load(open(args.update)) if os.path.exists(args.update) else {}
         data[args.key] = rec
@@ -111,6 +115,8 @@ def main():
     a.add_argument("--algorithmic-bytes", type=int, required=True)
     a.add_argument("--key", required=True)
     a.add_argument("--update")
+    a.add_argument("--kernel-name", default="", help="recorded in the json: the kernel the pass measured")
+    a.add_argument("--git", default="", help="recorded in the json: revision of the tree the pass ran on")
     a.set_defaults(fn=traffic)
     args = ap.parse_args()
     args.fn(args)
