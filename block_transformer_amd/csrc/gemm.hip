@@ -58,8 +58,10 @@ __device__ inline v2f gelu_tail2(v2f x) {
     const v2f t = ax * ax * -0.72134752044448170368f;   // -a^2 / 2 * log2(e)
     const v2f e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
     const v2f q = e * r;                                 // Phi(-|x|)
-    const v2f s = {x.x < 0.0f ? q.x : 1.0f - q.x, x.y < 0.0f ? q.y : 1.0f - q.y};
-    return x * s;
+    // x * Phi(x) = relu(x) - |x| * Phi(-|x|): the same value as selecting q or 1 - q by sign and multiplying (identical for x < 0,
+    // x - x q for x >= 0), in one packed FMA instead of two compares, two selects, a subtraction and a multiply
+    const v2f relu = {__builtin_fmaxf(x.x, 0.0f), __builtin_fmaxf(x.y, 0.0f)};
+    return relu - ax * q;
 }
 
 __device__ inline void gelu4(float (&v)[4]) {
@@ -1305,6 +1307,35 @@ __device__ inline __amdgpu_buffer_rsrc_t tile_rsrc(const char* base_uniform) {
     return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
 }
 
+// (b, t) = (m / q_len, m % q_len) for the rows of one tile: q_len == 1 (decode) is the identity; for q_len >= 256 a tile's 256 rows
+// cross at most one sequence boundary, so the tile's first row is divided once (scalar) and lanes add / wrap; otherwise divide.
+// (The per-lane 32-bit division is ~30 VALU instructions; the QKV epilogue needs it for 24 addresses per lane and tile.)
+struct RowSplit {
+    int q_len, b0, t0, m0;
+    bool wrap1;
+    __device__ inline RowSplit(int q_len_, int cm0) : q_len(q_len_), m0(cm0) {
+        wrap1 = q_len_ >= BM2;
+        b0 = wrap1 ? __builtin_amdgcn_readfirstlane(cm0 / q_len_) : 0;
+        t0 = wrap1 ? __builtin_amdgcn_readfirstlane(cm0 - b0 * q_len_) : 0;
+    }
+    __device__ inline void split(int m, int& b, int& t) const {
+        if (q_len == 1) {
+            b = m;
+            t = 0;
+        } else if (wrap1) {
+            t = t0 + (m - m0);
+            b = b0;
+            if (t >= q_len) {
+                t -= q_len;
+                b += 1;
+            }
+        } else {
+            b = m / q_len;
+            t = m - b * q_len;
+        }
+    }
+};
+
 // EABL (debug timing ablations, wrong results): 1 = no global stores, 2 = no LDS transposes (the packed registers are stored as is)
 template <int MODE, int EABL = 0>
 __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x4_t (&acc)[8][4], int cm0, int n_wave, int wm,
@@ -1326,11 +1357,14 @@ __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x
         if (rot[0] || rot[1]) {
             // table rows of the lane's 8 output rows (independent loads first, then the dependent cos / sin rows)
             int rpos[8];
+            const RowSplit rs(e.q.q_len, cm0);
 #pragma unroll
             for (int ai = 0; ai < 8; ++ai) {
                 int m = cm0 + (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16 + (lane & 15);
                 m = m < M ? m : M - 1;
-                rpos[ai] = pos0 + m % e.q.q_len;
+                int b_, t_;
+                rs.split(m, b_, t_);
+                rpos[ai] = pos0 + t_;
             }
             if (e.q.pos_table) {
 #pragma unroll
@@ -1473,8 +1507,9 @@ __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x
                     const int within = n - head * 3 * D;
                     const int part = within / D;
                     const int el = within - part * D;
-                    const int64_t b = m / e.q.q_len;
-                    const int t = m - (int)b * e.q.q_len;
+                    int bi, t;
+                    RowSplit(e.q.q_len, cm0).split(m, bi, t);
+                    const int64_t b = bi;
                     bf16* cache = part == 1 ? e.q.kc : e.q.vc;
                     dst = part == 0 ? e.out + (int64_t)m * e.ldo + n
                                     : cache + ((b * e.q.heads + head) * e.q.n_max + pos0 + t) * D + el;

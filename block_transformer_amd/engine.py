@@ -10,9 +10,14 @@ State lives in preallocated HBM buffers with fixed addresses, described once to 
 
 The Python side only captures those calls into hipGraphs once and replays them per block; everything that changes between
 replays (the number of cached block positions n, finished flags, the sampler's draw counter) is a device scalar read by
-the kernels.  Finished sequences are masked, not compacted (the reference compacts with boolean indexing + host syncs,
-C13/C14): fixed batch => static shapes => graph replay.  Local-KV "reset" costs nothing: every token block starts
-writing the local cache at row 0 again.
+the kernels.  Finished sequences are masked inside an engine (fixed batch => static shapes => graph replay); the reference
+instead compacts the batch with boolean indexing every block (model/block_transformer.py:381-398,421; C13/C14).  Round 3 adds
+compaction at bucket granularity: with EOS handling on, the per-block host look at ``finished[]`` (the reference's own sync,
+:415) counts the live sequences, and once at most half of an engine's rows are live the loop continues on a smaller engine
+(``DecodeEngine.compacted``): the live rows' global KV is moved to the front of the SAME cache storage, the small engine gets its
+own activation buffers and graphs, and its blocks are scattered back into the full ``out_ids`` at the end.  Greedy decoding only
+(the sampler's RNG streams are keyed by row index).  Local-KV "reset" costs nothing: every token block starts writing the
+local cache at row 0 again.
 
 ``PipelinedEngine`` (opt-in: ``model.pipeline = True`` / ``BT_PIPELINE=1``) runs TWO half-batch shards on two HIP streams,
 one token block apart, so that shard A's global-KV stream (block-decoder step, HBM-bound, matrix cores idle) can overlap
@@ -170,8 +175,13 @@ class DecodeEngine:
 
     pipelined = False
 
+    # compaction (EOS handling, greedy): continue on a smaller engine once <= half of the rows are live, down to this batch
+    MIN_COMPACT_BATCH = 64
+    COMPACT_BUCKET = 32           # compacted batches are multiples of this (bounds the number of engine shapes / graph sets)
+
     def __init__(self, model, batch: int, max_blocks: int, rope_policy: str = DEFAULT_ROPE_POLICY,
-                 prefill_rows: Optional[int] = None, stream: Optional[torch.cuda.Stream] = None):
+                 prefill_rows: Optional[int] = None, stream: Optional[torch.cuda.Stream] = None,
+                 kv_rows_of: Optional[KVCache] = None):
         self.model = model
         bd, td = model.block_decoder, model.token_decoder
         self.bd_rt: DecoderRuntime = bd._rt
@@ -183,7 +193,11 @@ class DecodeEngine:
         self.H = bd.config.hidden_size
         heads = bd.config.num_attention_heads
         self.n_max = max(max_blocks, 1)
-        self.glob = KVCache(bd.config.num_hidden_layers, batch, heads, self.n_max, self.H // heads, dt, dev)
+        # a compacted engine works on the first `batch` sequences of its parent's cache storage
+        self.glob = (KVCache(bd.config.num_hidden_layers, batch, heads, self.n_max, self.H // heads, dt, dev)
+                     if kv_rows_of is None else KVCache.rows_of(kv_rows_of, batch))
+        self._children = {}       # compacted engines by batch size (buffers and graphs are reused across generate() calls)
+        self.rope_policy = rope_policy
         self.tok = TokenBlockState(td, batch, dev, rope_policy)
         self.rope = ops.rope_tables(self.n_max, self.bd_rt.dims.rot,
                                     float(getattr(bd.config, "rotary_emb_base", 10000.0)), dev)
@@ -348,35 +362,92 @@ class DecodeEngine:
             # EOS handling needs a host look at finished[] between the token block and the roll-over (like the
             # reference, :415); without it a block step is ONE graph (token block + roll-over)
             fused_step = use_graphs and gen_eos < 0 and streamer is None and not per_iter
+            do_sample = bool(gen is not None and getattr(gen, "do_sample", False))
+            compacting = (gen_eos >= 0 and streamer is None and not do_sample
+                          and bool(getattr(self.model, "compact_finished", True)))
+            eng = self                    # the engine the loop currently runs on (self, or a compacted descendant)
+            rows = None                   # global row of each of eng's real rows (None = identity)
+            n_real = B                    # eng's rows that carry a sequence (the rest of a compacted engine is padding)
+            blk0 = nb                     # first block eng has generated itself
+            self.compactions = []         # (block index, live sequences, new batch) of this call: diagnostics / tests
             while True:
                 count = min(max_length - (n_blocks * L - added_pad), L)
                 last = (n_blocks + 1) * L >= max_length
                 if per_iter:
                     timers.mark_iter("token_decoder_start")
                 if streamer is not None:
-                    self.token_block_streamed(count, streamer)
+                    eng.token_block_streamed(count, streamer)
                 elif fused_step and not last and count == L:
-                    self.launch("step", L, True)
+                    eng.launch("step", L, True)
                     n_blocks += 1
                     continue
                 else:
-                    self.launch("tok", count, use_graphs)
+                    eng.launch("tok", count, use_graphs)
                 if per_iter:
                     timers.mark_iter("token_decoder_end")
                 n_blocks += 1
                 if n_blocks * L >= max_length:
                     break
-                if gen_eos >= 0 and bool(self.finished.all()):  # host sync per block, like the reference (:415)
-                    break
+                if gen_eos >= 0:   # host sync per block, like the reference (:415)
+                    live = (eng.finished[:n_real] == 0).nonzero().flatten()
+                    n_live = int(live.numel())
+                    if n_live == 0:
+                        break
+                    if compacting and eng.B >= self.MIN_COMPACT_BATCH and 2 * n_live <= eng.B:
+                        # reference :381-398,421: only decode_mask rows go on.  Blocks eng generated so far go home first.
+                        self._collect(eng, rows, n_real, blk0, n_blocks, cfg_pad)
+                        child = eng.compacted(live, n_blocks, gen, cfg_pad)
+                        rows = live if rows is None else rows[live]
+                        self.compactions.append((n_blocks, n_live, child.B))
+                        eng, n_real, blk0 = child, n_live, n_blocks
                 if per_iter:
                     timers.mark_iter("block_decoder_start")
-                self.launch("roll", 0, use_graphs and streamer is None)
+                eng.launch("roll", 0, use_graphs and streamer is None)
                 if per_iter:
                     timers.mark_iter("block_decoder_end")
+            if eng is not self:
+                self._collect(eng, rows, n_real, blk0, n_blocks, cfg_pad)
             if timers is not None:
                 timers.mark("decode_end")
         torch.cuda.current_stream().wait_stream(side)
         return self.out_ids[:, :n_blocks], count
+
+    # ---- compaction of finished sequences --------------------------------------------------------------------------------
+    def _collect(self, eng: "DecodeEngine", rows, n_real: int, blk_lo: int, blk_hi: int, cfg_pad: int) -> None:
+        """Blocks [blk_lo, blk_hi) generated by a compacted engine -> the root's out_ids, at the sequences' original rows; the
+        first time (eng is the root) every later block of every row is pre-filled with the pad id finished rows receive
+        (model/block_transformer.py:384: next_tokens = full(pad_token_id))."""
+        if eng is self:
+            self.out_ids[:, blk_hi:].fill_(int(cfg_pad))
+            return
+        if blk_hi > blk_lo:
+            self.out_ids[rows, blk_lo:blk_hi] = eng.out_ids[:n_real, blk_lo:blk_hi]
+
+    def compacted(self, live: torch.Tensor, n_cached: int, gen, cfg_pad: int) -> "DecodeEngine":
+        """The engine that continues only the sequences ``live`` (ascending row indices of this engine) after a token block:
+        their global KV rows move to the front of the shared cache storage (in place, layer by layer), and a smaller engine
+        (batch = live count rounded up to COMPACT_BUCKET; the surplus rows are inert: finished, attention skipped) takes over
+        the device-side state the roll-over needs: n_cur, the block just decoded, the block mask."""
+        n = int(live.numel())
+        Bc = min(self.B, -(-n // self.COMPACT_BUCKET) * self.COMPACT_BUCKET)
+        child = self._children.get(Bc)
+        if child is None:
+            child = self._children[Bc] = DecodeEngine(self.model, Bc, self.NB, self.rope_policy, stream=self.stream,
+                                                      kv_rows_of=self.glob)
+        k, v = self.glob.k, self.glob.v
+        for l in range(k.shape[0]):        # row i <- row live[i] >= i: gather to a temporary, then write the front
+            k[l, :n, :, :n_cached] = k[l, :, :, :n_cached].index_select(0, live)
+            v[l, :n, :, :n_cached] = v[l, :, :, :n_cached].index_select(0, live)
+        child.configure(gen, cfg_pad, True)
+        child.n_cur.copy_(self.n_cur)
+        child.finished.fill_(1)
+        child.finished[:n] = 0
+        child.finished_prev.copy_(child.finished)
+        child.mask.fill_(1)
+        child.mask[:n, :self.mask.shape[1]] = self.mask[live]
+        child.tok.raw.zero_()
+        child.tok.raw[:n] = self.tok.raw[live]
+        return child
 
 
 class PipelinedEngine:

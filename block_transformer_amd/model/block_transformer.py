@@ -81,6 +81,10 @@ class BlockTransformer(nn.Module):
         # its argmax in its epilogue (bt_logits_argmax) and the [B, vocab] matrix is never written.  True = also materialise the
         # last step's logits in ``_engine.tok.logits`` (tests, debugging); the tokens are the same bit for bit either way.
         self.keep_logits = False
+        # EOS handling: once at most half of the batch is still decoding, continue on a smaller engine with only the live
+        # sequences (the reference compacts every block with decode_mask indexing, :381-398,421; engine.DecodeEngine.compacted).
+        # False = finished rows stay in the batch, masked (same tokens; A/B and tests).
+        self.compact_finished = True
         self._engine: Optional[DecodeEngine] = None
         self.last_timers: Optional[_Timers] = None
 

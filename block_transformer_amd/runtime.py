@@ -38,6 +38,17 @@ class KVCache:
     def layer_stride(self) -> int:
         return self.k.stride(0)
 
+    @classmethod
+    def rows_of(cls, parent: "KVCache", batch: int) -> "KVCache":
+        """Sequences [0, batch) of ``parent``, SHARING its storage (views: the layer stride stays the parent's).  Used when the
+        decode engine compacts its batch: the surviving sequences are moved to the front of the same cache."""
+        assert 0 < batch <= parent.batch
+        self = cls.__new__(cls)
+        self.k = parent.k[:, :batch]
+        self.v = parent.v[:, :batch]
+        self.length = parent.length
+        return self
+
     def grown(self, n_max: int) -> "KVCache":
         """A larger cache holding the same rows (only the module-level API ever grows a cache)."""
         L, B, Hh, _, d = self.k.shape

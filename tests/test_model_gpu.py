@@ -862,6 +862,100 @@ def test_greedy_tokens_do_not_depend_on_keeping_logits():
     torch.cuda.empty_cache()
 
 
+def _two_group_eos_case(model, dims, B, P, D, seed):
+    """A batch whose even rows share one prompt and whose odd rows share another, and an EOS id that the even rows emit as the
+    first token of their THIRD generated block and nobody emits before: with that EOS half of the batch finishes exactly there."""
+    g = torch.Generator().manual_seed(seed)
+    for _ in range(50):
+        pa, pb = torch.randint(1, dims.vocab, (2, P), generator=g)
+        prompt = torch.stack([pa if i % 2 == 0 else pb for i in range(B)])
+        model.token_decoder.generation_config.eos_token_id = None
+        free = model.generate(prompt[:2].to(DEV), max_length=P + D).cpu()
+        L = dims.L
+        eos = int(free[0, P + 2 * L])
+        if eos not in free[0, P:P + 2 * L].tolist() and eos not in free[1, P:].tolist():
+            return prompt, eos, free
+    raise AssertionError("no usable EOS id found")
+
+
+@pytest.mark.parametrize("name,dtype", [("micro", torch.float32), ("micro128", torch.float32), ("micro", torch.bfloat16)])
+def test_compaction_of_finished_sequences_matches_masked_engine(gpu_model, name, dtype):
+    """Reference model/block_transformer.py:381-398,421 (only decode_mask rows are decoded): with EOS handling on, once half of the
+    batch has finished the engine continues on a compacted batch.  Tokens == the masked engine (compact_finished = False) ==
+    the CPU oracle (fp32), graphs on and off; and the compaction really happened (192 -> 96 rows after the third block)."""
+    model, dims, sd, fx = gpu_model(name, dtype)
+    B, P, D = 192, 16, 48
+    prompt, eos, free = _two_group_eos_case(model, dims, B, P, D, seed=3)
+    gcfg = model.token_decoder.generation_config
+    try:
+        gcfg.eos_token_id = eos
+        outs = {}
+        for compact in (True, False):
+            for graphs in (True, False):
+                model.compact_finished, model.use_graphs = compact, graphs
+                out = model.generate(prompt.to(DEV), max_length=P + D).cpu()
+                outs[(compact, graphs)] = out
+                if compact:
+                    comp = model._engine.compactions
+                    assert comp and comp[0][1] == B // 2 and comp[0][2] == B // 2, comp
+                else:
+                    assert model._engine.compactions == []
+        first = outs[(True, True)]
+        assert all(torch.equal(v, first) for v in outs.values())
+        # even rows: free-running tokens up to and including the EOS, pad afterwards; odd rows: untouched by their neighbours
+        L = dims.L
+        pad = int(model.token_decoder.config.pad_token_id)
+        assert torch.equal(first[0, :P + 2 * L + 1], free[0, :P + 2 * L + 1])
+        assert set(first[0, P + 3 * L:].tolist()) <= {pad}
+        assert torch.equal(first[1], free[1, :first.shape[1]]) or eos in free[1].tolist()
+        if dtype == torch.float32:
+            o = oracle_from_dims(dims, sd, gen_eos_token_id=eos, gen_pad_token_id=gcfg.pad_token_id,
+                                 pad_token_id=int(model.token_decoder.config.pad_token_id))
+            want = o.generate(prompt[:4], max_length=P + D)
+            assert torch.equal(first[:4, :want.shape[1]], want)
+    finally:
+        gcfg.eos_token_id = None
+        model.compact_finished, model.use_graphs = True, True
+
+
+def test_compaction_speeds_up_an_eos_heavy_batch():
+    """2-layer 1.2B-shaped bf16 model, B = 1024, half of the rows finish at the start of the third generated
+    block: the compacted continuation (512 rows) must be clearly faster than masking the dead rows, with identical tokens."""
+    import dataclasses
+    import time
+    base = named_dims("block_main_b4_1.2b")
+    dims = dataclasses.replace(base, name="b4_1.2b_2layer", bd=dataclasses.replace(base.bd, layers=2),
+                               td=dataclasses.replace(base.td, layers=2))
+    sd = random_state_dict(dims, seed=8, include_unused_embed_in=False)
+    model = load_block_transformer_from_dims(dims, "fp32", keep_unused_embed_in=False)
+    model.load_state_dict(sd, strict=True)
+    model = model.bfloat16().to(DEV)
+    B, P, D = 1024, 64, 128
+    prompt, eos, _ = _two_group_eos_case(model, dims, B, P, D, seed=5)
+    gcfg = model.token_decoder.generation_config
+    gcfg.eos_token_id = eos
+    times, outs = {}, {}
+    try:
+        for compact in (True, False, True, False):
+            model.compact_finished = compact
+            model.generate(prompt.to(DEV), max_length=P + D)            # warm-up: engines, graphs
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = model.generate(prompt.to(DEV), max_length=P + D)
+            torch.cuda.synchronize()
+            times.setdefault(compact, []).append(time.perf_counter() - t0)
+            outs[compact] = out.cpu()
+        assert torch.equal(outs[True], outs[False])
+        t_c, t_m = min(times[True]), min(times[False])
+        print(f"[compaction] B={B}: compacted {t_c * 1e3:.1f} ms vs masked {t_m * 1e3:.1f} ms -> {t_m / t_c:.2f}x")
+        assert t_m / t_c >= 1.25, (t_c, t_m)
+    finally:
+        gcfg.eos_token_id = None
+        model.compact_finished = True
+    del model
+    torch.cuda.empty_cache()
+
+
 def test_fp32_production_dims_one_layer_logits_within_1e3():
     """north_star tolerance at PRODUCTION tensor dims: fp32 instantiation, one layer per decoder, H = 2048, d = 128,
     rot = 32, I = 8192, V = 50304: context, first-token logits within 1e-3 of the CPU oracle, greedy tokens equal."""

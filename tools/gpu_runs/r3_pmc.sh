@@ -39,6 +39,8 @@ python tools/summarize_prof.py pmc $O/r3_pmc_local_B/*/ --kernel "local_attend_k
 python tools/summarize_prof.py traffic $O/r3_pmc_attn_F/*/ $O/r3_pmc_attn_W/*/ --kernel attend_rows_kernel \
    --shape "B=1024, 16 heads, d=128, n=528 keys, bf16" --algorithmic-bytes 4429185024 --key attn_rows \
    --kernel-name "attend_rows_kernel<bf16, 128, 4, false, false>" --git $GIT --update $O/r3_pmc_traffic.json > /dev/null
+# the rocprofv3 databases are large (gpurun merges at most 64 MiB back): keep the json summaries only
+rm -rf $O/r3_pmc_*/
 cat $O/r3_pmc_traffic.json
 for f in $O/r3_pmc_gemm_plain_A.json $O/r3_pmc_gemm_gelu_A.json $O/r3_pmc_gemm_res_A.json $O/r3_pmc_gemm_dec_A.json $O/r3_pmc_local_A.json $O/r3_pmc_flash_A.json; do echo $f; grep -A8 derived $f | tr -d '\n '; echo; done
 tail -3 $O/r3_pmc_gemm_plain_A.log
