@@ -2252,6 +2252,202 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
     if (!grp1) cbarrier();
 }
 
+// ---- 256 x 128 tiles, one per workgroup: the decode projections onto the residual stream at M = 4096 (N = 2048) ----------------------
+// attention.dense (K = 2048) and mlp.dense_4h_to_h (K = 8192) of a 4096-row decode step are 16 x 8 = 128 tiles of 256 x 256 -- half
+// of the chip for the persistent kernel -- and ran on the 4-wave 128 x 128 kernel at 0.78 / 0.96 PF (0.81-0.85 of the vendor
+// library, profiles/r3_vendor_hipblaslt.jsonl).  This kernel gives every CU exactly one 256 x 128 tile of such a problem with the
+// persistent kernel's machinery cut down to what one tile needs:
+//   * K-tile = three 16 KiB half-tiles [A rows 0-127 | A rows 128-255 | W rows 0-127], ring of two K-tiles (96 KiB);
+//   * 8 waves = two staggered groups; a wave owns 64 rows of each A half x 32 columns (64 accumulator registers);
+//     phase 0 reads A0 + W and runs 16 MFMAs, phase 1 reads A1 and runs 16;
+//   * half-tile s (consumption order A0, W, A1) is issued 5 ahead: A1 of K-tile t+1 in phase (t, 0), A0 and W of t+2 in (t, 1); three
+//     half-tiles = 6 DMA instructions stay in flight at every wait of the steady state (vmcnt(6)), the last two K-tiles
+//     drain (vmcnt(0));  RAW / WAR as in the persistent kernel (every wave waits for its share before the barrier that opens
+//     the reading phase; a slot is refilled one barrier after its last read was issued): tests/test_gemm_ring_schedule.py;
+//   * epilogue after the loop (nothing is in flight, the ring is free): bias in fp32, fragment -> wave-private LDS patch -> 16
+//     bytes per lane along rows, residual joined in the store layout, descriptor-addressed loads / stores.
+// Requires M % 256 == 0, N % 128 == 0, K % 64 == 0, K >= 256 (full tiles only: no clamping code).
+constexpr int T21_STAGE = 3 * HALF_BYTES;          // one K-tile of the ring
+constexpr int T21_SMEM = 2 * T21_STAGE;
+constexpr int T21_PATCH_PITCH = 80;                // 32 columns x 2 B + 16 pad
+constexpr int T21_WAIT = 6;
+
+template <bool RES>
+__global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_kernel(const bf16* __restrict__ A, int64_t lda,
+                                                                   const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
+                                                                   int K, int tiles_m, int tiles_n) {
+    __shared__ __attribute__((aligned(16))) char smem[T21_SMEM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool grp1 = wave >= 4;
+    int tm, tn;
+    {
+        const int nwg = tiles_m * tiles_n;
+        const int bid = blockIdx.x;
+        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        const int group_sz = GROUP_M2 * tiles_n;
+        const int g = id / group_sz;
+        const int first_m = g * GROUP_M2;
+        const int gm = min(tiles_m - first_m, GROUP_M2);
+        const int in_g = id - g * group_sz;
+        tm = first_m + in_g % gm;
+        tn = in_g / gm;
+    }
+    const int m0 = tm * 256, n0 = tn * 128;
+    const uint32_t lane_slot = (uint32_t)(((lane & 7) ^ ((lane >> 3) & 7)) * 16);
+    uint32_t voff_a = (uint32_t)(lane >> 3) * (uint32_t)(lda * 2) + lane_slot;
+    uint32_t voff_w = (uint32_t)(lane >> 3) * (uint32_t)(ldw * 2) + lane_slot;
+    const uint32_t row8_a = (uint32_t)(8 * lda * 2), row8_w = (uint32_t)(8 * ldw * 2);
+    const char* pa0 = reinterpret_cast<const char*>(A) + (int64_t)(m0 + wave * 16) * lda * 2;
+    const char* pa1 = pa0 + (int64_t)128 * lda * 2;
+    const char* pw = reinterpret_cast<const char*>(W) + (int64_t)(n0 + wave * 16) * ldw * 2;
+    const uint32_t ring_lds = lds_addr(smem) + (uint32_t)wave * 2048u;
+    const int nk = K / BK;
+    // load cursor: K-tile lt, ring buffer lt & 1; the lane offsets advance with it
+    int lt = 0;
+    auto issue_a = [&](auto hc) {
+        constexpr int half = decltype(hc)::value;
+        const uint32_t ring = ring_lds + (uint32_t)(lt & 1) * (uint32_t)T21_STAGE;
+        glds16_sbase_off<half * HALF_BYTES>(half ? pa1 : pa0, voff_a, ring);
+        glds16_sbase_off<half * HALF_BYTES + 1024>(half ? pa1 : pa0, voff_a + row8_a, ring);
+    };
+    auto issue_w = [&]() {
+        const uint32_t ring = ring_lds + (uint32_t)(lt & 1) * (uint32_t)T21_STAGE;
+        glds16_sbase_off<2 * HALF_BYTES>(pw, voff_w, ring);
+        glds16_sbase_off<2 * HALF_BYTES + 1024>(pw, voff_w + row8_w, ring);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    // prologue: K-tile 0 (A0, W, A1) and A0, W of K-tile 1 -- in consumption order
+    issue_a(I0{});
+    issue_w();
+    issue_a(I1{});
+    ++lt;
+    voff_a += 128;
+    voff_w += 128;
+    if (nk > 1) {
+        issue_a(I0{});
+        issue_w();
+    }
+    // (the cursor now stands at K-tile 1 with A1 outstanding)
+
+    f32x4_t acc[8][2];   // [A half * 4 + m-fragment][n-fragment]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t af[4][2], wf[2][2];
+
+    auto wait = [&](bool steady) {
+        if (steady) wait_vmcnt<T21_WAIT>();
+        else wait_vmcnt<0>();
+    };
+    if (grp1) {
+        wait(nk >= 3);
+        cbarrier();
+    }
+    for (int t = 0; t < nk; ++t) {
+        const bool steady = t + 3 <= nk;            // K-tiles 0 .. nk-3: three younger half-tiles are in flight at every wait
+        const char* buf = smem + (t & 1) * T21_STAGE;
+        // ---- phase 0: A0, W ----
+        if (!grp1) wait(steady);
+        cbarrier();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) wf[nb][ks] = read_frag(buf + 2 * HALF_BYTES, wn * 32 + nb * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i][ks] = read_frag(buf, wm * 64 + i * 16, ks, lane);
+        }
+        if (t + 1 < nk) issue_a(I1{});              // A1 of K-tile t + 1 (cursor at t + 1)
+        if (grp1) wait(steady);
+        cbarrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][ks], af[i][ks], acc[i][nb], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        // ---- phase 1: A1 ----
+        if (!grp1) wait(steady);
+        cbarrier();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i][ks] = read_frag(buf + HALF_BYTES, wm * 64 + i * 16, ks, lane);
+        ++lt;                                         // cursor -> K-tile t + 2
+        voff_a += 128;
+        voff_w += 128;
+        if (t + 2 < nk) {
+            issue_a(I0{});
+            issue_w();
+        }
+        if (grp1) wait(t + 4 <= nk);                // (its wait for phase 0 of K-tile t + 1: steady while t + 1 <= nk - 3)
+        cbarrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[4 + i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][ks], af[i][ks], acc[4 + i][nb], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    }
+    if (!grp1) cbarrier();
+    // ---- epilogue ----
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                  // every wave is past its last fragment read: the ring is free
+    char* patch = smem + wave * (16 * T21_PATCH_PITCH);
+    const int n_wave = n0 + wn * 32;
+    float bias_v[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (ep.bias) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const uint2 b2 = *reinterpret_cast<const uint2*>(ep.bias + n_wave + nb * 16 + (lane >> 4) * 4);
+            bias_v[nb][0] = __uint_as_float(b2.x << 16); bias_v[nb][1] = __uint_as_float(b2.x & 0xffff0000u);
+            bias_v[nb][2] = __uint_as_float(b2.y << 16); bias_v[nb][3] = __uint_as_float(b2.y & 0xffff0000u);
+        }
+    }
+    const __amdgpu_buffer_rsrc_t out_rsrc = tile_rsrc(reinterpret_cast<const char*>(ep.out) + ((int64_t)m0 * ep.ldo + n_wave) * 2);
+    const uint32_t out_voff = ((uint32_t)(lane >> 2) * (uint32_t)ep.ldo + (uint32_t)(lane & 3) * 8u) * 2u;
+    uint4 rres[8];
+    if (RES) {
+        const __amdgpu_buffer_rsrc_t res_rsrc = tile_rsrc(reinterpret_cast<const char*>(ep.res) + ((int64_t)m0 * ep.ldr + n_wave) * 2);
+        const uint32_t res_voff = ((uint32_t)(lane >> 2) * (uint32_t)ep.ldr + (uint32_t)(lane & 3) * 8u) * 2u;
+#pragma unroll
+        for (int ai = 0; ai < 8; ++ai) {
+            const int row_l = (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16;
+            const u32x4_t r4 = __builtin_amdgcn_raw_buffer_load_b128(res_rsrc, res_voff, (uint32_t)row_l * (uint32_t)ep.ldr * 2u, 0);
+            rres[ai] = uint4{r4.x, r4.y, r4.z, r4.w};
+        }
+    }
+#pragma unroll
+    for (int ai = 0; ai < 8; ++ai) {
+        const int row_l = (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16;
+        // accumulator layout: row (lane & 15), columns nb * 16 + (lane >> 4) * 4 .. + 3  ->  patch[row][col]
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            uint2 o;
+            o.x = pack_bf16x2(acc[ai][nb][0] + bias_v[nb][0], acc[ai][nb][1] + bias_v[nb][1]);
+            o.y = pack_bf16x2(acc[ai][nb][2] + bias_v[nb][2], acc[ai][nb][3] + bias_v[nb][3]);
+            *reinterpret_cast<uint2*>(patch + (lane & 15) * T21_PATCH_PITCH + (nb * 16 + (lane >> 4) * 4) * 2) = o;
+        }
+        // (wave-private patch: the LDS pipeline executes a wave's writes and reads in order)
+        uint4 v = *reinterpret_cast<const uint4*>(patch + (lane >> 2) * T21_PATCH_PITCH + (lane & 3) * 16);
+        if (RES) v = add_bf16x8(v, rres[ai]);
+        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{v.x, v.y, v.z, v.w}, out_rsrc, out_voff,
+                                               (uint32_t)row_l * (uint32_t)ep.ldo * 2u, 0);
+    }
+}
+
 // ---- GEMV for a handful of rows (M <= 4): the weight-streaming regime of small-batch decode ------------------------------
 // out[m, n] = epi(sum_k x[m, k] * W[n, k]).  One pass over W at HBM speed is the whole cost (N*K*2 bytes; x is a few KiB), so
 // the kernel is a pure streamer: a wave owns RW rows of W, every lane keeps 4 x 16-byte loads per row in flight (a 2048-wide
@@ -3099,6 +3295,18 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                 }
             }
 #undef BT_LAUNCH_256
+        } else if (mfma_ok && !seg2 && !ep.q.enabled && act == BT_ACT_NONE && g_gemm_variant == 0 && M % 256 == 0 && N % 128 == 0 &&
+                   K / BK >= 4 && (M / 256) * (N / 128) > 192 && (M / 256) * (N / 128) <= 256 && (ldo % 8 == 0) && aligned16(out) &&
+                   (!residual || (ldr % 8 == 0 && aligned16(residual))) && (K % 8 == 0)) {
+            // one 256 x 128 tile per CU: the decode projections onto the residual stream (M = 4096, N = 2048: 256 tiles)
+            ProfScope ps(BT_PROF_LINEAR_MFMA, s);
+            const int tiles_m = (int)(M / 256), tiles_n = (int)(N / 128);
+            if (residual)
+                hipLaunchKernelGGL((gemm_bf16_mfma256x128_kernel<true>), dim3(tiles_m * tiles_n), dim3(512), 0, s, (const bf16*)A, lda,
+                                   (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);
+            else
+                hipLaunchKernelGGL((gemm_bf16_mfma256x128_kernel<false>), dim3(tiles_m * tiles_n), dim3(512), 0, s, (const bf16*)A, lda,
+                                   (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);
         } else if (!seg2 && M <= 4 && !ep.q.enabled && g_gemm_variant != 1 && g_gemm_variant != 22 && (K % 512 == 0) && (lda % 8 == 0) &&
                    (K % 8 == 0) && aligned16(A) && aligned16(W) && !g_force_generic) {
             // a handful of rows: pure weight streaming (one launch, no fp32 partials).  Measured (bench.py, hipGraph replay):

@@ -352,3 +352,80 @@ def test_persistent_v2_model_detects_errors():
         pp_model(8, 3, [True] * 3, [PP_STORES] * 3, stream=functools.partial(_pp2_stream, bad="late_store_wait"))
     with pytest.raises(AssertionError):                   # boundary refill without its barrier: barrier counts / WAR break
         pp_model(8, 3, [True] * 3, [PP_STORES] * 3, stream=functools.partial(_pp2_stream, bad="no_boundary_barrier"))
+
+
+# ---- one-tile 256 x 128 kernel (gemm_bf16_mfma256x128_kernel): three half-tiles per K-tile, ring of six slots ---------------------
+T21_WAIT = int(re.search(r"constexpr int T21_WAIT = (\d+);", SRC).group(1))
+
+
+def _t21_stream(grp, nk, bad=None):
+    """program order of one wave: loads in consumption order A0 = 3t, W = 3t + 1, A1 = 3t + 2; two DMA instructions each"""
+    ev = []
+
+    def dma(sidx):
+        ev.append(("vm", ("ld", sidx)))
+        ev.append(("vm", ("ld", sidx)))
+
+    def wait(steady):
+        ev.append(("wait", T21_WAIT if steady else 0))
+
+    for sidx in (0, 1, 2):
+        dma(sidx)
+    if nk > 1:
+        dma(3)
+        dma(4)
+    if grp == 1:
+        wait(nk >= 3)
+        ev.append(("bar",))
+    for t in range(nk):
+        steady = t + 3 <= nk
+        if bad == "always_steady":
+            steady = True
+        if grp == 0:
+            wait(steady)
+        ev.append(("bar",))
+        ev.append(("read", ("ld", 3 * t)))
+        ev.append(("read", ("ld", 3 * t + 1)))
+        if t + 1 < nk:
+            dma(3 * (t + 1) + 2)
+        if grp == 1:
+            wait(steady)
+        ev.append(("bar",))
+        if grp == 0:
+            wait(steady)
+        ev.append(("bar",))
+        ev.append(("read", ("ld", 3 * t + 2)))
+        if t + 2 < nk:
+            dma(3 * (t + 2))
+            dma(3 * (t + 2) + 1)
+        if grp == 1:
+            wait(t + 4 <= nk or bad == "always_steady")
+        ev.append(("bar",))
+    if grp == 0:
+        ev.append(("bar",))
+    return ev
+
+
+def t21_model(nk, bad=None):
+    waves = {g: _pp_analyse(_t21_stream(g, nk, bad)) for g in (0, 1)}
+    assert len({v[3] for v in waves.values()}) == 1, "barrier counts differ between wave groups"
+    last_read = {}
+    for key, (issue, done, reads, _) in waves.items():
+        for tag, b in reads:
+            last_read[tag] = max(last_read.get(tag, -1), b)
+            for okey, (oissue, odone, _, _) in waves.items():
+                assert tag in odone and odone[tag] <= b - 1, f"RAW nk={nk}: {tag} read by group {key} not waited by group {okey}"
+    for key, (issue, done, reads, _) in waves.items():
+        for tag, b in list(issue.items()):
+            if tag[0] == "ld" and tag[1] >= 6:
+                assert b >= last_read[("ld", tag[1] - 6)] + 1, f"WAR nk={nk}: {tag} issued by group {key} too early"
+
+
+@pytest.mark.parametrize("nk", [1, 2, 3, 4, 5, 8, 32, 128])
+def test_one_tile_256x128_schedule(nk):
+    t21_model(nk)
+
+
+def test_one_tile_256x128_model_detects_a_missing_drain():
+    with pytest.raises(AssertionError, match="RAW"):
+        t21_model(8, bad="always_steady")

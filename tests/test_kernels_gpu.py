@@ -159,6 +159,36 @@ def test_linear_persistent_kernel(M, N, K, variant, max_wg, kernel, dbg_lib):
     assert float((err - 1.6e-2 * ref.abs() - 2e-2).max()) <= 0, float(err.max())
 
 
+@pytest.mark.parametrize("M,N,K", [(4096, 2048, 2048), (4096, 2048, 8192), (2048, 4096, 512), (1024, 6400, 256), (3328, 1920, 320)])
+@pytest.mark.parametrize("variant", ["plain", "bias", "bias_res", "res_inplace"])
+def test_linear_256x128_one_tile_kernel(M, N, K, variant):
+    """gemm_bf16_mfma256x128_kernel (one 256 x 128 tile per CU; the dispatch takes it for 193..256 such tiles, e.g. the decode
+    projections onto the residual stream at M = 4096, N = 2048) through the product library against fp64: plain / bias /
+    residual, in-place residual (x += ...), K = 256 (every K-tile in the drain path) to 8192, tile counts 195 / 200 / 256."""
+    assert (M // 256) * (N // 128) > 192 and (M // 256) * (N // 128) <= 256 and M % 256 == 0 and N % 128 == 0
+    x = rnd(M, K, seed=1).bfloat16()
+    w = rnd(N, K, seed=2, scale=K ** -0.5).bfloat16()
+    b = rnd(N, seed=3).bfloat16() if variant.startswith("bias") else None
+    r = rnd(M, N, seed=4).bfloat16() if "res" in variant else None
+    xd, wd = x.to(DEV), w.to(DEV)
+    ref = (xd.double() @ wd.double().T).cpu()
+    if b is not None:
+        ref = ref + b.double()
+    if r is not None:
+        ref = ref + r.double()
+    rd = None if r is None else r.to(DEV)
+    if variant == "res_inplace":
+        out = rd
+        ops.linear(xd, wd, None, rd, out=out)
+    else:
+        out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+        ops.linear(xd, wd, None if b is None else b.to(DEV), rd, out=out)
+    out = out.cpu()
+    assert rel_err(out, ref) <= 1.2e-2, rel_err(out, ref)
+    err = (out.double() - ref).abs()
+    assert float((err - 1.6e-2 * ref.abs() - 2e-2).max()) <= 0, float(err.max())
+
+
 @pytest.mark.parametrize("kernel", [12, 14])
 def test_linear_persistent_inplace_residual_and_strides(kernel, dbg_lib):
     """hidden += x @ W^T through the persistent kernels, in place (res == out), row strides > row length."""

@@ -164,7 +164,7 @@ def probe_copy(nbytes, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=["gemm", "attn", "flash", "suite", "copy", "ab", "abl", "skinny", "decode", "vendor", "pitch",
-                                     "local", "lin2", "ln", "ppabl", "ppstore", "ppv2", "ppepi", "ppab"])
+                                     "local", "lin2", "ln", "ppabl", "ppstore", "ppv2", "ppepi", "ppab", "t21"])
     ap.add_argument("--m", type=int, default=32768)
     ap.add_argument("--n", type=int, default=6144)
     ap.add_argument("--k", type=int, default=2048)
@@ -422,6 +422,29 @@ def main():
                 rec["b_TF"] = round(2.0 * M * N * K / min(rec["b_us"]) / 1e6, 1)
                 res.append(rec)
         hooks.bt_debug_gemm_variant(0)
+    elif args.what == "t21":
+        # the decode projections onto the residual stream at M = 4096: one-tile 256 x 128 kernel (production dispatch, variant 0) vs
+        # the 128^2 kernel (variant 1) vs torch F.linear (hipBLASLt), interleaved
+        import torch.nn.functional as F
+        for (M, N, K) in ((4096, 2048, 2048), (4096, 2048, 8192)):
+            x = torch.randn(M, K, device=DEV).bfloat16()
+            w = (torch.randn(N, K, device=DEV) * K ** -0.5).bfloat16()
+            b = torch.randn(N, device=DEV).bfloat16()
+            r = torch.randn(M, N, device=DEV).bfloat16()
+            out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+            for mode, res_ in (("bias", None), ("bias_res", r)):
+                rec = {"op": "t21", "M": M, "N": N, "K": K, "mode": mode}
+                for rep in range(3):
+                    for name, v in (("t256x128_us", 0), ("t128x128_us", 1)):
+                        hooks.bt_debug_gemm_variant(v)
+                        ms = timed(lambda: ops.linear(x, w, b, res_, out=out), 20)
+                        rec.setdefault(name, []).append(round(ms * 1e3, 1))
+                    hooks.bt_debug_gemm_variant(0)
+                    ms = timed(lambda: F.linear(x, w, b), 20)
+                    rec.setdefault("vendor_us", []).append(round(ms * 1e3, 1))
+                fl = 2.0 * M * N * K / 1e6
+                rec["TF"] = {k[:-3]: round(fl / min(v), 1) for k, v in rec.items() if k.endswith("_us")}
+                res.append(rec)
     elif args.what == "abl":
         for (M, N, K) in ((32768, 6144, 2048), (32768, 2048, 8192)):
             for v in (0, 3, 20, 21, 8, 0, 3, 20, 21, 8):   # production / 4-phase one-tile kernel: full, no MFMA, DMA only, MFMA+barriers only
