@@ -118,6 +118,8 @@ _SIGS = {
     "bt_event_destroy": (c_int, [c_void_p]),
     "bt_prof_enable": (c_int, [c_int]),
     "bt_prof_collect": (c_int, [POINTER(ctypes.c_double), POINTER(c_int64), c_int]),
+    "bt_prof_trace": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_int32), c_int64,
+                            POINTER(c_int64)]),
 }
 
 # test / A-B hooks: exported by libbt_hip_dbg.so only
@@ -196,6 +198,19 @@ def prof_collect() -> dict:
     cnt = (c_int64 * n)()
     check(lib().bt_prof_collect(ms, cnt, n), "bt_prof_collect")
     return {PROF_FAMILIES[i]: (ms[i], cnt[i]) for i in range(n)}
+
+
+def prof_trace() -> list:
+    """[(family, start_ms, dur_ms)] of every bracketed launch since prof_enable(True), in launch order (call before prof_collect)."""
+    n = c_int64(0)
+    check(lib().bt_prof_trace(None, None, None, 0, ctypes.byref(n)), "bt_prof_trace")
+    if n.value == 0:
+        return []
+    start = (ctypes.c_double * n.value)()
+    dur = (ctypes.c_double * n.value)()
+    fam = (ctypes.c_int32 * n.value)()
+    check(lib().bt_prof_trace(start, dur, fam, n.value, ctypes.byref(n)), "bt_prof_trace")
+    return [(PROF_FAMILIES[fam[i]], start[i], dur[i]) for i in range(n.value)]
 
 
 def check(rc: int, what: str = "") -> None:

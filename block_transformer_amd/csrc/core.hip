@@ -126,6 +126,30 @@ extern "C" int bt_prof_enable(int on) {
     return BT_OK;
 }
 
+extern "C" int bt_prof_trace(double* start_ms, double* dur_ms, int32_t* family, int64_t capacity, int64_t* n_out) {
+    BT_CHECK_ARG(n_out && capacity >= 0 && (capacity == 0 || (start_ms && dur_ms && family)), "bt_prof_trace: bad arguments");
+    const int64_t n = (int64_t)bt::g_prof_recs.size();
+    *n_out = n;
+    if (capacity == 0) return BT_OK;   // size query
+    BT_CHECK_ARG(capacity >= n, "bt_prof_trace: capacity below the record count (query with capacity 0 first)");
+    for (int64_t i = 0; i < n; ++i) {
+        const auto& r = bt::g_prof_recs[(size_t)i];
+        hipError_t e = hipEventSynchronize(r.b);
+        if (e != hipSuccess) return bt::hip_fail(e, "hipEventSynchronize");
+        float t0 = 0.f, d = 0.f;
+        if (i > 0) {
+            e = hipEventElapsedTime(&t0, bt::g_prof_recs[0].a, r.a);
+            if (e != hipSuccess) return bt::hip_fail(e, "hipEventElapsedTime");
+        }
+        e = hipEventElapsedTime(&d, r.a, r.b);
+        if (e != hipSuccess) return bt::hip_fail(e, "hipEventElapsedTime");
+        start_ms[i] = t0;
+        dur_ms[i] = d;
+        family[i] = r.fam;
+    }
+    return BT_OK;
+}
+
 extern "C" int bt_prof_collect(double* ms_out, int64_t* count_out, int n_fam) {
     BT_CHECK_ARG(ms_out && count_out && n_fam == BT_PROF_NFAM, "bt_prof_collect: bad arguments");
     for (int i = 0; i < n_fam; ++i) {

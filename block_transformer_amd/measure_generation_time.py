@@ -61,11 +61,46 @@ def generate_with_block_model_and_measure_time(model: BlockTransformer, prefill_
     start = torch.cuda.Event(enable_timing=True)
     end = torch.cuda.Event(enable_timing=True)
     start.record()
-    output = model.generate(input_ids.to(DEVICE), max_length=max_length, benchmark=False)
+    if log_path is None:
+        output = model.generate(input_ids.to(DEVICE), max_length=max_length, benchmark=False)
+    else:
+        output = _generate_profiled(model, input_ids.to(DEVICE), max_length, log_path)
     end.record()
     assert output.shape[1] == max_length, output.shape
     torch.cuda.synchronize()
     return start.elapsed_time(end)
+
+
+def _generate_profiled(model: BlockTransformer, input_ids, max_length: int, log_path: str):
+    """The reference wraps this generate() in torch.profiler and exports a Chrome trace (measure_generation_time.py:150-155).
+    The kernels here are launched by libbt_hip, so the trace comes from its own timer: the generate runs eagerly (no graph
+    replay -- a replayed graph is one opaque launch) with a hipEvent pair around every kernel, the ten most expensive
+    kernel families are printed and every launch becomes one complete ("X") event of a chrome://tracing / Perfetto file."""
+    import json
+    from . import _lib
+    graphs = model.use_graphs
+    model.use_graphs = False
+    _lib.prof_enable(True)
+    try:
+        output = model.generate(input_ids, max_length=max_length, benchmark=False)
+        torch.cuda.synchronize()
+        launches = _lib.prof_trace()
+        families = _lib.prof_collect()
+    finally:
+        _lib.prof_enable(False)
+        model.use_graphs = graphs
+    total = sum(ms for ms, _ in families.values()) or 1.0
+    print(f"{'kernel family':<18}{'GPU ms':>12}{'%':>8}{'launches':>10}{'avg us':>10}")
+    for name, (ms, n) in sorted(families.items(), key=lambda kv: -kv[1][0])[:10]:
+        if n:
+            print(f"{name:<18}{ms:>12.3f}{100 * ms / total:>8.2f}{n:>10d}{1e3 * ms / n:>10.1f}")
+    events = [{"name": fam, "cat": "kernel", "ph": "X", "pid": 0, "tid": 0, "ts": 1e3 * t0, "dur": 1e3 * d}
+              for fam, t0, d in launches]
+    events.append({"name": "process_name", "ph": "M", "pid": 0, "args": {"name": "libbt_hip launch stream (eager)"}})
+    with open(log_path, "w") as f:
+        json.dump({"traceEvents": events, "displayTimeUnit": "ms"}, f)
+    print(f"trace of {len(launches)} launches written to {log_path}")
+    return output
 
 
 def measure_generation(model, prefill_length, decode_length, batch_size, log_path=None) -> Dict:
@@ -197,6 +232,14 @@ def main(argv=None):
         total_memory = float(cfg["benchmark_memory_limit_gib"])
     min_free = float(cfg.get("benchmark_min_free_gib", 2))
     output_path = os.path.join(cfg.get("save_dir") or SAVE_DIR, cfg.get("output_dir") or cfg["name"], "generation_time.csv")
+    # ++profiling=true [++log_path=dir]: one trace file per measured batch size (reference :381-390, :460-463)
+    log_dir = None
+    if cfg.get("profiling", False):
+        log_dir = cfg.get("log_path") or os.path.join(cfg.get("save_dir") or SAVE_DIR, "profiler")
+        os.makedirs(log_dir, exist_ok=True)
+
+    def trace_path(b):
+        return None if log_dir is None else os.path.join(log_dir, f"{cfg['name']}_{b}_{P}_{D}.log")
     data: List[Dict] = []
     if os.path.exists(output_path):
         print("Reading existing measurement data")
@@ -205,14 +248,14 @@ def main(argv=None):
     if batch_sizes is None:
         for b in (1, 2):
             if not measurement_exists(data, b, P, D):
-                data.append(measure_generation(model, P, D, b))
+                data.append(measure_generation(model, P, D, b, trace_path(b)))
         while total_memory - get_max_batch_size_row(data, P, D)["max_memory_allocated"] >= min_free:
             nxt = find_next_batch_size(data, P, D, total_memory)
             if nxt is None:
                 break
             if predict_oom(data, nxt, P, D):
                 raise AssertionError("Something is wrong with the measurements")
-            data.append(measure_generation(model, P, D, nxt))
+            data.append(measure_generation(model, P, D, nxt, trace_path(nxt)))
     else:
         for b in batch_sizes:
             if measurement_exists(data, b, P, D):
@@ -220,7 +263,7 @@ def main(argv=None):
             elif predict_oom(data, b, P, D):
                 print(f"Skipping batch size {b} as it is predicted to OOM")
             else:
-                data.append(measure_generation(model, P, D, b))
+                data.append(measure_generation(model, P, D, b, trace_path(b)))
     df = pd.DataFrame(data).sort_values(["prefill_length", "decode_length", "batch_size"])
     os.makedirs(os.path.dirname(output_path), exist_ok=True)
     df.to_csv(output_path)

@@ -349,6 +349,11 @@ enum bt_prof_family {
 };
 int bt_prof_enable(int on);                                          /* clears previous records */
 int bt_prof_collect(double* ms_out, int64_t* count_out, int n_fam); /* n_fam = BT_PROF_NFAM */
+/* Per-launch records of the same timer, in launch order: start (ms after the first record's start), duration (ms) and
+ * family of every bracketed launch since bt_prof_enable(1).  capacity = 0 only returns the count in *n_out.  Does not
+ * clear the records (bt_prof_collect / bt_prof_enable do).  Replaces the role of torch.profiler's export_chrome_trace in
+ * the reference's harness (measure_generation_time.py:150-155): the harness counterpart writes these as trace events. */
+int bt_prof_trace(double* start_ms, double* dur_ms, int32_t* family, int64_t capacity, int64_t* n_out);
 
 #ifdef __cplusplus
 }

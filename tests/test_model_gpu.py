@@ -1190,6 +1190,29 @@ def test_measure_generation_time_main_runs(tmp_path):
     assert float(df["max_memory_allocated"].max()) <= limit + 0.2
 
 
+def test_measure_generation_time_profiling_writes_a_trace(tmp_path, capsys):
+    """++profiling=true (reference measure_generation_time.py:381-390,150-155): the timed generate runs with the library's
+    kernel timer, prints the family table and writes one Chrome-trace file per batch size; launches are ordered and
+    disjoint in time (one stream), and their families are the ones a decode uses."""
+    import json
+    from block_transformer_amd import measure_generation_time as mgt
+    df = mgt.main(["--config-name", "block_main_b4_5", "++benchmark_batch_sizes=[3]", "++output_dir=prof", "++profiling=true",
+                   f"++log_path={tmp_path / 'traces'}", "++block_decoder.config.num_hidden_layers=1",
+                   "++token_decoder.config.num_hidden_layers=1", "++benchmark_prefill_length=32",
+                   "++benchmark_decode_length=16", f"++save_dir={tmp_path}"])
+    assert list(df["batch_size"]) == [3]
+    text = capsys.readouterr().out
+    assert "kernel family" in text and "attn_rows" in text
+    files = list((tmp_path / "traces").iterdir())
+    assert len(files) == 1 and files[0].name.endswith("_3_32_16.log")
+    ev = [e for e in json.load(open(files[0]))["traceEvents"] if e["ph"] == "X"]
+    assert len(ev) > 50
+    assert {"linear_mfma", "linear_generic"} & {e["name"] for e in ev} and "attn_rows" in {e["name"] for e in ev}
+    for a, b in zip(ev, ev[1:]):
+        assert b["ts"] >= a["ts"] and a["dur"] > 0
+        assert b["ts"] + 1.0 >= a["ts"] + a["dur"], (a, b)     # 1 us slack: hipEvent timestamps are quantised
+
+
 def test_inference_demo_main_runs(capsys):
     """The harness counterpart of inference_demo.py end to end (random init: no checkpoint / tokenizer on the box):
     sampling with temperature, streamer attached, throughput report."""
