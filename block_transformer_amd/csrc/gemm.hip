@@ -1982,7 +1982,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
 // ---- persistent kernel, second generation of the K-loop (round 3) --------------------------------------------------------------
 // Same tile walk, LDS ring, fragment mapping, MFMA order, per-wave epilogue and -- phase for phase -- the same vmcnt values as
 // gemm_bf16_mfma256pp_kernel; what changes is the SCALAR code around them.  The round-3 timing ablations
-// (profiles/r3_pp_ablation.md) showed the MFMA + barrier skeleton of that kernel at 1.63 PF and the full kernel at 1.07-1.25 PF,
+// (profiles/r3_pp_v1_ablation.jsonl) showed the MFMA + barrier skeleton of that kernel at 1.63 PF and the full kernel at 1.07-1.25 PF,
 // and its ISA showed why: every phase ran a ~30-instruction SALU branch tree to pick its s_waitcnt immediate BETWEEN the MFMA
 // cluster and the barrier the partner wave group is parked at (pure matrix-pipe idle time, four times per K-tile), and each
 // half-tile issue recomputed a 64-bit row address with s_mul_hi / s_mul chains (~25 SALU per half-tile).  Here:
@@ -1994,7 +1994,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
 //     128 B per K-tile): one s_add into M0 + the DMA per instruction, four v_add per K-tile, no multiplies; tiles cut by the
 //     matrix edge keep the per-lane clamped path (stage_half_at).
 //   * tile boundary: a tile's 128 output stores (16 per wave) occupy the CU's vector-memory pipe for ~5 us (~16 cycles per VGPR
-//     operand of a VMEM instruction; profiles/r3_pp_epilogue_parts.md: the cost scales with the NUMBER of stores, whatever their
+//     operand of a VMEM instruction; profiles/r3_pp2_store_count_scaling.jsonl: the cost scales with the NUMBER of stores, whatever their
 //     destination), and everything issued behind them queues.  So the two half-tiles the next tile's first phase would issue
 //     (W1, A1 of its K-tile 1) go out BEFORE the epilogue's stores, behind one extra barrier per tile (their slots were last read
 //     in the tile's final phase): the ring then holds two full K-tiles = four phases of MFMA work that do not depend on anything
@@ -3147,7 +3147,7 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
         }
         const int64_t tiles256 = ceil_div(M, BM2) * ceil_div(N, BN2);
         // big-tile kernel: one 8-wave workgroup per CU -> needs >= ~3/4 of a wave of 256 tiles and little tail quantisation
-        // (round 3, profiles/r3_decode_shapes.jsonl + r3_ppv2.jsonl: M = 4096, N = 6144 = 384 tiles runs 94 us on the persistent
+        // (round 3, profiles/r3_decode_shapes.jsonl + r3_pp_v1_vs_v2.jsonl: M = 4096, N = 6144 = 384 tiles runs 94 us on the persistent
         //  kernel vs 130 us on the 128^2 kernel, M = 2048, N = 6144 = 192 tiles 57 vs 70 us; 128 tiles lose: 54 vs 44 us)
         const bool pp_ok = (N % 8 == 0) && (ldo % 8 == 0) && aligned16(out) && (K + s2.K) / BK >= 4 &&
                            (!residual || (ldr % 8 == 0 && aligned16(residual))) && (!bias || aligned16(bias));

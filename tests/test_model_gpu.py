@@ -1240,6 +1240,44 @@ def _mid_stack(layers=2, hidden=512, heads=4, inter=2048, seed=31):
     return model, dims, oracle_from_dims(dims, sd16)
 
 
+@pytest.mark.parametrize("B,q_len", [(32, 1), (2, 1), (300, 1), (16, 2)])
+def test_decoder_forward_rejects_cache_overflow_before_any_launch(B, q_len):
+    """a C caller of bt_decoder_forward with a host position past the cache end gets BT_ERR_ARG and NOTHING is
+    enqueued -- on every row-count path (few-rows dual launch, 17..256-row slabs, large M), not only on the entry points the
+    fused QKV + append kernels replaced.  Called through the C-ABI directly (runtime.forward has its own Python guard)."""
+    import ctypes
+    from block_transformer_amd import _lib
+    from block_transformer_amd._lib import bt_attn_args, current_stream, dtype_code, lib, ptr
+    from block_transformer_amd.runtime import KVCache, _shared_ws
+    model, dims, _ = _mid_stack()
+    rt = model.block_decoder._rt
+    d = dims.bd
+    n_max = 8
+    cache = KVCache(d.layers, B, d.heads, n_max, d.hidden // d.heads, torch.bfloat16, DEV)
+    cache.k.fill_(3.0)
+    cache.v.fill_(3.0)
+    x = torch.zeros(B * q_len, d.hidden, dtype=torch.bfloat16, device=DEV)
+    out = torch.full((B * q_len, d.hidden), 7.0, dtype=torch.bfloat16, device=DEV)
+    ws = _shared_ws.get(rt.workspace_bytes(B * q_len), x.device)
+    rope = rt.rope(n_max)
+    pos0 = n_max - q_len + 1                                   # last row would land at index n_max
+    args = bt_attn_args(cache.k.data_ptr(), cache.v.data_ptr(), cache.layer_stride, cache.n_max, None, pos0, None, None, 0,
+                        rope[0].data_ptr(), rope[1].data_ptr(), _lib.ATTN_ROWS, 1, None, 0)
+    w = rt.weights()
+    rc = lib().bt_decoder_forward(dtype_code(x.dtype), ctypes.byref(rt.dims), ctypes.byref(w), B, q_len, ptr(x),
+                                  ctypes.byref(args), 0, ptr(out), ptr(ws), ws.numel(), current_stream())
+    torch.cuda.synchronize()
+    assert rc == -1, rc                                         # BT_ERR_ARG
+    assert b"overflow" in lib().bt_last_error().lower() or b"n_max" in lib().bt_last_error().lower()
+    assert bool((cache.k == 3.0).all()) and bool((cache.v == 3.0).all()) and bool((out == 7.0).all())
+    # one row earlier is accepted
+    args.pos0_host = pos0 - 1
+    rc = lib().bt_decoder_forward(dtype_code(x.dtype), ctypes.byref(rt.dims), ctypes.byref(w), B, q_len, ptr(x),
+                                  ctypes.byref(args), 0, ptr(out), ptr(ws), ws.numel(), current_stream())
+    torch.cuda.synchronize()
+    assert rc == 0, lib().bt_last_error()
+
+
 @pytest.mark.parametrize("M", [17, 32, 64, 128, 256])
 def test_mid_rows_decoder_stack_vs_fp32_oracle(M, dbg_lib):
     """17 .. 256 rows through bt_decoder_forward: the split-K slab GEMMs + fused reduces (bias + RoPE + KV append; bias +
