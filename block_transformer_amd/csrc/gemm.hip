@@ -2102,10 +2102,30 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
             if (lvalid) enter_tile();
         }
     };
+    // steady state inside a full tile (fast K-tiles, below): the cursor's tile is the compute tile, full, and does not end within the
+    // next two K-tiles -> no edge / validity / wrap test, and the ring stage RING is a compile-time constant of the unrolled loop
+    auto issue1_fast = [&](auto kc, auto rc) {
+        if (ABL & 1) return;
+        constexpr int kind = decltype(kc)::value, RING = decltype(rc)::value;
+        constexpr bool is_a = (kind == 0) || (kind == 3);
+        constexpr int half = (kind >= 2) ? 1 : 0;
+        constexpr int off = RING * 4 * HALF_BYTES + ((is_a ? 0 : 2) + half) * HALF_BYTES;
+        const char* base = is_a ? (half ? pa1 : pa0) : (half ? pw1 : pw0);
+        const uint32_t v0 = is_a ? voff_a : voff_w;
+        glds16_sbase_off<off>(base, v0, ring_lds);
+        glds16_sbase_off<off + 1024>(base, v0 + (is_a ? row8_a : row8_w), ring_lds);
+    };
+    auto advance_fast = [&]() {
+        ++lx;
+        ++lt;
+        voff_a += 128;
+        voff_w += 128;
+    };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>;
+    using IDyn = std::integral_constant<int, -1>;
     // prologue: K-tile 0 (4 half-tiles) + K-tile 1 (A0, W0) = PD2 loads
     issue_bias();
     issue2(I0{}, I1{}, true);
@@ -2129,8 +2149,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
     bool prev_full = false;   // the previous tile's epilogue issued PP_STORES stores per wave (a full tile) ...
     bool pre_issued = false;  // ... behind the half-tiles phase (0, 0) of this tile would have issued
     // one phase.  PM: 0 = K-tiles 0 and 1 of a tile (store-count waits behind a full tile), 1 = steady state, 2 = generic (stream tail)
-    auto phase = [&](auto pc, auto pmc, int t, int j) {
-        constexpr int p = decltype(pc)::value, PM = decltype(pmc)::value;
+    // ST >= 0: fast K-tile (PM == 1 only) whose ring stage is the compile-time constant ST -- LDS addresses become loop-invariant
+    // registers + immediates, the loads go out unconditionally
+    auto phase = [&](auto pc, auto pmc, int t, int j, auto stc) {
+        constexpr int p = decltype(pc)::value, PM = decltype(pmc)::value, ST = decltype(stc)::value;
+        static_assert(ST < 0 || PM == 1, "fast K-tiles are steady-state K-tiles");
         if (!grp1) {
             if constexpr (PM == 2) {
                 wait_for_phase_pp(g, total, false);
@@ -2142,7 +2165,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
             }
         }
         cbarrier();
-        const char* buf = smem + (g & 2) * 2 * HALF_BYTES;
+        const char* buf = smem + (ST >= 0 ? ST * 4 * HALF_BYTES : (g & 2) * 2 * HALF_BYTES);
         const bool do_reads = !(ABL & 2) || g == 0;
         if constexpr (p == 0) {
             if constexpr (PM == 0 && !(ABL & 128)) {
@@ -2157,7 +2180,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
                     for (int i = 0; i < P::MI; ++i) af[i][ks] = P::read_a(buf, wm, i, ks, lane);
                 }
             }
-            if (PM == 0 && t == 0 && pre_issued) {
+            if constexpr (ST >= 0) {     // the cursor stands one K-tile ahead: the other ring stage
+                issue1_fast(I2{}, std::integral_constant<int, 1 - ST>{});
+                issue1_fast(I3{}, std::integral_constant<int, 1 - ST>{});
+                advance_fast();
+            } else if (PM == 0 && t == 0 && pre_issued) {
                 pre_issued = false;          // issued at the tile boundary, ahead of the previous tile's stores
             } else {
                 issue2(I2{}, I3{}, PM == 2);
@@ -2170,8 +2197,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
 #pragma unroll
                     for (int i = 0; i < P::MI; ++i) af[i][ks] = P::read_a(buf + HALF_BYTES, wm, i, ks, lane);
             }
-            if (lt == 0) issue_bias();
-            issue2(I0{}, I1{}, PM == 2);
+            if constexpr (ST >= 0) {     // two K-tiles ahead: this K-tile's own stage
+                issue1_fast(I0{}, std::integral_constant<int, ST>{});
+                issue1_fast(I1{}, std::integral_constant<int, ST>{});
+            } else {
+                if (lt == 0) issue_bias();
+                issue2(I0{}, I1{}, PM == 2);
+            }
         }
         if (grp1) {   // group 1 waits for the data of phase g + 1 before the barrier that opens it for group 0
             if constexpr (PM == 2) {
@@ -2212,18 +2244,33 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
         // the generic waits are only needed where the end of the load stream clips the issue count: the last two K-tiles of
         // the workgroup's last tile (nk >= 4 is a launch precondition, so K-tile 0 is never among them)
         const int t_gen = (j == nt - 1) ? nk - 2 : nk;
-        phase(I0{}, I0{}, 0, j);
-        phase(I1{}, I0{}, 0, j);
-        phase(I0{}, I0{}, 1, j);
-        phase(I1{}, I0{}, 1, j);
+        phase(I0{}, I0{}, 0, j, IDyn{});
+        phase(I1{}, I0{}, 0, j, IDyn{});
+        phase(I0{}, I0{}, 1, j, IDyn{});
+        phase(I1{}, I0{}, 1, j, IDyn{});
         int t = 2;
+        if (!(ABL & 1024) && (cm0 + BM2 <= M) && (cn0 + BN2 <= N)) {
+            // fast K-tiles: t <= nk - 3, i.e. everything the K-tile issues (K-tiles t + 1, t + 2 of THIS tile) lies before the tile's
+            // end.  Unrolled by two so that the ring stage of a K-tile is a constant; one generic K-tile first if stage 1 is next
+            if ((g & 2) && t <= nk - 3) {
+                phase(I0{}, I1{}, t, j, IDyn{});
+                phase(I1{}, I1{}, t, j, IDyn{});
+                ++t;
+            }
+            for (; t + 1 <= nk - 3; t += 2) {
+                phase(I0{}, I1{}, t, j, I0{});
+                phase(I1{}, I1{}, t, j, I0{});
+                phase(I0{}, I1{}, t + 1, j, I1{});
+                phase(I1{}, I1{}, t + 1, j, I1{});
+            }
+        }
         for (; t < t_gen; ++t) {
-            phase(I0{}, I1{}, t, j);
-            phase(I1{}, I1{}, t, j);
+            phase(I0{}, I1{}, t, j, IDyn{});
+            phase(I1{}, I1{}, t, j, IDyn{});
         }
         for (; t < nk; ++t) {
-            phase(I0{}, I2{}, t, j);
-            phase(I1{}, I2{}, t, j);
+            phase(I0{}, I2{}, t, j, IDyn{});
+            phase(I1{}, I2{}, t, j, IDyn{});
         }
         if (ABL & 4) {
 #pragma unroll
@@ -3228,6 +3275,9 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
     if (g_gemm_variant == 16)                                                                                       \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp_kernel<MODE_, Mma16>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,   \
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n, Seg2{});                           \
+    else if (g_gemm_variant == 18) /* second generation without the fast (static ring stage) K-tiles */             \
+        hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 1024>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,   \
+                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
     else
 #define BT_PP2_ABL(MODE_, ABL_)                                                                                     \
     hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, ABL_>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A, lda,  \
