@@ -2115,11 +2115,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
         glds16_sbase_off<off>(base, v0, ring_lds);
         glds16_sbase_off<off + 1024>(base, v0 + (is_a ? row8_a : row8_w), ring_lds);
     };
-    auto advance_fast = [&]() {
+    auto advance_fast = [&]() {   // the K step goes into the scalar base pointers: the lane offsets of the DMAs stay loop-invariant
         ++lx;
         ++lt;
-        voff_a += 128;
-        voff_w += 128;
+        pa0 += 128;   // (SALU instead of VALU adds: same speed, six registers less -- profiles/r3_ppab_k_step_sgpr_vs_valu.jsonl)
+        pa1 += 128;
+        pw0 += 128;
+        pw1 += 128;
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -2149,6 +2151,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
     bool prev_full = false;   // the previous tile's epilogue issued PP_STORES stores per wave (a full tile) ...
     bool pre_issued = false;  // ... behind the half-tiles phase (0, 0) of this tile would have issued
     // one phase.  PM: 0 = K-tiles 0 and 1 of a tile (store-count waits behind a full tile), 1 = steady state, 2 = generic (stream tail)
+    // ABL bit 2048 (experiment, variant 19; rejected: 6-12 % slower, profiles/r3_ppab_cluster_tail_after_barrier.jsonl): the last four
+    // MFMAs of a cluster are issued AFTER the barrier that hands the matrix pipe to the other wave group (at the top of the wave's
+    // next phase), so that group starts while this one still has work queued.  The held-back MFMAs then queue behind the other
+    // group's on the same pipe and delay this wave's fragment reads -- the off-turn path is the one that must stay short
+    constexpr bool TAIL = (ABL & 2048) != 0;
+    bool tail_pending = false;
+    auto run_tail = [&](auto ppc) {   // the held-back MFMAs of the previous phase (its p = ppc): i = MI - 1, ks = KS - 1, every nb
+        constexpr int pp = decltype(ppc)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int nb = 0; nb < P::NB; ++nb)
+            acc[pp * P::MI + P::MI - 1][nb] = P::mma(wf[nb][P::KS - 1], af[P::MI - 1][P::KS - 1], acc[pp * P::MI + P::MI - 1][nb]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
     // ST >= 0: fast K-tile (PM == 1 only) whose ring stage is the compile-time constant ST -- LDS addresses become loop-invariant
     // registers + immediates, the loads go out unconditionally
     auto phase = [&](auto pc, auto pmc, int t, int j, auto stc) {
@@ -2165,6 +2183,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
             }
         }
         cbarrier();
+        if constexpr (TAIL) {
+            if (ST >= 0 || tail_pending) run_tail(std::integral_constant<int, 1 - p>{});
+            tail_pending = true;
+        }
         const char* buf = smem + (ST >= 0 ? ST * 4 * HALF_BYTES : (g & 2) * 2 * HALF_BYTES);
         const bool do_reads = !(ABL & 2) || g == 0;
         if constexpr (p == 0) {
@@ -2226,7 +2248,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
                 for (int i = 0; i < P::MI; ++i)
 #pragma unroll
                     for (int nb = 0; nb < P::NB; ++nb)
-                        acc[p * P::MI + i][nb] = P::mma(wf[nb][ks], af[i][ks], acc[p * P::MI + i][nb]);
+                        if (!(TAIL && ks == P::KS - 1 && i == P::MI - 1))
+                            acc[p * P::MI + i][nb] = P::mma(wf[nb][ks], af[i][ks], acc[p * P::MI + i][nb]);
         } else {
 #pragma unroll
             for (int ks = 0; ks < P::KS; ++ks) {
@@ -2271,6 +2294,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
         for (; t < nk; ++t) {
             phase(I0{}, I2{}, t, j, IDyn{});
             phase(I1{}, I2{}, t, j, IDyn{});
+        }
+        if constexpr (TAIL) {   // the tile's last cluster is complete before the epilogue
+            run_tail(I1{});
+            tail_pending = false;
         }
         if (ABL & 4) {
 #pragma unroll
@@ -3277,6 +3304,9 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n, Seg2{});                           \
     else if (g_gemm_variant == 18) /* second generation without the fast (static ring stage) K-tiles */             \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 1024>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,   \
+                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
+    else if (g_gemm_variant == 19) /* experiment: cluster tail after the hand-over barrier */                       \
+        hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 2048>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,   \
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
     else
 #define BT_PP2_ABL(MODE_, ABL_)                                                                                     \

@@ -354,6 +354,113 @@ def test_persistent_v2_model_detects_errors():
         pp_model(8, 3, [True] * 3, [PP_STORES] * 3, stream=functools.partial(_pp2_stream, bad="no_boundary_barrier"))
 
 
+def _pp2_ktile_walk(nk, nt, full):
+    """Index bookkeeping of gemm_bf16_mfma256pp2_kernel's K loop, restated: the phase counter g (ring stage of compute K-tile =
+    (g >> 1) & 1), the load cursor (tile lj, K-tile lt, running K-tile index lx -> ring stage lx & 1), the fast K-tiles of full
+    tiles (static ring stage, unconditional issue, no wrap test in their cursor step).  Returns per-K-tile records
+    (j, t, kind) with kind in {"generic", "fast"} and asserts what the fast path takes for granted."""
+    g = 0
+    lx, lt, lj = 0, 0, 0
+    issued = []                                   # (tile, K-tile, half-tile kind, ring stage) in issue order
+
+    def issue(kinds, ring=None, fast_expect=None):
+        if lj >= nt:
+            return
+        r = lx & 1
+        if ring is not None:
+            assert ring == r, "static ring stage of a fast K-tile differs from the cursor's"
+        if fast_expect is not None:
+            assert (lj, lt) == fast_expect, ("fast K-tile issues outside its own tile", (lj, lt), fast_expect)
+        for k in kinds:
+            issued.append((lj, lt, k, r))
+
+    def advance(fast=False):
+        nonlocal lx, lt, lj
+        lx += 1
+        lt += 1
+        if fast:
+            assert lt < nk, "cursor of a fast K-tile reached the end of the tile"
+        elif lt == nk:
+            lt = 0
+            lj += 1
+
+    issue([0, 1, 2, 3])
+    advance()
+    issue([0, 1])
+    walked = []
+    pre_issued = False
+    for j in range(nt):
+        t = 0
+
+        def generic(t):
+            nonlocal g, pre_issued
+            for p in (0, 1):
+                if p == 0:
+                    if t == 0 and pre_issued:
+                        pre_issued = False
+                    else:
+                        issue([2, 3])
+                        advance()
+                else:
+                    issue([0, 1])
+                g += 1
+            walked.append((j, t, "generic"))
+
+        def fast(t, st):
+            nonlocal g
+            assert st == (g >> 1) & 1, "static compute stage differs from the phase counter's"
+            issue([2, 3], ring=1 - st, fast_expect=(j, t + 1))
+            advance(fast=True)
+            g += 1
+            assert st == (g >> 1) & 1
+            issue([0, 1], ring=st, fast_expect=(j, t + 2))
+            g += 1
+            walked.append((j, t, "fast"))
+
+        generic(0)
+        generic(1)
+        t = 2
+        if full[j]:
+            if (g & 2) and t <= nk - 3:
+                generic(t)
+                t += 1
+            while t + 1 <= nk - 3:
+                fast(t, 0)
+                fast(t + 1, 1)
+                t += 2
+        while t < nk:
+            generic(t)
+            t += 1
+        if j + 1 < nt:                            # tile boundary: W1 / A1 of the next tile's K-tile 1 ahead of the stores
+            issue([2, 3])
+            advance()
+            pre_issued = True
+    return walked, issued
+
+
+@pytest.mark.parametrize("nk", [4, 5, 6, 7, 8, 9, 16, 31, 32, 33, 128])
+@pytest.mark.parametrize("nt", [1, 2, 3, 4])
+def test_persistent_gemm_v2_fast_ktiles_bookkeeping(nk, nt):
+    """Every K-tile of every tile is computed exactly once and in order whichever mix of generic / fast K-tiles the loop
+    takes; every half-tile of every K-tile is issued exactly once, in consumption order, into the ring stage its K-tile is
+    read from; fast K-tiles never touch another tile and know their ring stages at compile time."""
+    for full in ([True] * nt, [False] * nt, [j % 2 == 0 for j in range(nt)], [j % 2 == 1 for j in range(nt)]):
+        walked, issued = _pp2_ktile_walk(nk, nt, full)
+        assert [(j, t) for j, t, _ in walked] == [(j, t) for j in range(nt) for t in range(nk)]
+        want = [(j, t, k) for j in range(nt) for t in range(nk) for k in range(4)]
+        assert [(j, t, k) for j, t, k, _ in issued] == want
+        for j, t, k, ring in issued:
+            assert ring == (j * nk + t) & 1                      # K-tile (j, t) is compute K-tile number j * nk + t
+        n_fast = sum(1 for _, _, kind in walked if kind == "fast")
+        for j in range(nt):
+            mine = [kind for jj, _, kind in walked if jj == j]
+            if not full[j]:
+                assert "fast" not in mine
+            elif nk >= 8:
+                assert mine.count("fast") >= nk - 6           # at most K-tiles 0, 1, one stage-alignment K-tile and the last 2-3
+        assert n_fast % 2 == 0
+
+
 # ---- one-tile 256 x 128 kernel (gemm_bf16_mfma256x128_kernel): three half-tiles per K-tile, ring of six slots ---------------------
 T21_WAIT = int(re.search(r"constexpr int T21_WAIT = (\d+);", SRC).group(1))
 
