@@ -2189,7 +2189,31 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
         }
         const char* buf = smem + (ST >= 0 ? ST * 4 * HALF_BYTES : (g & 2) * 2 * HALF_BYTES);
         const bool do_reads = !(ABL & 2) || g == 0;
-        if constexpr (p == 0) {
+        if (ABL & 16384) __builtin_amdgcn_s_setprio(2);   // experiment (variant 25): the off-turn (reads + DMA issue) at raised priority
+        if constexpr ((ABL & 4096) != 0 && ST >= 0) {
+            // experiment (variant 23): the four DMA instructions spread among the fragment reads instead of behind them
+            constexpr int STc = ST >= 0 ? ST : 0;
+            if constexpr (p == 0) {
+#pragma unroll
+                for (int nb = 0; nb < P::NB; ++nb) wf[nb][0] = P::read_w(buf + (2 + wh) * HALF_BYTES, wrow, nb, 0, lane);
+                issue1_fast(I2{}, std::integral_constant<int, 1 - STc>{});
+#pragma unroll
+                for (int i = 0; i < P::MI; ++i) af[i][0] = P::read_a(buf, wm, i, 0, lane);
+#pragma unroll
+                for (int nb = 0; nb < P::NB; ++nb) wf[nb][1] = P::read_w(buf + (2 + wh) * HALF_BYTES, wrow, nb, 1, lane);
+                issue1_fast(I3{}, std::integral_constant<int, 1 - STc>{});
+                advance_fast();
+#pragma unroll
+                for (int i = 0; i < P::MI; ++i) af[i][1] = P::read_a(buf, wm, i, 1, lane);
+            } else {
+#pragma unroll
+                for (int i = 0; i < P::MI; ++i) af[i][0] = P::read_a(buf + HALF_BYTES, wm, i, 0, lane);
+                issue1_fast(I0{}, std::integral_constant<int, STc>{});
+#pragma unroll
+                for (int i = 0; i < P::MI; ++i) af[i][1] = P::read_a(buf + HALF_BYTES, wm, i, 1, lane);
+                issue1_fast(I1{}, std::integral_constant<int, STc>{});
+            }
+        } else if constexpr (p == 0) {
             if constexpr (PM == 0 && !(ABL & 128)) {
                 if (t == 0) P::init(acc, ep.bias != nullptr, false, lds_addr(smem + PP_BIAS_OFF + (j & 1) * 1024), wcol, lane);
             }
@@ -2238,9 +2262,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
                 wait_vmcnt<(p == 0 ? PP2_WAIT_P1 : PP2_WAIT_P0)>();
             }
         }
+        if (ABL & 16384) __builtin_amdgcn_s_setprio(0);
         cbarrier();
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+        // (no s_setprio around the cluster: raising the MFMA-issuing wave's priority delays the OTHER group's fragment reads and
+        //  DMA issue on the same SIMD, and that off-turn path is what bounds a phase -- +1-5 % without it on every shape and
+        //  epilogue, profiles/r3_ppab_no_setprio.jsonl; ABL 8192 = the round-2 setting, 16384 = priority for the off-turn instead)
+        if (ABL & 8192) __builtin_amdgcn_s_setprio(1);
         if (!(ABL & 16)) {
 #pragma unroll
             for (int ks = 0; ks < P::KS; ++ks)
@@ -2259,7 +2287,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
                 for (int nb = 0; nb < P::NB; ++nb) asm volatile("" ::"v"(wf[nb][ks]));
             }
         }
-        __builtin_amdgcn_s_setprio(0);
+        if (ABL & 8192) __builtin_amdgcn_s_setprio(0);
         ++g;
     };
     for (int j = 0; j < nt; ++j) {
@@ -2346,7 +2374,7 @@ constexpr int T21_SMEM = 2 * T21_STAGE;
 constexpr int T21_PATCH_PITCH = 80;                // 32 columns x 2 B + 16 pad
 constexpr int T21_WAIT = 6;
 
-template <bool RES>
+template <bool RES, bool PRIO = true>
 __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_kernel(const bf16* __restrict__ A, int64_t lda,
                                                                    const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
                                                                    int K, int tiles_m, int tiles_n) {
@@ -2439,7 +2467,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_kernel(const bf16* 
         if (grp1) wait(steady);
         cbarrier();
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -2447,7 +2475,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_kernel(const bf16* 
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
                     acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][ks], af[i][ks], acc[i][nb], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         // ---- phase 1: A1 ----
         if (!grp1) wait(steady);
         cbarrier();
@@ -2465,7 +2493,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_kernel(const bf16* 
         if (grp1) wait(t + 4 <= nk);                // (its wait for phase 0 of K-tile t + 1: steady while t + 1 <= nk - 3)
         cbarrier();
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+        if (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -2473,7 +2501,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_kernel(const bf16* 
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
                     acc[4 + i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][ks], af[i][ks], acc[4 + i][nb], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
     }
     if (!grp1) cbarrier();
     // ---- epilogue ----
@@ -3305,6 +3333,15 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
     else if (g_gemm_variant == 18) /* second generation without the fast (static ring stage) K-tiles */             \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 1024>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,   \
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
+    else if (g_gemm_variant == 23) /* experiment: DMA instructions spread among the fragment reads */               \
+        hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 4096>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,   \
+                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
+    else if (g_gemm_variant == 24) /* A/B: s_setprio 1 around the MFMA cluster (round 2) */                          \
+        hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 8192>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,   \
+                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
+    else if (g_gemm_variant == 25) /* experiment: raised priority for the off-turn instead of the MFMA cluster */    \
+        hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 16384>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
+                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
     else if (g_gemm_variant == 19) /* experiment: cluster tail after the hand-over barrier */                       \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 2048>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,   \
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
@@ -3381,12 +3418,19 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
             // one 256 x 128 tile per CU: the decode projections onto the residual stream (M = 4096, N = 2048: 256 tiles)
             ProfScope ps(BT_PROF_LINEAR_MFMA, s);
             const int tiles_m = (int)(M / 256), tiles_n = (int)(N / 128);
-            if (residual)
-                hipLaunchKernelGGL((gemm_bf16_mfma256x128_kernel<true>), dim3(tiles_m * tiles_n), dim3(512), 0, s, (const bf16*)A, lda,
-                                   (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);
-            else
-                hipLaunchKernelGGL((gemm_bf16_mfma256x128_kernel<false>), dim3(tiles_m * tiles_n), dim3(512), 0, s, (const bf16*)A, lda,
-                                   (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);
+#define BT_LAUNCH_T21(RES_, PRIO_)                                                                                           \
+    hipLaunchKernelGGL((gemm_bf16_mfma256x128_kernel<RES_, PRIO_>), dim3(tiles_m * tiles_n), dim3(512), 0, s, (const bf16*)A, lda,  \
+                       (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n)
+#ifdef BT_DEBUG_HOOKS   /* A/B: without s_setprio around the MFMA clusters (bt_debug_small_stages(9); the knob is otherwise unused here).
+                           Unlike the persistent kernel this one is not faster without it: 0 .. -2 %, profiles/r3_t21_setprio.jsonl */
+            if (g_small_stages == 9) {
+                if (residual) BT_LAUNCH_T21(true, false);
+                else BT_LAUNCH_T21(false, false);
+            } else
+#endif
+            if (residual) BT_LAUNCH_T21(true, true);
+            else BT_LAUNCH_T21(false, true);
+#undef BT_LAUNCH_T21
         } else if (!seg2 && M <= 4 && !ep.q.enabled && g_gemm_variant != 1 && g_gemm_variant != 22 && (K % 512 == 0) && (lda % 8 == 0) &&
                    (K % 8 == 0) && aligned16(A) && aligned16(W) && !g_force_generic) {
             // a handful of rows: pure weight streaming (one launch, no fp32 partials).  Measured (bench.py, hipGraph replay):

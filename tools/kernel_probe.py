@@ -435,11 +435,13 @@ def main():
             for mode, res_ in (("bias", None), ("bias_res", r)):
                 rec = {"op": "t21", "M": M, "N": N, "K": K, "mode": mode}
                 for rep in range(3):
-                    for name, v in (("t256x128_us", 0), ("t128x128_us", 1)):
+                    for name, v, st in (("t256x128_us", 0, 0), ("t256x128_no_setprio_us", 0, 9), ("t128x128_us", 1, 0)):
                         hooks.bt_debug_gemm_variant(v)
+                        hooks.bt_debug_small_stages(st)     # 9: the 256 x 128 kernel without s_setprio around its MFMA clusters (A/B)
                         ms = timed(lambda: ops.linear(x, w, b, res_, out=out), 20)
                         rec.setdefault(name, []).append(round(ms * 1e3, 1))
                     hooks.bt_debug_gemm_variant(0)
+                    hooks.bt_debug_small_stages(0)
                     ms = timed(lambda: F.linear(x, w, b), 20)
                     rec.setdefault("vendor_us", []).append(round(ms * 1e3, 1))
                 fl = 2.0 * M * N * K / 1e6
