@@ -2156,6 +2156,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
     // next phase), so that group starts while this one still has work queued.  The held-back MFMAs then queue behind the other
     // group's on the same pipe and delay this wave's fragment reads -- the off-turn path is the one that must stay short
     constexpr bool TAIL = (ABL & 2048) != 0;
+    // ABL bit 32768 (experiment, variant 26): in fast K-tiles the second half-tile of a phase is issued inside the MFMA cluster
+    constexpr bool DMAC = (ABL & 32768) != 0;
     bool tail_pending = false;
     auto run_tail = [&](auto ppc) {   // the held-back MFMAs of the previous phase (its p = ppc): i = MI - 1, ks = KS - 1, every nb
         constexpr int pp = decltype(ppc)::value;
@@ -2228,8 +2230,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
             }
             if constexpr (ST >= 0) {     // the cursor stands one K-tile ahead: the other ring stage
                 issue1_fast(I2{}, std::integral_constant<int, 1 - ST>{});
-                issue1_fast(I3{}, std::integral_constant<int, 1 - ST>{});
-                advance_fast();
+                if constexpr (!DMAC) {
+                    issue1_fast(I3{}, std::integral_constant<int, 1 - ST>{});
+                    advance_fast();
+                }
             } else if (PM == 0 && t == 0 && pre_issued) {
                 pre_issued = false;          // issued at the tile boundary, ahead of the previous tile's stores
             } else {
@@ -2245,7 +2249,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
             }
             if constexpr (ST >= 0) {     // two K-tiles ahead: this K-tile's own stage
                 issue1_fast(I0{}, std::integral_constant<int, ST>{});
-                issue1_fast(I1{}, std::integral_constant<int, ST>{});
+                if constexpr (!DMAC) issue1_fast(I1{}, std::integral_constant<int, ST>{});
             } else {
                 if (lt == 0) issue_bias();
                 issue2(I0{}, I1{}, PM == 2);
@@ -2259,7 +2263,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
                 if (prev_full && !(t == 1 && p == 1)) wait_vmcnt_pp<(p == 0 ? PP2_WAIT_P1 : PP2_WAIT_P0) + PP_STORES>();
                 else wait_vmcnt<(p == 0 ? PP2_WAIT_P1 : PP2_WAIT_P0)>();
             } else {
-                wait_vmcnt<(p == 0 ? PP2_WAIT_P1 : PP2_WAIT_P0)>();
+                wait_vmcnt<(p == 0 ? PP2_WAIT_P1 : PP2_WAIT_P0) - ((DMAC && ST >= 0) ? 2 : 0)>();
             }
         }
         if (ABL & 16384) __builtin_amdgcn_s_setprio(0);
@@ -2276,8 +2280,20 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
                 for (int i = 0; i < P::MI; ++i)
 #pragma unroll
                     for (int nb = 0; nb < P::NB; ++nb)
-                        if (!(TAIL && ks == P::KS - 1 && i == P::MI - 1))
+                        if (!(TAIL && ks == P::KS - 1 && i == P::MI - 1)) {
+                            if constexpr (DMAC && ST >= 0) {
+                                if (ks == 0 && i == 2 && nb == 0) {   // before the 9th MFMA of the cluster
+                                    constexpr int STc = ST >= 0 ? ST : 0;
+                                    if constexpr (p == 0) {
+                                        issue1_fast(I3{}, std::integral_constant<int, 1 - STc>{});
+                                        advance_fast();
+                                    } else {
+                                        issue1_fast(I1{}, std::integral_constant<int, STc>{});
+                                    }
+                                }
+                            }
                             acc[p * P::MI + i][nb] = P::mma(wf[nb][ks], af[i][ks], acc[p * P::MI + i][nb]);
+                        }
         } else {
 #pragma unroll
             for (int ks = 0; ks < P::KS; ++ks) {
@@ -3341,6 +3357,9 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
     else if (g_gemm_variant == 25) /* experiment: raised priority for the off-turn instead of the MFMA cluster */    \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 16384>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
+                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
+    else if (g_gemm_variant == 26) /* experiment: second half-tile of a fast phase issued inside the MFMA cluster */  \
+        hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 32768>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
     else if (g_gemm_variant == 19) /* experiment: cluster tail after the hand-over barrier */                       \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 2048>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,   \

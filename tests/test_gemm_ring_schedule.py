@@ -274,10 +274,15 @@ def _pp2_stream(grp, wave0, nk, nt, full, stores, pd, has_bias, bad=None, dmac=F
     g = 0
     prev_full = False
     pre_issued = False
+    dmac_all = dmac
+    fast_kt = set()
+    if dmac == "fast":                            # the kernel's experiment: only in the fast K-tiles of full tiles
+        fast_kt = {(j, t) for j, t, kind in _pp2_ktile_walk(nk, nt, full)[0] if kind == "fast"}
     for j in range(nt):
         t_gen = nk - 2 if j == nt - 1 else nk
         for t in range(nk):
             pm = 0 if t < 2 else (1 if t < t_gen else 2)
+            dmac = (dmac_all is True) or ((j, t) in fast_kt)
             for p in (0, 1):
                 if grp == 0:
                     if pm == 2:
@@ -342,6 +347,17 @@ def test_persistent_gemm_v2_schedule(nk, nt):
     pp_model(nk, nt, [False] * nt, [PP_STORES] * nt, stream=_pp2_stream)
     pp_model(nk, nt, [j % 2 == 0 for j in range(nt)], [PP_STORES if j % 2 == 0 else 3 for j in range(nt)], has_bias=False,
              stream=_pp2_stream)
+
+
+@pytest.mark.parametrize("nk", [8, 9, 32])
+@pytest.mark.parametrize("nt", [1, 2, 3])
+def test_persistent_gemm_v2_late_half_tile_experiment_schedule(nk, nt):
+    """Experiment variant 26 (ABL 32768): in fast K-tiles the second half-tile of a phase is issued inside the MFMA cluster and
+    group 1 waits for two instructions fewer -- hazards of that program order, mixed with generic K-tiles."""
+    import functools
+    st = functools.partial(_pp2_stream, dmac="fast")
+    pp_model(nk, nt, [True] * nt, [PP_STORES] * nt, stream=st)
+    pp_model(nk, nt, [j % 2 == 0 for j in range(nt)], [PP_STORES if j % 2 == 0 else 3 for j in range(nt)], has_bias=False, stream=st)
 
 
 def test_persistent_v2_model_detects_errors():
