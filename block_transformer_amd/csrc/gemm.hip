@@ -1336,7 +1336,8 @@ struct RowSplit {
     }
 };
 
-// EABL (debug timing ablations, wrong results): 1 = no global stores, 2 = no LDS transposes (the packed registers are stored as is)
+// EABL (debug timing ablations, wrong results): 1 = no global stores, 2 = no LDS transposes (the packed registers are stored as is);
+// 16 (correct results, A/B): QKV mode with the generic per-lane K / V addresses
 template <int MODE, int EABL = 0>
 __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x4_t (&acc)[8][4], int cm0, int n_wave, int wm,
                                    int lane) {
@@ -1430,6 +1431,53 @@ __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x
     // the descriptor form reads 4 + 1.
     const __amdgpu_buffer_rsrc_t out_rsrc = tile_rsrc(reinterpret_cast<const char*>(e.out) + ((int64_t)cm0 * e.ldo + n_wave) * 2);
     const uint32_t out_voff = ((uint32_t)(lane >> 3) * (uint32_t)e.ldo + (uint32_t)(lane & 7) * 8u) * 2u;
+    // QKV mode, K / V columns: the same descriptor form into the cache.  A wave's 64 columns lie inside one head's q, k or v part
+    // (head_dim % 64 == 0), so head / part are scalars, and the cache row of output row r of the tile is an affine function of r
+    // for q_len == 1 (one sequence per row: stride = one sequence of the cache), for q_len >= 256 (consecutive positions of one
+    // sequence, + one jump where the tile crosses into the next sequence) and for power-of-two q_len (shift / mask).  The generic
+    // form below (two integer divisions and a 64-bit address per lane and store: ~80 VALU instructions x 16 stores per wave
+    // and tile) made the fused epilogue cost +15 % of a prefill QKV GEMM; it stays for cut tiles, other q_len and > 2 GiB spans.
+    int kv_mode = 0;                       // 0 generic, 1 q_len == 1, 2 q_len >= 256 (one wrap), 3 power-of-two q_len
+    int part_u = 0, kv_shift = 0, kv_thr0 = 0;
+    uint32_t kv_voff = 0, kv_row = 0, kv_seq = 0, kv_delta = 0;
+    __amdgpu_buffer_rsrc_t kv_rsrc = out_rsrc;
+    if (qkv) {
+        const int D = e.q.head_dim, q_len = e.q.q_len;
+        const int64_t seq_bytes = (int64_t)e.q.heads * e.q.n_max * D * 2;
+        const bool pow2 = (q_len & (q_len - 1)) == 0;
+        if (!(EABL & 16) && D % 64 == 0 && cm0 + BM2 <= M && n_wave + 64 <= N && seq_bytes * (q_len >= BM2 ? 1 : BM2) < (int64_t)0x7ff00000 &&
+            (q_len == 1 || q_len >= BM2 || pow2)) {
+            const int head = n_wave / (3 * D);
+            const int within = n_wave - head * 3 * D;
+            part_u = within / D;
+            const int el0 = within - part_u * D;
+            const RowSplit rs(q_len, cm0);
+            int64_t b_base = cm0, t_base = 0;
+            if (q_len == 1) {
+                kv_mode = 1;
+                kv_row = (uint32_t)seq_bytes;
+            } else if (q_len >= BM2) {
+                kv_mode = 2;
+                b_base = rs.b0;
+                t_base = rs.t0;
+                kv_row = (uint32_t)(D * 2);
+                kv_delta = (uint32_t)(seq_bytes - (int64_t)q_len * D * 2);
+                kv_thr0 = q_len - rs.t0;             // tile rows >= kv_thr0 belong to the next sequence
+            } else {
+                kv_mode = 3;
+                kv_shift = 31 - __builtin_clz(q_len);
+                b_base = cm0 >> kv_shift;            // cm0 is a multiple of 256 >= q_len: t_base = 0
+                kv_row = (uint32_t)(D * 2);
+                kv_seq = (uint32_t)seq_bytes;
+            }
+            if (part_u != 0) {
+                const bf16* cache = part_u == 1 ? e.q.kc : e.q.vc;
+                kv_rsrc = tile_rsrc(reinterpret_cast<const char*>(cache) +
+                                    (((b_base * e.q.heads + head) * e.q.n_max + pos0 + t_base) * D + el0) * 2);
+                kv_voff = (uint32_t)(lane >> 3) * kv_row + (uint32_t)(lane & 7) * 16u;
+            }
+        }
+    }
 #pragma unroll
     for (int ai = 0; ai < 8; ++ai) {
         const int row_l = (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16;
@@ -1500,6 +1548,20 @@ __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x
                 if (!qkv) {
                     __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{v.x, v.y, v.z, v.w}, out_rsrc, out_voff,
                                                            (uint32_t)(row_l + h * 8) * (uint32_t)e.ldo * 2u, 0);
+                    continue;
+                } else if (kv_mode != 0) {
+                    const uint32_t r0 = (uint32_t)(row_l + h * 8);          // first tile row of this store (scalar)
+                    if (part_u == 0) {                                       // q columns: rows of the qkv buffer
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{v.x, v.y, v.z, v.w}, out_rsrc, out_voff, r0 * (uint32_t)e.ldo * 2u, 0);
+                    } else if (kv_mode == 3) {
+                        const uint32_t r = r0 + (uint32_t)(lane >> 3);
+                        const uint32_t vo = (r >> kv_shift) * kv_seq + (r & ((1u << kv_shift) - 1u)) * kv_row + (uint32_t)(lane & 7) * 16u;
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{v.x, v.y, v.z, v.w}, kv_rsrc, vo, 0, 0);
+                    } else {
+                        uint32_t vo = kv_voff;
+                        if (kv_mode == 2 && (int)(r0 + (uint32_t)(lane >> 3)) >= kv_thr0) vo += kv_delta;
+                        __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{v.x, v.y, v.z, v.w}, kv_rsrc, vo, r0 * kv_row, 0);
+                    }
                     continue;
                 } else {
                     const int D = e.q.head_dim;
@@ -2365,7 +2427,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
         }
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
-        P::template epilogue<MODE, (ABL >> 5) & 3 | ((ABL >> 6) & 12)>(ep, pos0, stage, acc, cm0, cn0 + wcol, wm, lane_e);
+        P::template epilogue<MODE, (ABL >> 5) & 3 | ((ABL >> 6) & 12) | ((ABL >> 12) & 16)>(ep, pos0, stage, acc, cm0, cn0 + wcol, wm, lane_e);
     }
     if (!grp1) cbarrier();
 }
@@ -3360,6 +3422,9 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
     else if (g_gemm_variant == 26) /* experiment: second half-tile of a fast phase issued inside the MFMA cluster */  \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 32768>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
+                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
+    else if (g_gemm_variant == 27) /* A/B: QKV epilogue with the generic (per-lane division) K / V addresses */      \
+        hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 65536>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
     else if (g_gemm_variant == 19) /* experiment: cluster tail after the hand-over barrier */                       \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 2048>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,   \

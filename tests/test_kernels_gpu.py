@@ -599,7 +599,11 @@ def test_qkv_rope_append_fused_head_dims(d, heads, kernel, max_wg, dbg_lib):
     run_qkv_fused(5, 61, 2, heads, d, True, True, True, kernel, max_wg)
 
 
-@pytest.mark.parametrize("B,q,pos0,heads,d", [(4, 64, 3, 2, 128), (2, 256, 0, 2, 128), (8, 32, 1, 8, 32), (1, 512, 0, 4, 64)])
+@pytest.mark.parametrize("B,q,pos0,heads,d", [(4, 64, 3, 2, 128), (2, 256, 0, 2, 128), (8, 32, 1, 8, 32), (1, 512, 0, 4, 64),
+                                              # K / V descriptor addressing: tiles that cross a sequence boundary (q_len >= 256, not a
+                                              # multiple of the tile), power-of-two q_len, q_len = 1 over several full tiles
+                                              (3, 384, 1, 2, 128), (6, 320, 0, 2, 128), (16, 16, 2, 2, 128), (512, 1, 4, 2, 128),
+                                              (5, 256, 2, 2, 64), (96, 8, 0, 4, 64)])
 @pytest.mark.parametrize("use_dev_pos,use_table", [(False, False), (True, True)])
 @pytest.mark.parametrize("max_wg", [0, 2])
 @pytest.mark.parametrize("kernel", [12, 14, 16])

@@ -164,7 +164,7 @@ def probe_copy(nbytes, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=["gemm", "attn", "flash", "suite", "copy", "ab", "abl", "skinny", "decode", "vendor", "pitch",
-                                     "local", "lin2", "ln", "ppabl", "ppstore", "ppv2", "ppepi", "ppab", "t21"])
+                                     "local", "lin2", "ln", "ppabl", "ppstore", "ppv2", "ppepi", "ppab", "t21", "ppqkv"])
     ap.add_argument("--m", type=int, default=32768)
     ap.add_argument("--n", type=int, default=6144)
     ap.add_argument("--k", type=int, default=2048)
@@ -421,6 +421,38 @@ def main():
                 rec["a_TF"] = round(2.0 * M * N * K / min(rec["a_us"]) / 1e6, 1)
                 rec["b_TF"] = round(2.0 * M * N * K / min(rec["b_us"]) / 1e6, 1)
                 res.append(rec)
+        hooks.bt_debug_gemm_variant(0)
+    elif args.what == "ppqkv":
+        # the fused QKV + RoPE + KV-append mode of the persistent kernel (the single largest consumer of a generate()) at the prefill
+        # chunk shape (64 sequences x 512 positions) and the decode shapes (4096 x 1, 4096 x 2): interleaved A/B of variants
+        heads, d, rot = 16, 128, 32
+        H = heads * d
+        tab = ops.rope_tables(1024, rot, 10000.0, DEV)
+        va, vb = (args.variant or 12), args.ab_other
+        for (B, q) in ((64, 512), (4096, 1), (4096, 2)):
+            n_max = q + 2
+            x = torch.randn(B * q, H, device=DEV).bfloat16()
+            w = (torch.randn(3 * H, H, device=DEV) * H ** -0.5).bfloat16()
+            b = torch.randn(3 * H, device=DEV).bfloat16()
+            qkv = torch.empty(B * q, 3 * H, dtype=torch.bfloat16, device=DEV)
+            kc = torch.zeros(B, heads, n_max, d, dtype=torch.bfloat16, device=DEV)
+            vc = torch.zeros_like(kc)
+
+            def call():
+                check(lib().bt_qkv_rope_append(_lib.BT_BF16, B, q, heads, d, rot, ptr(x), H, ptr(w), ptr(b), ptr(qkv), 3 * H, ptr(kc),
+                                               ptr(vc), n_max, None, 0, None, ptr(tab[0]), ptr(tab[1]), None, 0, current_stream()))
+            rec = {"op": "pp_qkv_ab", "B": B, "q_len": q, "a": va, "b": vb, "a_us": [], "b_us": []}
+            outs = {}
+            for rep in range(3):
+                for v in (va, vb):
+                    hooks.bt_debug_gemm_variant(v)
+                    ms = timed(call, 10 if B * q > 8192 else 20)
+                    rec["a_us" if v == va else "b_us"].append(round(ms * 1e3, 1))
+                    outs[v] = (qkv.view(B * q, heads, 3, d)[:, :, 0].clone(), kc.clone())
+            rec["bit_identical"] = bool(torch.equal(outs[va][0], outs[vb][0]) and torch.equal(outs[va][1], outs[vb][1]))
+            fl = 2.0 * B * q * 3 * H * H / 1e6
+            rec["a_TF"], rec["b_TF"] = round(fl / min(rec["a_us"]), 1), round(fl / min(rec["b_us"]), 1)
+            res.append(rec)
         hooks.bt_debug_gemm_variant(0)
     elif args.what == "t21":
         # the decode projections onto the residual stream at M = 4096: one-tile 256 x 128 kernel (production dispatch, variant 0) vs
