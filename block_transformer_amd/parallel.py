@@ -18,8 +18,84 @@ def env_world() -> Tuple[int, int, int]:
     return (int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0)))
 
 
+def parse_cpulist(text: str) -> List[int]:
+    """Linux cpulist syntax ("0-15,32-47", "3", "") -> sorted CPU ids."""
+    cpus = set()
+    for part in text.strip().split(","):
+        part = part.strip()
+        if not part:
+            continue
+        if "-" in part:
+            lo, hi = part.split("-", 1)
+            cpus.update(range(int(lo), int(hi) + 1))
+        else:
+            cpus.add(int(part))
+    return sorted(cpus)
+
+
+def gpu_numa_cpus(local_rank: int, sysfs_root: str = "/sys") -> Tuple[Optional[int], List[int]]:
+    """(NUMA node, CPU ids local to it) of the GPU ``local_rank`` drives, from sysfs: the PCI function of the torch device
+    (``pci_domain_id:pci_bus_id:pci_device_id.0``) when torch exposes it, else the local_rank-th ``/sys/class/drm/card*`` that
+    is an amdgpu device.  (None, []) when the box does not say (single-node container without NUMA information)."""
+    dev_dirs = []
+    try:
+        p = torch.cuda.get_device_properties(local_rank)
+        bdf = f"{int(p.pci_domain_id):04x}:{int(p.pci_bus_id):02x}:{int(p.pci_device_id):02x}.0"
+        dev_dirs.append(os.path.join(sysfs_root, "bus", "pci", "devices", bdf))
+    except Exception:
+        pass
+    drm = os.path.join(sysfs_root, "class", "drm")
+    try:
+        cards = sorted((c for c in os.listdir(drm) if c.startswith("card") and c[4:].isdigit()), key=lambda c: int(c[4:]))
+        cards = [os.path.join(drm, c, "device") for c in cards if os.path.exists(os.path.join(drm, c, "device", "numa_node"))]
+        if local_rank < len(cards):
+            dev_dirs.append(cards[local_rank])
+    except OSError:
+        pass
+    for d in dev_dirs:
+        try:
+            node = int(open(os.path.join(d, "numa_node")).read().strip())
+        except (OSError, ValueError):
+            continue
+        if node < 0:
+            return None, []
+        for src in (os.path.join(d, "local_cpulist"), os.path.join(sysfs_root, "devices", "system", "node", f"node{node}", "cpulist")):
+            try:
+                cpus = parse_cpulist(open(src).read())
+            except (OSError, ValueError):
+                continue
+            if cpus:
+                return node, cpus
+        return node, []
+    return None, []
+
+
+def bind_to_gpu_numa_node(local_rank: int, world: int, sysfs_root: str = "/sys") -> Optional[dict]:
+    """Pin this rank's host threads to the CPUs of its GPU's NUMA node (small batches are host-launch bound: 52 launches per
+    block step at B = 1, and a rank scheduled on the far socket pays cross-socket latency on every one).  Ranks sharing a node
+    split its CPUs evenly by local rank.  No-op (returns None) when sysfs has no NUMA information, the intersection with the
+    current affinity mask is empty, or BT_NO_NUMA_BIND=1."""
+    if os.environ.get("BT_NO_NUMA_BIND") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    node, cpus = gpu_numa_cpus(local_rank, sysfs_root)
+    if node is None or not cpus:
+        return None
+    allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+    if not allowed:
+        return None
+    peers = [r for r in range(world) if gpu_numa_cpus(r, sysfs_root)[0] == node] or [local_rank]
+    if local_rank in peers and len(peers) > 1 and len(allowed) >= len(peers):
+        per = len(allowed) // len(peers)
+        i = peers.index(local_rank)
+        allowed = allowed[i * per:(i + 1) * per]
+    os.sched_setaffinity(0, allowed)
+    return {"numa_node": node, "cpus": allowed}
+
+
 def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank, world, local = env_world()
+    if world > 1:
+        bind_to_gpu_numa_node(local, world)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
@@ -133,17 +209,14 @@ def generate_sharded(generate_fn, input_ids: torch.Tensor, *, pad_token_id: int,
 
 
 def launch_self_under_torchrun(n_procs: int, script: str, argv: List[str]) -> None:
-    """Re-exec ``script argv`` as ``n_procs`` ranks of one node under ``torch.distributed.run`` (rendezvous on 127.0.0.1, a
-    free port) when this process is not already one of them.  Does not return on success (os.execv)."""
-    import socket
+    """Re-exec ``script argv`` as ``n_procs`` ranks of one node under ``torch.distributed.run`` when this process is not
+    already one of them.  ``--standalone`` lets the launcher itself pick (and hold) a free rendezvous port on 127.0.0.1 --
+    no bind-then-close probe that a concurrent launch could race.  Does not return on success (os.execv)."""
     import sys
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 or n_procs <= 1:
         return
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_procs}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), script] + list(argv)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={n_procs}", script] + list(argv)
     sys.stdout.flush()
     sys.stderr.flush()
     os.execv(sys.executable, cmd)

@@ -180,3 +180,54 @@ open(os.path.join({str(out)!r}, f"rank{{rank}}"), "w").write(f"{{world}} {{total
     got = sorted(os.listdir(out))
     assert got == ["rank0", "rank1"], got
     assert (out / "rank0").read_text() == "2 3.0" and (out / "rank1").read_text() == "2 3.0"
+
+
+def test_parse_cpulist():
+    assert parallel.parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]
+    assert parallel.parse_cpulist("") == [] and parallel.parse_cpulist("5") == [5]
+
+
+def _fake_sysfs(root, nodes):
+    """sysfs stand-in: card<i> -> numa node nodes[i]; node n owns the CPUs the CURRENT affinity mask allows, split by node."""
+    allowed = sorted(os.sched_getaffinity(0))
+    n_nodes = max(nodes) + 1
+    per = max(1, len(allowed) // n_nodes)
+    lists = {n: allowed[n * per:(n + 1) * per] or allowed[:1] for n in range(n_nodes)}
+    for i, node in enumerate(nodes):
+        d = root / "class" / "drm" / f"card{i}" / "device"
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text(f"{node}\n")
+        (d / "local_cpulist").write_text(",".join(str(c) for c in lists[node]) + "\n")
+    (root / "class" / "drm" / "renderD128").mkdir()
+    return lists
+
+
+def test_numa_binding_from_sysfs(tmp_path):
+    """each rank pins itself to the CPUs of its GPU's NUMA node; ranks sharing a node split them; a box
+    without NUMA information (numa_node = -1) or BT_NO_NUMA_BIND=1 is left alone.  Runs in a child process (affinity is
+    process state)."""
+    import subprocess
+    import sys
+    lists = _fake_sysfs(tmp_path, [0, 0, 1, 1] if len(os.sched_getaffinity(0)) >= 4 else [0, 0])
+    node, cpus = parallel.gpu_numa_cpus(1, str(tmp_path))
+    assert node == 0 and cpus == lists[0]
+    code = (f"import os, sys; sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r});"
+            f"from block_transformer_amd import parallel;"
+            f"r = parallel.bind_to_gpu_numa_node(int(sys.argv[1]), 2, {str(tmp_path)!r});"
+            f"print(r, sorted(os.sched_getaffinity(0)))")
+    outs = []
+    for rank in (0, 1):
+        r = subprocess.run([sys.executable, "-c", code, str(rank)], capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-1500:]
+        outs.append(r.stdout.strip())
+    got = [eval(o.split("} ", 1)[1]) if o.startswith("{") else None for o in outs]
+    if len(lists[0]) >= 2:
+        assert got[0] and got[1] and set(got[0]) | set(got[1]) <= set(lists[0]) and not set(got[0]) & set(got[1]), outs
+    # no NUMA information -> untouched
+    (tmp_path / "class" / "drm" / "card0" / "device" / "numa_node").write_text("-1\n")
+    assert parallel.bind_to_gpu_numa_node(0, 1, str(tmp_path)) is None
+    os.environ["BT_NO_NUMA_BIND"] = "1"
+    try:
+        assert parallel.bind_to_gpu_numa_node(1, 2, str(tmp_path)) is None
+    finally:
+        del os.environ["BT_NO_NUMA_BIND"]
