@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbt_hip.s
 DEBUG_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbt_hip_dbg.so")
 
 BT_F32, BT_BF16 = 0, 1
+BT_DEV_ERR_CACHE_FULL, BT_DEV_ERR_BLOCK_RANGE = 1, 2
 BT_ACT_NONE, BT_ACT_GELU = 0, 1
 ATTN_ROWS, ATTN_FLASH = 0, 1
 
@@ -54,7 +55,8 @@ class bt_engine_desc(Structure):
                 ("exp_scratch", c_void_p), ("exp_scratch_bytes", c_int64),
                 ("n_split", c_int32), ("top_k", c_int32), ("split_ws", c_void_p), ("split_ws_bytes", c_int64),
                 ("temperature", c_float), ("skip_logits", c_int32), ("sample_row0", c_int64), ("seed", c_uint64), ("sample_step", c_void_p),
-                ("config_pad", c_int64), ("gen_eos", c_int64), ("gen_pad", c_int64)]
+                ("config_pad", c_int64), ("gen_eos", c_int64), ("gen_pad", c_int64),
+                ("row_map", c_void_p), ("err_flag", c_void_p)]
 
 
 class bt_attn_args(Structure):
@@ -108,6 +110,7 @@ _SIGS = {
     "bt_token_block_enqueue": (c_int, [POINTER(bt_engine_desc), c_int32, c_int32, c_int32, c_void_p]),
     "bt_roll_over_enqueue": (c_int, [POINTER(bt_engine_desc), c_void_p]),
     "bt_block_step_enqueue": (c_int, [POINTER(bt_engine_desc), c_int32, c_int32, c_void_p]),
+    "bt_compact_enqueue": (c_int, [POINTER(bt_engine_desc), POINTER(bt_engine_desc), c_void_p, c_int64, c_void_p]),
     "bt_graph_begin_capture": (c_int, [c_void_p]),
     "bt_graph_end_capture": (c_int, [c_void_p, POINTER(c_void_p)]),
     "bt_graph_launch": (c_int, [c_void_p, c_void_p]),

@@ -171,6 +171,15 @@ int attention_impl(int dtype, int mode, int64_t B, int32_t q_len, int32_t heads,
                    int32_t pos0_host, const uint8_t* mask, int64_t mask_ld, void* out, int64_t ldo, int32_t n_split, void* ws,
                    int64_t ws_bytes, const int32_t* seq_skip, bt_stream stream);
 
+// ---- engine-side forms of bt_finish_block / bt_topk_sample (row_map of a compacted engine, device error flag) and the roll-over guard (misc.hip)
+int finish_block_impl(int64_t B, int32_t L, int32_t count, int64_t* raw, int64_t* out_ids, int64_t nb_max, const int32_t* blk_dev,
+                      int32_t* finished, int32_t* finished_prev, uint8_t* mask, int64_t mask_ld, int64_t config_pad, int64_t gen_eos,
+                      int64_t gen_pad, const int64_t* row_map, int32_t* err_flag, bt_stream stream);
+int topk_sample_impl(int dtype, int64_t M, int64_t V, const void* logits, int64_t ld, float temperature, int32_t top_k, uint64_t seed,
+                     const int32_t* step_dev, int64_t row0, const int64_t* row_map, int64_t* ids_out, int64_t ids_stride,
+                     bt_stream stream);
+int guard_ncur(int32_t* n_cur, int64_t n_max, int32_t* err_flag, bt_stream stream);
+
 // ---- <= 4 rows: QKV (LN1, RoPE, append) and h->4h (LN2, GELU) GEMVs of one layer as ONE launch (gemm.hip) ----------------------
 bool few_rows_dual_ok(int64_t M, int64_t H, int64_t I, int head_dim, int rot);
 int few_rows_qkv_h4(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, const void* x, int64_t ldx, const void* ln1_w,

@@ -316,8 +316,8 @@ extern "C" int bt_token_block_enqueue(const bt_engine_desc* e, int32_t t_begin, 
         if (e->do_sample) {
             BT_TRY(bt_linear(e->dtype, B, e->vocab, Htd, e->hid, Htd, e->embed_out, nullptr, nullptr, 0, e->logits, e->vocab,
                              BT_ACT_NONE, stream));
-            BT_TRY(bt_topk_sample(e->dtype, B, e->vocab, e->logits, e->vocab, e->temperature, e->top_k, e->seed,
-                                  e->sample_step, e->sample_row0, e->raw + t, e->L, stream));
+            BT_TRY(topk_sample_impl(e->dtype, B, e->vocab, e->logits, e->vocab, e->temperature, e->top_k, e->seed,
+                                    e->sample_step, e->sample_row0, e->row_map, e->raw + t, e->L, stream));
             BT_TRY(bt_bump(e->sample_step, 1, stream));
         } else {
             // logits GEMM + argmax; the token decoder's workspace is idle between its forward and the next step: it holds the
@@ -328,8 +328,8 @@ extern "C" int bt_token_block_enqueue(const bt_engine_desc* e, int32_t t_begin, 
     }
     if (finish_count > 0) {
         BT_CHECK_ARG(e->out_ids && e->n_cur && e->finished && e->finished_prev, "bt_token_block_enqueue: finish needs out_ids / n_cur / finished[_prev]");
-        BT_TRY(bt_finish_block(B, e->L, finish_count, e->raw, e->out_ids, e->nb_max, e->n_cur, e->finished, e->finished_prev,
-                               e->mask, e->mask_ld, e->config_pad, e->gen_eos, e->gen_pad, stream));
+        BT_TRY(finish_block_impl(B, e->L, finish_count, e->raw, e->out_ids, e->nb_max, e->n_cur, e->finished, e->finished_prev,
+                                 e->mask, e->mask_ld, e->config_pad, e->gen_eos, e->gen_pad, e->row_map, e->err_flag, stream));
     }
     return BT_OK;
 }
@@ -338,6 +338,8 @@ extern "C" int bt_roll_over_enqueue(const bt_engine_desc* e, bt_stream stream) {
     BT_TRY(check_desc(e, "bt_roll_over_enqueue", false, true));
     if (e->B == 0) return BT_OK;
     const int64_t B = e->B;
+    // device-side guard: this step appends at cache row *n_cur in every layer (the host cannot see a device scalar inside a replay)
+    if (e->err_flag) BT_TRY(guard_ncur(e->n_cur, e->g_nmax, e->err_flag, stream));
     // embedder lookup + concat of the block just finished; zero rows for sequences that were finished before it (:419-421)
     BT_TRY(bt_embed_rows(e->dtype, B * e->L, e->emb_width, e->raw, 1, e->vocab, e->emb_table, e->x_blk, e->emb_width,
                          e->finished_prev, e->L, stream));

@@ -87,7 +87,8 @@ constexpr int MAX_CAND = 1024;
 template <typename T>
 __global__ __launch_bounds__(256) void topk_sample_kernel(const T* __restrict__ logits, int64_t ld, int V_, float inv_temp,
                                                          int top_k, uint64_t seed, const int32_t* __restrict__ step_dev,
-                                                         int64_t row0, int64_t* __restrict__ ids_out, int64_t ids_stride) {
+                                                         int64_t row0, const int64_t* __restrict__ row_map,
+                                                         int64_t* __restrict__ ids_out, int64_t ids_stride) {
     __shared__ int hist[256];
     __shared__ uint32_t s_prefix, s_mask;
     __shared__ int s_k;
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(256) void topk_sample_kernel(const T* __restrict__ 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const T* row = logits + (int64_t)blockIdx.x * ld;
     const uint64_t rnd = splitmix64(splitmix64(seed ^ (uint64_t)(step_dev ? *step_dev : 0) * 0x100000001b3ull) +
-                                    (uint64_t)(row0 + blockIdx.x));
+                                    (uint64_t)(row0 + (row_map ? row_map[blockIdx.x] : (int64_t)blockIdx.x)));
     const float u01 = (float)((rnd >> 40) & 0xffffff) * (1.0f / 16777216.0f);
 
     if (top_k > 0 && top_k < V_) {
@@ -230,9 +231,15 @@ __global__ __launch_bounds__(1024) void finish_block_kernel(int64_t B, int L, in
                                                            int32_t* __restrict__ finished,
                                                            int32_t* __restrict__ finished_prev,
                                                            uint8_t* __restrict__ mask, int64_t mask_ld,
-                                                           int64_t config_pad, int64_t gen_eos, int64_t gen_pad) {
+                                                           int64_t config_pad, int64_t gen_eos, int64_t gen_pad,
+                                                           const int64_t* __restrict__ row_map, int32_t* __restrict__ err_flag) {
     __shared__ int s_stop;
     const int blk = *blk_dev;
+    // device-side guard (a binder replaying the block step past the end of its buffers): flag it, write nothing
+    if (blk < 0 || blk >= nb_max || (mask && blk >= mask_ld)) {
+        if (threadIdx.x == 0 && err_flag) atomicOr(err_flag, BT_DEV_ERR_BLOCK_RANGE);
+        return;
+    }
     if (threadIdx.x == 0) s_stop = -1;
     __syncthreads();
     // HF greedy_search stops right after the first step at which every active row has produced EOS (Q6)
@@ -250,10 +257,13 @@ __global__ __launch_bounds__(1024) void finish_block_kernel(int64_t B, int L, in
     for (int64_t b = threadIdx.x; b < B; b += blockDim.x) {
         bool fin = finished[b] != 0;
         if (finished_prev) finished_prev[b] = fin ? 1 : 0;
+        // row of out_ids: the sequence's ORIGINAL batch row once the engine has been compacted (< 0: padding row)
+        const int64_t orow = row_map ? row_map[b] : b;
+        int64_t* __restrict__ dst = out_ids + (orow * nb_max + blk) * L;
         if (fin) {
             for (int t = 0; t < L; ++t) {
                 raw[b * L + t] = config_pad;
-                out_ids[(b * nb_max + blk) * L + t] = config_pad;
+                if (orow >= 0) dst[t] = config_pad;
             }
         } else {
             bool seen = false, any_eos = false;
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(1024) void finish_block_kernel(int64_t B, int L, in
                 }
                 any_eos = any_eos || (gen_eos >= 0 && tok == gen_eos);
                 raw[b * L + t] = tok;
-                out_ids[(b * nb_max + blk) * L + t] = tok;
+                if (orow >= 0) dst[t] = tok;
             }
             fin = any_eos;  // unfinished *= next_tokens.ne(eos).all(-1)   (block_transformer.py:411-412)
             finished[b] = fin ? 1 : 0;
@@ -277,6 +287,69 @@ __global__ __launch_bounds__(1024) void finish_block_kernel(int64_t B, int L, in
 }
 
 __global__ void bump_kernel(int32_t* c, int32_t d) { *c += d; }
+
+// bt_roll_over_enqueue's guard: the block-decoder step appends at global cache row *n_cur
+__global__ void guard_ncur_kernel(int32_t* n_cur, int32_t n_max, int32_t* err_flag) {
+    if (*n_cur >= n_max || *n_cur < 0) {
+        atomicOr(err_flag, BT_DEV_ERR_CACHE_FULL);
+        *n_cur = n_max - 1;
+    }
+}
+
+// ---- bt_compact_enqueue ------------------------------------------------------------------------------------------------------
+// K/V rows of sequence live[i] -> sequence slot i, in place.  grid.x = 4 KiB chunks of one (sequence, head) slab's first
+// *n_cur positions (contiguous: [n_max][d] per head), grid.y = (layer, head, K|V).  A thread owns ONE 16-byte offset of the slab and
+// walks i upward: slot i is written after slot live[i] >= i was read, and later sources live[i'] > live[i] >= i are never a slot
+// this thread has written -- so U loads go out back to back before their stores (U x 16 B per thread in flight), no barrier.
+constexpr int COMPACT_U = 8;
+__global__ __launch_bounds__(256) void compact_kv_kernel(char* __restrict__ k, char* __restrict__ v, int64_t layer_stride_b,
+                                                         int64_t seq_stride_b, int64_t head_stride_b, int heads, int row_bytes,
+                                                         const int64_t* __restrict__ live, int n_live,
+                                                         const int32_t* __restrict__ n_cur_dev, int n_max) {
+    const int n = min(max(*n_cur_dev, 0), n_max);
+    const int64_t span = (int64_t)n * row_bytes;
+    const int64_t off = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (off >= span) return;
+    const int y = blockIdx.y;
+    const int lh = y >> 1;
+    char* base = ((y & 1) ? v : k) + (int64_t)(lh / heads) * layer_stride_b + (int64_t)(lh % heads) * head_stride_b + off;
+    int i = 0;
+    while (i < n_live && live[i] == i) ++i;   // rows already in place (wave-uniform scalar loads)
+    for (; i < n_live; i += COMPACT_U) {
+        uint4 t[COMPACT_U];
+#pragma unroll
+        for (int u = 0; u < COMPACT_U; ++u)
+            if (i + u < n_live) t[u] = *reinterpret_cast<const uint4*>(base + live[i + u] * seq_stride_b);
+#pragma unroll
+        for (int u = 0; u < COMPACT_U; ++u)
+            if (i + u < n_live) *reinterpret_cast<uint4*>(base + (int64_t)(i + u) * seq_stride_b) = t[u];
+    }
+}
+
+// the small per-sequence state of the compacted engine (its own buffers: a plain gather); one workgroup per dst row
+__global__ __launch_bounds__(64) void compact_state_kernel(const int64_t* __restrict__ live, int n_live, int L,
+                                                          const uint8_t* __restrict__ s_mask, int64_t s_mask_ld,
+                                                          uint8_t* __restrict__ d_mask, int64_t d_mask_ld,
+                                                          const int64_t* __restrict__ s_raw, int64_t* __restrict__ d_raw,
+                                                          int32_t* __restrict__ d_fin, int32_t* __restrict__ d_fin_prev,
+                                                          const int64_t* __restrict__ s_map, int64_t* __restrict__ d_map,
+                                                          const int32_t* __restrict__ s_ncur, int32_t* __restrict__ d_ncur) {
+    const int i = blockIdx.x, tid = threadIdx.x;
+    const bool real = i < n_live;
+    const int64_t src = real ? live[i] : 0;
+    if (d_mask) {
+        const int64_t w = min(s_mask_ld, d_mask_ld);
+        for (int64_t c = tid; c < d_mask_ld; c += 64)
+            d_mask[i * d_mask_ld + c] = (real && s_mask && c < w) ? s_mask[src * s_mask_ld + c] : (uint8_t)1;
+    }
+    for (int t = tid; t < L; t += 64) d_raw[(int64_t)i * L + t] = real ? s_raw[src * L + t] : 0;
+    if (tid == 0) {
+        d_fin[i] = real ? 0 : 1;
+        d_fin_prev[i] = real ? 0 : 1;
+        d_map[i] = real ? (s_map ? s_map[src] : src) : -1;
+        if (i == 0) *d_ncur = *s_ncur;
+    }
+}
 
 #ifdef BT_DEBUG_HOOKS
 // debug probe of ds_read_b64_tr_b16: lds[i] = in[i] (4096 shorts); lane l reads at element offset addr[l]; out[l*4 + j]
@@ -352,9 +425,9 @@ extern "C" int bt_argmax(int dtype, int64_t M, int64_t V, const void* logits, in
     return launch_argmax<float>(M, V, logits, ld, ids_out, ids_stride, (hipStream_t)stream);
 }
 
-extern "C" int bt_topk_sample(int dtype, int64_t M, int64_t V, const void* logits, int64_t ld, float temperature,
-                              int32_t top_k, uint64_t seed, const int32_t* step_dev, int64_t row0, int64_t* ids_out,
-                              int64_t ids_stride, bt_stream stream) {
+int bt::topk_sample_impl(int dtype, int64_t M, int64_t V, const void* logits, int64_t ld, float temperature, int32_t top_k,
+                         uint64_t seed, const int32_t* step_dev, int64_t row0, const int64_t* row_map, int64_t* ids_out,
+                         int64_t ids_stride, bt_stream stream) {
     BT_CHECK_ARG(dtype == BT_F32 || dtype == BT_BF16, "bt_topk_sample: bad dtype %d", dtype);
     BT_CHECK_ARG(M >= 0 && V > 0 && V < (1ll << 31) && ld >= V && M < (1ll << 31), "bt_topk_sample: bad shape");
     BT_CHECK_ARG(logits && ids_out, "bt_topk_sample: null pointer");
@@ -369,11 +442,32 @@ extern "C" int bt_topk_sample(int dtype, int64_t M, int64_t V, const void* logit
     ProfScope ps(BT_PROF_SAMPLE, s);
     if (dtype == BT_BF16)
         hipLaunchKernelGGL(topk_sample_kernel<bf16>, dim3((unsigned)M), dim3(256), 0, s, (const bf16*)logits, ld, (int)V,
-                           1.0f / temperature, top_k, seed, step_dev, row0, ids_out, ids_stride);
+                           1.0f / temperature, top_k, seed, step_dev, row0, row_map, ids_out, ids_stride);
     else
         hipLaunchKernelGGL(topk_sample_kernel<float>, dim3((unsigned)M), dim3(256), 0, s, (const float*)logits, ld,
-                           (int)V, 1.0f / temperature, top_k, seed, step_dev, row0, ids_out, ids_stride);
+                           (int)V, 1.0f / temperature, top_k, seed, step_dev, row0, row_map, ids_out, ids_stride);
     BT_LAUNCH_CHECK("bt_topk_sample launch");
+    return BT_OK;
+}
+
+extern "C" int bt_topk_sample(int dtype, int64_t M, int64_t V, const void* logits, int64_t ld, float temperature,
+                              int32_t top_k, uint64_t seed, const int32_t* step_dev, int64_t row0, int64_t* ids_out,
+                              int64_t ids_stride, bt_stream stream) {
+    return topk_sample_impl(dtype, M, V, logits, ld, temperature, top_k, seed, step_dev, row0, nullptr, ids_out, ids_stride, stream);
+}
+
+int bt::finish_block_impl(int64_t B, int32_t L, int32_t count, int64_t* raw, int64_t* out_ids, int64_t nb_max,
+                          const int32_t* blk_dev, int32_t* finished, int32_t* finished_prev, uint8_t* mask, int64_t mask_ld,
+                          int64_t config_pad, int64_t gen_eos, int64_t gen_pad, const int64_t* row_map, int32_t* err_flag,
+                          bt_stream stream) {
+    BT_CHECK_ARG(B >= 0 && L > 0 && count >= 0 && count <= L, "bt_finish_block: bad shape B=%lld L=%d count=%d",
+                 (long long)B, L, count);
+    BT_CHECK_ARG(raw && out_ids && blk_dev && finished, "bt_finish_block: null pointer");
+    if (B == 0) return BT_OK;
+    ProfScope ps(BT_PROF_FINISH, (hipStream_t)stream);
+    hipLaunchKernelGGL(finish_block_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, L, count, raw, out_ids,
+                       nb_max, blk_dev, finished, finished_prev, mask, mask_ld, config_pad, gen_eos, gen_pad, row_map, err_flag);
+    BT_LAUNCH_CHECK("bt_finish_block launch");
     return BT_OK;
 }
 
@@ -381,14 +475,48 @@ extern "C" int bt_finish_block(int64_t B, int32_t L, int32_t count, int64_t* raw
                                const int32_t* blk_dev, int32_t* finished, int32_t* finished_prev, uint8_t* mask,
                                int64_t mask_ld, int64_t config_pad, int64_t gen_eos, int64_t gen_pad,
                                bt_stream stream) {
-    BT_CHECK_ARG(B >= 0 && L > 0 && count >= 0 && count <= L, "bt_finish_block: bad shape B=%lld L=%d count=%d",
-                 (long long)B, L, count);
-    BT_CHECK_ARG(raw && out_ids && blk_dev && finished, "bt_finish_block: null pointer");
-    if (B == 0) return BT_OK;
-    ProfScope ps(BT_PROF_FINISH, (hipStream_t)stream);
-    hipLaunchKernelGGL(finish_block_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, B, L, count, raw, out_ids,
-                       nb_max, blk_dev, finished, finished_prev, mask, mask_ld, config_pad, gen_eos, gen_pad);
-    BT_LAUNCH_CHECK("bt_finish_block launch");
+    return finish_block_impl(B, L, count, raw, out_ids, nb_max, blk_dev, finished, finished_prev, mask, mask_ld, config_pad,
+                             gen_eos, gen_pad, nullptr, nullptr, stream);
+}
+
+int bt::guard_ncur(int32_t* n_cur, int64_t n_max, int32_t* err_flag, bt_stream stream) {
+    hipLaunchKernelGGL(guard_ncur_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, n_cur, (int32_t)n_max, err_flag);
+    BT_LAUNCH_CHECK("bt_roll_over_enqueue guard launch");
+    return BT_OK;
+}
+
+extern "C" int bt_compact_enqueue(const bt_engine_desc* src, const bt_engine_desc* dst, const int64_t* live_rows, int64_t n_live,
+                                  bt_stream stream) {
+    BT_CHECK_ARG(src && dst && live_rows, "bt_compact_enqueue: null pointer");
+    BT_CHECK_ARG(n_live >= 0 && n_live <= dst->B && dst->B <= src->B && n_live < (1ll << 31), "bt_compact_enqueue: bad row counts "
+                 "(n_live %lld, dst B %lld, src B %lld)", (long long)n_live, (long long)dst->B, (long long)src->B);
+    BT_CHECK_ARG(src->gk && src->gv && src->gk == dst->gk && src->gv == dst->gv && src->g_layer_stride == dst->g_layer_stride &&
+                     src->g_nmax == dst->g_nmax && src->dtype == dst->dtype && src->L == dst->L,
+                 "bt_compact_enqueue: dst must describe the same global KV storage as src");
+    BT_CHECK_ARG(src->n_cur && src->raw && dst->n_cur && dst->raw && dst->finished && dst->finished_prev && dst->row_map,
+                 "bt_compact_enqueue: null state buffer (n_cur / raw / finished / finished_prev / row_map)");
+    BT_CHECK_ARG(dst->raw != src->raw && dst->finished != src->finished && dst->n_cur != src->n_cur &&
+                     (!dst->mask || dst->mask != src->mask) && dst->row_map != src->row_map,
+                 "bt_compact_enqueue: dst's state buffers must be distinct from src's (only the KV storage is compacted in place)");
+    if (dst->B == 0) return BT_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const bt_decoder_dims& d = src->bd_dims;
+    const int64_t es = (int64_t)dtype_size(src->dtype);
+    const int64_t row_bytes = (int64_t)d.head_dim * es;
+    BT_CHECK_ARG(row_bytes % 16 == 0 && aligned16(src->gk) && aligned16(src->gv), "bt_compact_enqueue: K/V rows must be 16-byte multiples");
+    if (n_live > 0) {
+        const int64_t head_stride_b = src->g_nmax * row_bytes, seq_stride_b = (int64_t)d.heads * head_stride_b;
+        const unsigned gx = (unsigned)ceil_div(head_stride_b, 4096);
+        ProfScope ps(BT_PROF_EMBED, s);
+        hipLaunchKernelGGL(compact_kv_kernel, dim3(gx, (unsigned)(d.layers * d.heads * 2)), dim3(256), 0, s, (char*)src->gk,
+                           (char*)src->gv, src->g_layer_stride * es, seq_stride_b, head_stride_b, d.heads, (int)row_bytes, live_rows,
+                           (int)n_live, src->n_cur, (int)src->g_nmax);
+        BT_LAUNCH_CHECK("bt_compact_enqueue KV launch");
+    }
+    hipLaunchKernelGGL(compact_state_kernel, dim3((unsigned)dst->B), dim3(64), 0, s, live_rows, (int)n_live, (int)src->L, src->mask,
+                       src->mask_ld, dst->mask, dst->mask_ld, src->raw, dst->raw, dst->finished, dst->finished_prev, src->row_map,
+                       const_cast<int64_t*>(dst->row_map), src->n_cur, dst->n_cur);
+    BT_LAUNCH_CHECK("bt_compact_enqueue state launch");
     return BT_OK;
 }
 

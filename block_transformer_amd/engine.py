@@ -11,13 +11,16 @@ State lives in preallocated HBM buffers with fixed addresses, described once to 
 The Python side only captures those calls into hipGraphs once and replays them per block; everything that changes between
 replays (the number of cached block positions n, finished flags, the sampler's draw counter) is a device scalar read by
 the kernels.  Finished sequences are masked inside an engine (fixed batch => static shapes => graph replay); the reference
-instead compacts the batch with boolean indexing every block (model/block_transformer.py:381-398,421; C13/C14).  Round 3 adds
-compaction at bucket granularity: with EOS handling on, the per-block host look at ``finished[]`` (the reference's own sync,
+instead compacts the batch with boolean indexing every block (model/block_transformer.py:381-398,421; C13/C14).  Compaction
+here happens at bucket granularity: with EOS handling on, the per-block host look at ``finished[]`` (the reference's own sync,
 :415) counts the live sequences, and once at most half of an engine's rows are live the loop continues on a smaller engine
-(``DecodeEngine.compacted``): the live rows' global KV is moved to the front of the SAME cache storage, the small engine gets its
-own activation buffers and graphs, and its blocks are scattered back into the full ``out_ids`` at the end.  Greedy decoding only
-(the sampler's RNG streams are keyed by row index).  Local-KV "reset" costs nothing: every token block starts writing the
-local cache at row 0 again.
+(``DecodeEngine.compacted``).  Since round 4 that is ONE C call, ``bt_compact_enqueue``: the live rows' global KV moves to the
+front of the SAME cache storage in place (no temporary), and the small engine is a *view* of the root engine -- the same
+activation buffers, workspaces and local KV, its own graphs and a few KB of per-row state -- that writes its blocks straight
+into the root's ``out_ids`` through ``bt_engine_desc.row_map`` (original row of each compacted row).  The sampler keys its RNG
+streams by the same map, so compaction also runs under ``do_sample`` and with a streamer (the path inference_demo.py:62-83
+takes); the streamer then receives the live rows only, like the reference's token decoder, which only ever sees
+``decode_mask`` rows.  Local-KV "reset" costs nothing: every token block starts writing the local cache at row 0 again.
 
 ``PipelinedEngine`` (opt-in: ``model.pipeline = True`` / ``BT_PIPELINE=1``) runs TWO half-batch shards on two HIP streams,
 one token block apart, so that shard A's global-KV stream (block-decoder step, HBM-bound, matrix cores idle) can overlap
@@ -110,6 +113,25 @@ class TokenBlockState:
                         if batch <= 256 else None)
         self._desc: Optional[bt_engine_desc] = None   # stand-alone descriptor (token_decoder.generate)
 
+    @classmethod
+    def view(cls, parent: "TokenBlockState", batch: int) -> "TokenBlockState":
+        """The first ``batch`` sequences of ``parent``, sharing its buffers (a compacted engine): nothing on the token side
+        carries state across a roll-over except the block's raw tokens, which the view owns."""
+        assert 0 < batch <= parent.B
+        self = cls.__new__(cls)
+        self.__dict__.update(parent.__dict__)
+        self.B = batch
+        self.local = KVCache.rows_of(parent.local, batch)
+        dev = parent.raw.device
+        self.raw = torch.zeros(batch, parent.L, dtype=torch.int64, device=dev)
+        need = max(self.rt.workspace_bytes(batch * self.E), self.rt.workspace_bytes(batch))
+        if parent.ws.numel() < need:      # a <= 256-row view of a large engine: its own split-K scratch (mid-batch path)
+            self.ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        if batch <= 256 and parent.scratch is None:
+            self.scratch = torch.empty(16 * batch * self.E * self.H, dtype=torch.float32, device=dev)
+        self._desc = None
+        return self
+
     def weight_key(self):
         td = self.td
         return (self.rt.weight_key(), td.expansion_layer.weight.data_ptr(),
@@ -181,8 +203,11 @@ class DecodeEngine:
 
     def __init__(self, model, batch: int, max_blocks: int, rope_policy: str = DEFAULT_ROPE_POLICY,
                  prefill_rows: Optional[int] = None, stream: Optional[torch.cuda.Stream] = None,
-                 kv_rows_of: Optional[KVCache] = None):
+                 view_of: Optional["DecodeEngine"] = None):
         self.model = model
+        if view_of is not None:
+            self._init_view(view_of, batch)
+            return
         bd, td = model.block_decoder, model.token_decoder
         self.bd_rt: DecoderRuntime = bd._rt
         dev = self.bd_rt.device
@@ -193,10 +218,11 @@ class DecodeEngine:
         self.H = bd.config.hidden_size
         heads = bd.config.num_attention_heads
         self.n_max = max(max_blocks, 1)
-        # a compacted engine works on the first `batch` sequences of its parent's cache storage
-        self.glob = (KVCache(bd.config.num_hidden_layers, batch, heads, self.n_max, self.H // heads, dt, dev)
-                     if kv_rows_of is None else KVCache.rows_of(kv_rows_of, batch))
-        self._children = {}       # compacted engines by batch size (buffers and graphs are reused across generate() calls)
+        self.glob = KVCache(bd.config.num_hidden_layers, batch, heads, self.n_max, self.H // heads, dt, dev)
+        self.root = self
+        self._children = {}       # compacted views by batch size (state buffers and graphs are reused across generate() calls)
+        self.row_map: Optional[torch.Tensor] = None     # identity
+        self.err_flag = torch.zeros(1, dtype=torch.int32, device=dev)   # sticky device-side guard bits (BT_DEV_ERR_*)
         self.rope_policy = rope_policy
         self.tok = TokenBlockState(td, batch, dev, rope_policy)
         self.rope = ops.rope_tables(self.n_max, self.bd_rt.dims.rot,
@@ -231,6 +257,45 @@ class DecodeEngine:
         self.graphs = {}
         self._graph_key = None
 
+    def _init_view(self, root: "DecodeEngine", batch: int) -> None:
+        """A compacted engine: the first ``batch`` sequence slots of ``root`` (same KV storage, activation buffers, workspaces,
+        stream, out_ids) with its own per-row state (mask, finished flags, raw tokens, n_cur, row_map) and its own graphs."""
+        assert root.root is root and 0 < batch <= root.B
+        self.root = root
+        self.bd_rt, self.device, self.dtype = root.bd_rt, root.device, root.dtype
+        self.B, self.NB, self.L, self.H, self.n_max = batch, root.NB, root.L, root.H, root.n_max
+        dev = self.device
+        self.glob = KVCache.rows_of(root.glob, batch)
+        self._children = None
+        self.rope_policy = root.rope_policy
+        self.tok = TokenBlockState.view(root.tok, batch)
+        self.rope = root.rope
+        self.x_blk, self.ctx = root.x_blk[:batch], root.ctx[:batch]
+        self.out_ids = root.out_ids                       # written at row_map[b]
+        self.mask = torch.ones(batch, self.n_max + 1, dtype=torch.uint8, device=dev)
+        self.finished = torch.zeros(batch, dtype=torch.int32, device=dev)
+        self.finished_prev = torch.zeros(batch, dtype=torch.int32, device=dev)
+        self.row_map = torch.full((batch,), -1, dtype=torch.int64, device=dev)
+        self.err_flag = root.err_flag
+        self.stream = root.stream
+        self.n_cur = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.prefill_rows = root.prefill_rows
+        need = self.bd_rt.workspace_bytes(batch)
+        self.ws_step = root.ws_step if root.ws_step.numel() >= need else torch.empty(need, dtype=torch.uint8, device=dev)
+        self.ws_prefill = self.x_prefill = None
+        heads = self.glob.k.shape[2]
+        hint, work = 1, batch * heads
+        if work < 512 and self.n_max >= 256:
+            hint = int(min(16, max(1, 1024 // max(work, 1)), max(1, self.n_max // 64)))
+        self.n_split = int(lib().bt_attention_split_count(self.H // heads, self.n_max, hint))
+        self.split_ws = None
+        if self.n_split > 1:
+            self.split_ws = torch.empty(batch * heads * self.n_split * (self.H // heads + 2), dtype=torch.float32, device=dev)
+        self.desc = bt_engine_desc()
+        self._desc_key = None
+        self.graphs = {}
+        self._graph_key = None
+
     # ---- descriptor ----------------------------------------------------------------------------------------------------------
     def weight_key(self):
         emb = self.model.embedder.embeddings.weight
@@ -260,6 +325,8 @@ class DecodeEngine:
         d.n_split = self.n_split
         d.split_ws = ptr(self.split_ws)
         d.split_ws_bytes = 0 if self.split_ws is None else self.split_ws.numel() * 4
+        d.row_map = ptr(self.row_map)
+        d.err_flag = self.err_flag.data_ptr()
         self._desc_key = key
         self.graphs = {}          # captured graphs bake in the old parameter pointers
 
@@ -332,14 +399,16 @@ class DecodeEngine:
             self.graphs[what] = g
         g.launch()
 
-    def token_block_streamed(self, count: int, streamer):
-        """Eager token block with one host callback per token (HF streamer protocol, inference_demo.py:69-83)."""
+    def token_block_streamed(self, count: int, streamer, n_real: Optional[int] = None):
+        """Eager token block with one host callback per token (HF streamer protocol, inference_demo.py:69-83).  ``n_real``:
+        rows of a compacted engine that carry a sequence (the streamer sees those, like the reference's token decoder)."""
         d = ctypes.byref(self.desc)
-        streamer.block_start()
+        n = self.B if n_real is None else n_real
+        streamer.block_start(n)
         for t in range(count):
             fin = count if t == count - 1 else 0
             check(lib().bt_token_block_enqueue(d, t, t + 1, fin, current_stream()), "bt_token_block_enqueue")
-            streamer.put(self.tok.raw[:, t])
+            streamer.put(self.tok.raw[:n, t])
         streamer.block_end()
 
     # ---- the generate loop -------------------------------------------------------------------------------------------------
@@ -362,13 +431,9 @@ class DecodeEngine:
             # EOS handling needs a host look at finished[] between the token block and the roll-over (like the
             # reference, :415); without it a block step is ONE graph (token block + roll-over)
             fused_step = use_graphs and gen_eos < 0 and streamer is None and not per_iter
-            do_sample = bool(gen is not None and getattr(gen, "do_sample", False))
-            compacting = (gen_eos >= 0 and streamer is None and not do_sample
-                          and bool(getattr(self.model, "compact_finished", True)))
-            eng = self                    # the engine the loop currently runs on (self, or a compacted descendant)
-            rows = None                   # global row of each of eng's real rows (None = identity)
+            compacting = gen_eos >= 0 and bool(getattr(self.model, "compact_finished", True))
+            eng = self                    # the engine the loop currently runs on (self, or a compacted view of it)
             n_real = B                    # eng's rows that carry a sequence (the rest of a compacted engine is padding)
-            blk0 = nb                     # first block eng has generated itself
             self.compactions = []         # (block index, live sequences, new batch) of this call: diagnostics / tests
             while True:
                 count = min(max_length - (n_blocks * L - added_pad), L)
@@ -376,7 +441,7 @@ class DecodeEngine:
                 if per_iter:
                     timers.mark_iter("token_decoder_start")
                 if streamer is not None:
-                    eng.token_block_streamed(count, streamer)
+                    eng.token_block_streamed(count, streamer, n_real)
                 elif fused_step and not last and count == L:
                     eng.launch("step", L, True)
                     n_blocks += 1
@@ -394,59 +459,50 @@ class DecodeEngine:
                     if n_live == 0:
                         break
                     if compacting and eng.B >= self.MIN_COMPACT_BATCH and 2 * n_live <= eng.B:
-                        # reference :381-398,421: only decode_mask rows go on.  Blocks eng generated so far go home first.
-                        self._collect(eng, rows, n_real, blk0, n_blocks, cfg_pad)
-                        child = eng.compacted(live, n_blocks, gen, cfg_pad)
-                        rows = live if rows is None else rows[live]
+                        # reference :381-398,421: only decode_mask rows go on
+                        if eng is self:   # rows that drop out keep the pad id in every later block (:384)
+                            self.out_ids[:, n_blocks:].fill_(int(cfg_pad))
+                        child = self.compacted(eng, live, gen, cfg_pad)
                         self.compactions.append((n_blocks, n_live, child.B))
-                        eng, n_real, blk0 = child, n_live, n_blocks
+                        eng, n_real = child, n_live
                 if per_iter:
                     timers.mark_iter("block_decoder_start")
                 eng.launch("roll", 0, use_graphs and streamer is None)
                 if per_iter:
                     timers.mark_iter("block_decoder_end")
-            if eng is not self:
-                self._collect(eng, rows, n_real, blk0, n_blocks, cfg_pad)
             if timers is not None:
                 timers.mark("decode_end")
         torch.cuda.current_stream().wait_stream(side)
+        self.check_device_errors()
         return self.out_ids[:, :n_blocks], count
 
-    # ---- compaction of finished sequences --------------------------------------------------------------------------------
-    def _collect(self, eng: "DecodeEngine", rows, n_real: int, blk_lo: int, blk_hi: int, cfg_pad: int) -> None:
-        """Blocks [blk_lo, blk_hi) generated by a compacted engine -> the root's out_ids, at the sequences' original rows; the
-        first time (eng is the root) every later block of every row is pre-filled with the pad id finished rows receive
-        (model/block_transformer.py:384: next_tokens = full(pad_token_id))."""
-        if eng is self:
-            self.out_ids[:, blk_hi:].fill_(int(cfg_pad))
-            return
-        if blk_hi > blk_lo:
-            self.out_ids[rows, blk_lo:blk_hi] = eng.out_ids[:n_real, blk_lo:blk_hi]
+    def check_device_errors(self) -> None:
+        """Read the sticky bits the device-side guards set (bt_engine_desc.err_flag).  The Python loop bounds the block count
+        itself (n_blocks <= NB by construction), so this can only fire on an engine misuse -- it is the same check a C binder
+        that replays its captured block step makes after its last replay."""
+        bits = int(self.err_flag.item())
+        if bits:
+            self.err_flag.zero_()
+            what = [n for b, n in ((_lib.BT_DEV_ERR_CACHE_FULL, "global KV cache full (roll-over past g_nmax)"),
+                                   (_lib.BT_DEV_ERR_BLOCK_RANGE, "block index past out_ids / mask")) if bits & b]
+            raise _lib.BtError("device-side guard tripped: " + ", ".join(what))
 
-    def compacted(self, live: torch.Tensor, n_cached: int, gen, cfg_pad: int) -> "DecodeEngine":
-        """The engine that continues only the sequences ``live`` (ascending row indices of this engine) after a token block:
-        their global KV rows move to the front of the shared cache storage (in place, layer by layer), and a smaller engine
-        (batch = live count rounded up to COMPACT_BUCKET; the surplus rows are inert: finished, attention skipped) takes over
-        the device-side state the roll-over needs: n_cur, the block just decoded, the block mask."""
+    # ---- compaction of finished sequences --------------------------------------------------------------------------------
+    def compacted(self, eng: "DecodeEngine", live: torch.Tensor, gen, cfg_pad: int) -> "DecodeEngine":
+        """The view of this (root) engine that continues only the sequences ``live`` (ascending row indices of ``eng`` = this
+        engine or one of its views) after a token block: batch = live count rounded up to COMPACT_BUCKET (the surplus rows are
+        inert padding: finished, attention skipped, row_map -1 -> nothing of theirs is written).  bt_compact_enqueue moves the
+        live rows' global KV to the front of the shared cache storage in place and fills the view's per-row state."""
+        assert self.root is self and eng.root is self
         n = int(live.numel())
-        Bc = min(self.B, -(-n // self.COMPACT_BUCKET) * self.COMPACT_BUCKET)
+        Bc = min(eng.B, -(-n // self.COMPACT_BUCKET) * self.COMPACT_BUCKET)
         child = self._children.get(Bc)
         if child is None:
-            child = self._children[Bc] = DecodeEngine(self.model, Bc, self.NB, self.rope_policy, stream=self.stream,
-                                                      kv_rows_of=self.glob)
-        k, v = self.glob.k, self.glob.v
-        for l in range(k.shape[0]):        # row i <- row live[i] >= i: gather to a temporary, then write the front
-            k[l, :n, :, :n_cached] = k[l, :, :, :n_cached].index_select(0, live)
-            v[l, :n, :, :n_cached] = v[l, :, :, :n_cached].index_select(0, live)
+            child = self._children[Bc] = DecodeEngine(self.model, Bc, self.NB, view_of=self)
+        assert child is not eng
         child.configure(gen, cfg_pad, True)
-        child.n_cur.copy_(self.n_cur)
-        child.finished.fill_(1)
-        child.finished[:n] = 0
-        child.finished_prev.copy_(child.finished)
-        child.mask.fill_(1)
-        child.mask[:n, :self.mask.shape[1]] = self.mask[live]
-        child.tok.raw.zero_()
-        child.tok.raw[:n] = self.tok.raw[live]
+        check(lib().bt_compact_enqueue(ctypes.byref(eng.desc), ctypes.byref(child.desc), ptr(live.contiguous()), n,
+                                       current_stream()), "bt_compact_enqueue")
         return child
 
 

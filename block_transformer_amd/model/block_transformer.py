@@ -312,8 +312,9 @@ class _BlockStreamer:
     def put(self, t: torch.Tensor):
         self.s.put(t.cpu())
 
-    def block_start(self):
-        self.s.put(torch.full((self.B, 1), self.eos, dtype=torch.long))
+    def block_start(self, n=None):
+        """``n``: rows the token decoder runs on (the live rows once the batch has been compacted; reference :389-398)."""
+        self.s.put(torch.full((self.B if n is None else n, 1), self.eos, dtype=torch.long))
 
     def block_end(self):
         self.s.end()

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define BT_VERSION 200 /* 0.2.0: bt_engine_desc + bt_*_enqueue */
+#define BT_VERSION 210 /* 0.2.1: bt_engine_desc.row_map / err_flag, bt_compact_enqueue */
 
 typedef void* bt_stream; /* hipStream_t */
 
@@ -305,7 +305,20 @@ typedef struct bt_engine_desc {
     int64_t config_pad;      /* token_decoder.config.pad_token_id (fills the unfilled tail of a partial block) */
     int64_t gen_eos;         /* generation_config.eos_token_id, < 0 = EOS handling disabled */
     int64_t gen_pad;         /* pad written after EOS */
+    /* ---- since 0.2.1 (compaction of finished sequences; overflow guard) ---- */
+    const int64_t* row_map;  /* [B] or NULL (identity): ORIGINAL batch row of engine row b after bt_compact_enqueue -- the row of
+                                out_ids bt_finish_block writes and the RNG stream bt_topk_sample draws from (key = seed, step,
+                                sample_row0 + row_map[b]); < 0 marks a padding row of a compacted engine (nothing is written) */
+    int32_t* err_flag;       /* device int32 or NULL: sticky error bits set by the device-side guards (BT_DEV_ERR_*); the host reads
+                                it whenever it synchronises anyway.  With it set, bt_roll_over_enqueue clamps *n_cur to g_nmax - 1
+                                before anything is appended (a binder replaying one graph too many overwrites the last cache row
+                                and gets the flag instead of writing past the cache) */
 } bt_engine_desc;
+
+enum bt_dev_err {
+    BT_DEV_ERR_CACHE_FULL = 1, /* bt_roll_over_enqueue found *n_cur >= g_nmax */
+    BT_DEV_ERR_BLOCK_RANGE = 2 /* bt_finish_block found *n_cur >= nb_max (out_ids) or >= mask_ld (mask): nothing was written */
+};
 
 /* Prefill of sequences [b0, b0+nseq): embed their nb prompt blocks (block_ids [B, nb, L] int64 on device), run the block
  * decoder over them (causal, mode 1 = MFMA flash for bf16 when nb > 1) writing global KV rows 0..nb-1, and leave the last
@@ -324,6 +337,22 @@ int bt_roll_over_enqueue(const bt_engine_desc* e, bt_stream stream);
 /* One full block step = bt_token_block_enqueue(e, 0, count, count) followed, when roll != 0, by bt_roll_over_enqueue:
  * the unit that is hipGraph-captured. */
 int bt_block_step_enqueue(const bt_engine_desc* e, int32_t count, int32_t roll, bt_stream stream);
+
+/* Compaction of finished sequences between a token block and the roll-over (reference model/block_transformer.py:381-398,421:
+ * only decode_mask rows are decoded; inference_demo.py:62-83 runs exactly this mode -- sampling, EOS on).  `live_rows` =
+ * device array of n_live ASCENDING row indices of `src` that continue.  `dst` describes the engine that carries on: the SAME
+ * global KV storage as src (gk / gv / g_layer_stride / g_nmax equal), dst->B in [n_live, src->B], and its OWN small state
+ * buffers (mask, raw, finished, finished_prev, n_cur, row_map -- distinct from src's; all required except mask).
+ *   - global K/V rows of sequence live_rows[i] move to sequence slot i, positions [0, *src->n_cur), layer by layer and head by
+ *     head, IN PLACE: live_rows[i] >= i and ascending, so every workgroup walks i upward over its own byte range of a slot and
+ *     never reads a slot it has already overwritten -- no temporary, no extra HBM;
+ *   - dst state rows i < n_live: mask / raw rows of live_rows[i], finished = finished_prev = 0,
+ *     row_map[i] = src->row_map ? src->row_map[live_rows[i]] : live_rows[i]  (compaction composes);
+ *     rows n_live <= i < dst->B are padding: finished = finished_prev = 1, row_map = -1, mask row 1, raw 0;
+ *   - *dst->n_cur = *src->n_cur.
+ * Local KV, ctx, x_blk and the activation buffers carry no state across the roll-over: dst may share src's. */
+int bt_compact_enqueue(const bt_engine_desc* src, const bt_engine_desc* dst, const int64_t* live_rows, int64_t n_live,
+                       bt_stream stream);
 
 /* ---- hipGraph helpers (capture the block step once, replay per block) ------------------------------------------ */
 typedef struct bt_graph bt_graph;

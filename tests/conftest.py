@@ -15,6 +15,7 @@ GOLDEN_CONFIGS = ["micro", "micro_l8", "micro128", "micro64", "block_main_b4_5"]
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `pytest -m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "perf: wall-clock comparison (sanity bound only; the ratio is printed, not gated)")
 
 
 def load_golden(name):

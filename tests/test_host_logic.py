@@ -56,7 +56,7 @@ def test_overrides():
 def test_library_exports_every_declared_symbol():
     """The C-ABI library loads and exports exactly what include/bt_hip.h declares (no compute without a GPU)."""
     lib = _lib.lib()
-    assert lib.bt_version() == 200
+    assert lib.bt_version() == 210
     header = open(os.path.join(ROOT, "include", "bt_hip.h")).read()
     declared = set(re.findall(r"^\s*(?:int|int32_t|int64_t|const char\*)\s+(bt_\w+)\(", header, flags=re.M))
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
@@ -71,6 +71,17 @@ def test_library_exports_every_declared_symbol():
     assert rc == -1 and b"descriptor" in lib.bt_last_error()
     rc = lib.bt_topk_sample(1, 1, 50304, 1, 50304, 1.0, 2000, 0, None, 0, 1, 1, None)   # top_k beyond the candidate buffer
     assert rc == -2 and b"top_k" in lib.bt_last_error()
+    # bt_compact_enqueue: dst must describe the same KV storage as src and own its state buffers (checked before any launch)
+    import ctypes
+    src, dst = _lib.bt_engine_desc(), _lib.bt_engine_desc()
+    src.B, dst.B, src.gk, src.gv, dst.gk, dst.gv = 8, 4, 0x1000, 0x2000, 0x1000, 0x3000
+    rc = lib.bt_compact_enqueue(ctypes.byref(src), ctypes.byref(dst), 0x10, 2, None)
+    assert rc == -1 and b"same global KV storage" in lib.bt_last_error()
+    dst.gv = 0x2000
+    rc = lib.bt_compact_enqueue(ctypes.byref(src), ctypes.byref(dst), 0x10, 5, None)
+    assert rc == -1 and b"row counts" in lib.bt_last_error()
+    rc = lib.bt_compact_enqueue(ctypes.byref(src), ctypes.byref(dst), 0x10, 2, None)
+    assert rc == -1 and b"null state buffer" in lib.bt_last_error()
     # split-N rule shared by the library and the engine's workspace sizing
     assert lib.bt_attention_split_count(128, 544, 1) == 1 and lib.bt_attention_split_count(128, 544, 4) == 4
     assert lib.bt_attention_split_count(128, 40000, 1) == 3   # 40000 keys do not fit one 64 KiB score row
@@ -90,7 +101,7 @@ def test_product_library_has_no_debug_hooks():
         assert name in dbg, name
     prev = _lib.use_debug_library(True)
     try:
-        assert _lib.lib().bt_version() == 200 and hasattr(_lib.lib(), "bt_debug_gemm_variant")
+        assert _lib.lib().bt_version() == 210 and hasattr(_lib.lib(), "bt_debug_gemm_variant")
     finally:
         _lib.use_debug_library(prev)
     assert not hasattr(_lib.lib(), "bt_debug_gemm_variant_missing")

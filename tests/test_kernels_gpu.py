@@ -981,3 +981,71 @@ def test_attention_local_window_kernel(B, heads, q, pos0, n_max, dbg_lib):
     finally:
         dbg_lib.bt_debug_local_kernel(1)
     assert (out.float() - old.float()).abs().max() <= 2.0 ** -7 * ref.abs().max()
+
+
+# ---- bt_compact_enqueue (round 4) ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("B,n_live,Bc,n_max,n_cur,pattern", [
+    (37, 11, 32, 20, 13, "random"),      # padded view (21 surplus rows), partial cache
+    (64, 32, 32, 544, 520, "odd"),       # the benchmark's cache depth, every second row
+    (9, 9, 9, 8, 8, "all"),              # identity: nothing moves
+    (33, 1, 32, 5, 5, "last"),           # one survivor, the last row
+    (40, 24, 32, 17, 0, "random"),       # nothing cached yet: only the state is gathered
+])
+def test_compact_enqueue_c_abi(dtype, B, n_live, Bc, n_max, n_cur, pattern):
+    """bt_compact_enqueue straight through the C-ABI with hand-filled descriptors (what a non-Python binder does, INTEGRATION.md
+    section 2b): the in-place ascending K/V gather == torch.index_select on positions [0, n_cur), positions >= n_cur and
+    sequence slots >= n_live are untouched, state rows gathered, row maps compose."""
+    layers, heads, d, L = 3, 4, 64 if dtype == torch.bfloat16 else 32, 4
+    gen = g(B * 1000 + n_live)
+    k = torch.randn(layers, B, heads, n_max, d, generator=gen).to(dtype).to(DEV)
+    v = torch.randn(layers, B, heads, n_max, d, generator=gen).to(dtype).to(DEV)
+    if pattern == "random":
+        live = torch.randperm(B, generator=gen)[:n_live].sort().values
+    elif pattern == "odd":
+        live = torch.arange(1, B, 2)[:n_live]
+    elif pattern == "all":
+        live = torch.arange(B)
+    else:
+        live = torch.tensor([B - 1])
+    assert live.numel() == n_live
+    k0, v0 = k.clone(), v.clone()
+    s_mask = (torch.rand(B, n_max + 1, generator=gen) > 0.3).to(torch.uint8).to(DEV)
+    s_raw = torch.randint(0, 1000, (B, L), generator=gen).to(DEV)
+    s_map = torch.randperm(5 * B, generator=gen)[:B].to(DEV)          # src is itself a compacted engine
+    s_ncur = torch.tensor([n_cur], dtype=torch.int32, device=DEV)
+    d_mask = torch.zeros(Bc, n_max + 1, dtype=torch.uint8, device=DEV)
+    d_raw = torch.full((Bc, L), -7, dtype=torch.int64, device=DEV)
+    d_fin = torch.full((Bc,), 9, dtype=torch.int32, device=DEV)
+    d_finp = torch.full((Bc,), 9, dtype=torch.int32, device=DEV)
+    d_map = torch.full((Bc,), 99, dtype=torch.int64, device=DEV)
+    d_ncur = torch.zeros(1, dtype=torch.int32, device=DEV)
+    s_fin = torch.zeros(B, dtype=torch.int32, device=DEV)
+    src, dst = _lib.bt_engine_desc(), _lib.bt_engine_desc()
+    for e, Bx in ((src, B), (dst, Bc)):
+        e.dtype, e.L, e.B = dtype_code(dtype), L, Bx
+        e.bd_dims = _lib.bt_decoder_dims(heads * d, heads, d, d // 4, 4 * heads * d, layers, 1e-5)
+        e.gk, e.gv, e.g_layer_stride, e.g_nmax = k.data_ptr(), v.data_ptr(), k.stride(0), n_max
+    src.mask, src.mask_ld, src.raw, src.n_cur, src.row_map, src.finished = (s_mask.data_ptr(), s_mask.stride(0), s_raw.data_ptr(),
+                                                                         s_ncur.data_ptr(), s_map.data_ptr(), s_fin.data_ptr())
+    dst.mask, dst.mask_ld, dst.raw, dst.n_cur, dst.row_map = (d_mask.data_ptr(), d_mask.stride(0), d_raw.data_ptr(), d_ncur.data_ptr(),
+                                                             d_map.data_ptr())
+    dst.finished, dst.finished_prev = d_fin.data_ptr(), d_finp.data_ptr()
+    live_dev = live.to(DEV)
+    check(lib().bt_compact_enqueue(ctypes.byref(src), ctypes.byref(dst), ptr(live_dev), n_live, current_stream()), "compact")
+    torch.cuda.synchronize()
+    for got, ref in ((k, k0), (v, v0)):
+        want = ref.clone()
+        want[:, :n_live, :, :n_cur] = ref[:, live.to(DEV), :, :n_cur]
+        assert torch.equal(got, want)
+    assert torch.equal(d_mask[:n_live], s_mask[live_dev]) and bool((d_mask[n_live:] == 1).all())
+    assert torch.equal(d_raw[:n_live], s_raw[live_dev]) and bool((d_raw[n_live:] == 0).all())
+    assert d_fin.tolist() == [0] * n_live + [1] * (Bc - n_live) == d_finp.tolist()
+    assert d_map.tolist() == s_map[live_dev].tolist() + [-1] * (Bc - n_live)
+    assert int(d_ncur.item()) == n_cur
+    # without a source map the live rows themselves are the map
+    src.row_map = None
+    k.copy_(k0)
+    check(lib().bt_compact_enqueue(ctypes.byref(src), ctypes.byref(dst), ptr(live_dev), n_live, current_stream()), "compact")
+    torch.cuda.synchronize()
+    assert d_map.tolist() == live.tolist() + [-1] * (Bc - n_live)
