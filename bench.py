@@ -105,6 +105,51 @@ def algorithmic_counts(dims, B: int, P: int, D: int, itemsize: int = 2):
             "decode_bytes": float(decode_bytes), "decode_flops": float(lin_decode_exec + attn_decode_flops)}
 
 
+def decode_phase_roofline(counts, decode_ms: float):
+    """SURVEY 8d decode-phase roofline: both lower bounds (HBM bytes, MFMA flops) against the measured decode time."""
+    t_dec = decode_ms / 1e3
+    hbm_lb_ms = counts["decode_bytes"] / (HBM_PEAK_GBS * 1e9) * 1e3
+    mfma_lb_ms = counts["decode_flops"] / (MFMA_BF16_PEAK_TFLOPS * 1e12) * 1e3
+    return {
+        "decode_ms": decode_ms, "bytes": counts["decode_bytes"], "flops": counts["decode_flops"],
+        "achieved_hbm_GBs": counts["decode_bytes"] / t_dec / 1e9, "frac_hbm": counts["decode_bytes"] / t_dec / 1e9 / HBM_PEAK_GBS,
+        "achieved_mfma_TFLOPs": counts["decode_flops"] / t_dec / 1e12,
+        "frac_mfma": counts["decode_flops"] / t_dec / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+        "lower_bound_ms": {"hbm": hbm_lb_ms, "mfma": mfma_lb_ms, "serial_sum": hbm_lb_ms + mfma_lb_ms},
+        "binding": "hbm" if hbm_lb_ms >= mfma_lb_ms else "mfma",
+        "frac_of_binding_roof": max(hbm_lb_ms, mfma_lb_ms) / decode_ms,
+        "note": "SURVEY 8d formulas: weights once per forward + global/local KV reads and appends + embedding rows; "
+                "executed GEMM flops (last-layer tail skip subtracted) + attention flops; peaks 8 TB/s and 2.5 PF"}
+
+
+def secondary_workload(model, dims, cfg_name: str, P: int, D: int, B: int, device, seed: int, itemsize: int):
+    """One warm-up + ONE timed generate() of a secondary north-star workload (BASELINE.json configs[2] / configs[4]; the reference's
+    harness sweeps (prefill, decode) pairs in one run the same way, measure_generation_time.py:445-468).  The warm-up is a short
+    decode of the same prompt on the same engine (two block steps: graphs captured, prefill kernels of this prompt length
+    loaded); the timed run carries hipEvent phase marks for the decode-phase roofline."""
+    L = dims.L
+    ids = torch.randint(0, dims.vocab, (B, P), generator=torch.Generator().manual_seed(seed)).to(device)
+    ml = get_max_length(L, P, D)
+    model.generate(ids, max_length=get_max_length(L, P, 2 * L))
+    torch.cuda.synchronize()
+    model.collect_timers = True
+    t0 = time.perf_counter()
+    out = model.generate(ids, max_length=ml)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    model.collect_timers = False
+    assert out.shape == (B, ml), out.shape
+    tm = model.last_timers
+    decode_ms = tm.ms("decode_start", "decode_end")
+    counts = algorithmic_counts(dims, B, P, D, itemsize)
+    return {"workload": f"{cfg_name} prefill{P}/decode{D}, greedy, EOS disabled, end-to-end generate()", "batch_per_gpu": B,
+            "block_length": L, "value": B * D / dt, "unit": "tokens/s", "ms_per_step": dt * 1e3, "steps": 1,
+            "warmup": f"1 x generate(prefill {P} / decode {2 * L}) on the same engine and graphs",
+            "prefill_ms": tm.ms("prefill_start", "decode_start"), "decode_ms": decode_ms,
+            "decode_phase_tokens_per_s_per_gpu": B * D / (decode_ms / 1e3),
+            "roofline_decode_phase": decode_phase_roofline(counts, decode_ms)}
+
+
 def build_model(dims, dtype_name: str, device, seed: int):
     torch.manual_seed(seed)
     with torch.device(device):
@@ -124,15 +169,92 @@ def log(msg: str) -> None:
 T_START = time.perf_counter()
 
 
+_ORACLE = {}
+
+
+def host_oracle(model, dims):
+    """The CPU oracle (oracle/cpu_ref.py: checker and cpu_baseline leg only) on exactly the GPU model's weights, fp32, built once
+    per run.  Threads are capped at 32: the per-op work at batch 1-2 does not scale past that and oversubscription makes eager
+    PyTorch slower."""
+    if "o" not in _ORACLE:
+        from oracle.cpu_ref import oracle_from_dims
+        cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 32)
+        torch.set_num_threads(cores)
+        sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+        _ORACLE["o"] = (oracle_from_dims(dims, sd, pad_token_id=1), cores)
+    return _ORACLE["o"]
+
+
+def parity_in_run(model, dims, input_ids, out, P: int, rows):
+    """The timed batch checks itself (VERDICT r3 next #2b; the reference's only in-run check is the shape assert,
+    measure_generation_time.py:125,158): for ``rows`` of the TIMED batch's own prompt, against the fp32 CPU oracle on the same
+    (bf16) weights --
+      ctx_err / logit_err: context embedding of the prompt and first-token logits (one extra generate(max_length = P + 1) of the
+          whole batch with the logits kept: same prefill, same kernels, same batch), budget = 3 % of max|ref| + 0.01 (the bf16
+          budget of tests/test_model_gpu.py: 24 layers of bf16-rounded activations);
+      tokens_within_band: every token of the timed output's first generated block, and the first token of its SECOND block (the
+          steady-state step: roll-over + global attention over P/L + 1 cached positions), is the oracle's argmax or lies within
+          2 x budget below it, the oracle teacher-forced along the GPU's own tokens.
+    ``ok`` False fails the run."""
+    o, _ = host_oracle(model, dims)
+    L = dims.L
+    dev = input_ids.device
+    t0 = time.perf_counter()
+    keep = model.keep_logits
+    model.keep_logits = True
+    try:
+        first = model.generate(input_ids, max_length=P + 1)
+        eng = model._engine
+        sel = torch.tensor(rows, device=dev)
+        ctx = eng.ctx.index_select(0, sel).float().cpu()
+        logits = eng.tok.logits.index_select(0, sel).float().cpu()
+        first_tok = first.index_select(0, sel)[:, P].cpu()
+    finally:
+        model.keep_logits = keep
+    timed = out.index_select(0, torch.tensor(rows, device=out.device)).cpu()
+    prompt = timed[:, :P]
+    with torch.no_grad():
+        d = o.preprocess_inputs_for_generation(prompt, None)
+        ids, bm = d["input_ids"], d["block_attention_mask"]
+        nb = ids.shape[1]
+        hidden, _ = o.block_decoder(o.embed(ids).view(len(rows), nb, -1), bm)
+        ref_ctx = hidden[:, -1]
+        ref_blk = o.token_decoder_teacher_forced(ref_ctx, timed[:, P:P + L - 1], positions=o.td_pos)     # [rows, L, V]
+        # second block: oracle prefilled on prompt + the GPU's own first block
+        d2 = o.preprocess_inputs_for_generation(timed[:, :P + L], None)
+        ids2, bm2 = d2["input_ids"], d2["block_attention_mask"]
+        hidden2, _ = o.block_decoder(o.embed(ids2).view(len(rows), nb + 1, -1), bm2)
+        _, ref_lg2 = o.token_decoder_generate(hidden2[:, -1], 1, return_logits=True)
+
+    def budget(ref):
+        return 3e-2 * ref.abs().max().item() + 1e-2
+
+    def gaps(ref, toks):        # oracle logit of the emitted token below the oracle's best, per token
+        return (ref.max(-1).values - ref.gather(-1, toks.unsqueeze(-1)).squeeze(-1))
+
+    ctx_err = (ctx - ref_ctx).abs().max().item()
+    logit_err = (logits - ref_blk[:, 0]).abs().max().item()
+    b_ctx, b_lg = budget(ref_ctx), budget(ref_blk)
+    g1 = gaps(ref_blk, timed[:, P:P + L])
+    g2 = gaps(ref_lg2[:, 0], timed[:, P + L])
+    b2 = budget(ref_lg2)
+    within = bool((g1 <= 2 * b_lg).all()) and bool((g2 <= 2 * b2).all())
+    same_first = bool(torch.equal(first_tok, timed[:, P]))
+    exact = float(((ref_blk.argmax(-1) == timed[:, P:P + L]).float().sum() + (ref_lg2[:, 0].argmax(-1) == timed[:, P + L]).float().sum())
+                  / (len(rows) * (L + 1)))
+    ok = ctx_err <= b_ctx and logit_err <= b_lg and within and same_first
+    return {"ok": bool(ok), "rows": list(rows), "ctx_err": ctx_err, "ctx_budget": b_ctx, "logit_err": logit_err,
+            "budget": b_lg, "tokens_within_band": within, "worst_token_gap": float(max(g1.max().item(), g2.max().item())),
+            "band": 2 * b_lg, "tokens_checked": len(rows) * (L + 1), "exact_argmax_agreement": exact,
+            "first_token_rerun_equal": same_first, "seconds": time.perf_counter() - t0,
+            "what": "rows of the timed batch: prompt context + first logits (extra generate(max_length=P+1), logits kept) and the "
+                    "timed output's first block + first token of block 2 vs the fp32 CPU oracle on the same weights"}
+
+
 def cpu_baseline(model, dims, sample_prefill: int, sample_decode: int):
     """The CPU oracle (a port of the reference's eager path) timed on this box's host cores, on a bounded sample of
-    the same workload: same weights (copied from the GPU model, fp32), batch 1.  Threads are capped at 32: the per-op
-    work at batch 1 (GEMV-sized) does not scale past that and oversubscription makes eager PyTorch slower."""
-    from oracle.cpu_ref import oracle_from_dims
-    cores = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)), 32)
-    torch.set_num_threads(cores)
-    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-    o = oracle_from_dims(dims, sd, pad_token_id=1)
+    the same workload: same weights (copied from the GPU model, fp32), batch 1."""
+    o, cores = host_oracle(model, dims)
     ids = torch.randint(0, dims.vocab, (1, sample_prefill), generator=torch.Generator().manual_seed(0))
     ml = get_max_length(dims.L, sample_prefill, sample_decode)
     t0 = time.perf_counter()
@@ -201,6 +323,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1234)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run oracle check of the timed batch (parity_in_run)")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary north-star workloads (prefill 128 / decode 2048; the L = 8 variant) of the default run")
     ap.add_argument("--no-graphs", action="store_true")
     ap.add_argument("--pipeline", choices=["auto", "on", "off"], default="auto",
                     help="two half-batch shards on two streams (global-attention / GEMM overlap, measured not to pay: DESIGN.md "
@@ -285,6 +410,16 @@ def main():
                    "logits_materialised": bool(model.keep_logits)},
     }
 
+    parity_failed = False
+    if rank == 0 and not args.no_parity and args.dtype == "bf16" and D >= L + 1:
+        log("parity_in_run: oracle on 2 rows of the timed batch ...")
+        rows = sorted({0, B - 1})
+        par = parity_in_run(model, dims, input_ids, out, P, rows)
+        log(f"parity_in_run: ok={par['ok']} ctx {par['ctx_err']:.4f}/{par['ctx_budget']:.4f} logits {par['logit_err']:.4f}/"
+            f"{par['budget']:.4f} worst token gap {par['worst_token_gap']:.4f}/{par['band']:.4f} ({par['seconds']:.1f}s)")
+        result["parity_in_run"] = par
+        parity_failed = not par["ok"]
+
     if rank == 0:
         # phase split (one extra generate with hipEvent phase marks): decode-phase-only throughput
         model.collect_timers = True
@@ -303,19 +438,7 @@ def main():
         # launch stream (libbt_hip's built-in timer), against the algorithmic flops/bytes of the same generate
         counts = algorithmic_counts(dims, B, P, D, itemsize)
         # section 8d decode-phase roofline of the TIMED configuration: both lower bounds against the measured decode time
-        t_dec = decode_ms / 1e3
-        hbm_lb_ms = counts["decode_bytes"] / (HBM_PEAK_GBS * 1e9) * 1e3
-        mfma_lb_ms = counts["decode_flops"] / (MFMA_BF16_PEAK_TFLOPS * 1e12) * 1e3
-        result["roofline_decode_phase"] = {
-            "decode_ms": decode_ms, "bytes": counts["decode_bytes"], "flops": counts["decode_flops"],
-            "achieved_hbm_GBs": counts["decode_bytes"] / t_dec / 1e9, "frac_hbm": counts["decode_bytes"] / t_dec / 1e9 / HBM_PEAK_GBS,
-            "achieved_mfma_TFLOPs": counts["decode_flops"] / t_dec / 1e12,
-            "frac_mfma": counts["decode_flops"] / t_dec / 1e12 / MFMA_BF16_PEAK_TFLOPS,
-            "lower_bound_ms": {"hbm": hbm_lb_ms, "mfma": mfma_lb_ms, "serial_sum": hbm_lb_ms + mfma_lb_ms},
-            "binding": "hbm" if hbm_lb_ms >= mfma_lb_ms else "mfma",
-            "frac_of_binding_roof": max(hbm_lb_ms, mfma_lb_ms) / decode_ms,
-            "note": "SURVEY 8d formulas: weights once per forward + global/local KV reads and appends + embedding rows; "
-                    "executed GEMM flops (last-layer tail skip subtracted) + attention flops; peaks 8 TB/s and 2.5 PF"}
+        result["roofline_decode_phase"] = decode_phase_roofline(counts, decode_ms)
         # kernels in isolation: single-stream engine (the half-batch pipeline overlaps kernels, which inflates per-kernel times)
         was_pipeline = model.pipeline
         if model._engine is not None and model._engine.pipelined:
@@ -409,11 +532,34 @@ def main():
         base["gpu_vs_cpu_first_block_equal"] = bool(same[:dims.L].all())
         result["cpu_baseline"] = base
 
+    default_workload = (args.config == "block_main_b4_1.2b" and P == 2048 and D == 128 and args.dtype == "bf16")
+    if rank == 0 and world == 1 and default_workload and not args.no_secondary:
+        # the other north-star target and the L = 8 variant in the same record
+        sec = []
+        log("secondary: prefill 128 / decode 2048 on the same model and engine ...")
+        sec.append(secondary_workload(model, dims, args.config, 128, 2048, B, device, args.seed + 1, itemsize))
+        log(f"secondary: {sec[-1]['value']:.0f} tok/s")
+        model.release_buffers()
+        del model
+        torch.cuda.empty_cache()
+        d8 = named_dims("block_main_b8_1.2b")
+        log("secondary: building block_main_b8_1.2b (L = 8) ...")
+        m8 = build_model(d8, args.dtype, device, args.seed)
+        m8.use_graphs = not args.no_graphs
+        B8 = args.batch if args.batch > 0 else auto_batch(d8, 2048, 128, device, itemsize)
+        sec.append(secondary_workload(m8, d8, "block_main_b8_1.2b", 2048, 128, B8, device, args.seed + 2, itemsize))
+        log(f"secondary: {sec[-1]['value']:.0f} tok/s")
+        m8.release_buffers()
+        del m8
+        result["secondary"] = sec
+
     if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         parallel.barrier()
         torch.distributed.destroy_process_group()
+    if parity_failed:
+        raise SystemExit("bench.py: parity_in_run failed -- the timed batch's own output is outside the oracle's band")
 
 
 if __name__ == "__main__":

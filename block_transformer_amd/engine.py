@@ -32,6 +32,7 @@ from __future__ import annotations
 
 import ctypes
 import os
+import weakref
 from typing import List, Optional
 
 import torch
@@ -219,7 +220,7 @@ class DecodeEngine:
         heads = bd.config.num_attention_heads
         self.n_max = max(max_blocks, 1)
         self.glob = KVCache(bd.config.num_hidden_layers, batch, heads, self.n_max, self.H // heads, dt, dev)
-        self.root = self
+        self._root = None         # views hold a weak reference to their root (no reference cycle: an engine is 100s of GB)
         self._children = {}       # compacted views by batch size (state buffers and graphs are reused across generate() calls)
         self.row_map: Optional[torch.Tensor] = None     # identity
         self.err_flag = torch.zeros(1, dtype=torch.int32, device=dev)   # sticky device-side guard bits (BT_DEV_ERR_*)
@@ -261,7 +262,7 @@ class DecodeEngine:
         """A compacted engine: the first ``batch`` sequence slots of ``root`` (same KV storage, activation buffers, workspaces,
         stream, out_ids) with its own per-row state (mask, finished flags, raw tokens, n_cur, row_map) and its own graphs."""
         assert root.root is root and 0 < batch <= root.B
-        self.root = root
+        self._root = weakref.ref(root)
         self.bd_rt, self.device, self.dtype = root.bd_rt, root.device, root.dtype
         self.B, self.NB, self.L, self.H, self.n_max = batch, root.NB, root.L, root.H, root.n_max
         dev = self.device
@@ -295,6 +296,10 @@ class DecodeEngine:
         self._desc_key = None
         self.graphs = {}
         self._graph_key = None
+
+    @property
+    def root(self) -> "DecodeEngine":
+        return self if self._root is None else self._root()
 
     # ---- descriptor ----------------------------------------------------------------------------------------------------------
     def weight_key(self):
@@ -482,7 +487,8 @@ class DecodeEngine:
         that replays its captured block step makes after its last replay."""
         bits = int(self.err_flag.item())
         if bits:
-            self.err_flag.zero_()
+            with torch.inference_mode():
+                self.err_flag.zero_()
             what = [n for b, n in ((_lib.BT_DEV_ERR_CACHE_FULL, "global KV cache full (roll-over past g_nmax)"),
                                    (_lib.BT_DEV_ERR_BLOCK_RANGE, "block index past out_ids / mask")) if bits & b]
             raise _lib.BtError("device-side guard tripped: " + ", ".join(what))

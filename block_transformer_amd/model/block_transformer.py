@@ -151,7 +151,7 @@ class BlockTransformer(nn.Module):
         pipelined = self._want_pipeline(batch) and not streaming
         if (e is None or e.B != batch or e.NB < max_blocks or e.dtype != rt.dtype or e.device != rt.device
                 or e.tok.policy != policy or e.pipelined != pipelined):
-            self._engine = None  # free the old buffers before allocating the new ones
+            self._engine = e = None  # free the old buffers before allocating the new ones
             cls = PipelinedEngine if pipelined else DecodeEngine
             e = self._engine = cls(self, batch, max_blocks, rope_policy=policy)
         return e
@@ -160,6 +160,8 @@ class BlockTransformer(nn.Module):
         """Drop the engine (KV caches, workspaces, captured graphs) and return the blocks to the driver (a differently
         shaped engine -- other batch, single-stream vs half-batch shards -- needs contiguous room for its own caches)."""
         self._engine = None
+        import gc
+        gc.collect()
         if torch.cuda.is_available():
             torch.cuda.empty_cache()
 

@@ -1091,7 +1091,7 @@ def test_device_guard_flags_a_replay_past_the_cache(gpu_model):
     eng = model._engine
     guard_k = eng.glob.k.clone()
     assert int(eng.err_flag.item()) == 0
-    with torch.cuda.stream(eng.stream):
+    with torch.inference_mode(), torch.cuda.stream(eng.stream):
         eng.n_cur.fill_(eng.n_max)                                  # "one replay too many"
         _lib.check(_lib.lib().bt_roll_over_enqueue(ctypes.byref(eng.desc), _lib.current_stream()), "roll")
     torch.cuda.synchronize()
@@ -1101,13 +1101,14 @@ def test_device_guard_flags_a_replay_past_the_cache(gpu_model):
     with pytest.raises(_lib.BtError, match="cache full"):
         eng.check_device_errors()
     assert int(eng.err_flag.item()) == 0
-    with torch.cuda.stream(eng.stream):
+    with torch.inference_mode(), torch.cuda.stream(eng.stream):
         eng.n_cur.fill_(eng.NB)                                     # block index past out_ids
         before = eng.out_ids.clone()
         _lib.check(_lib.lib().bt_token_block_enqueue(ctypes.byref(eng.desc), 0, dims.L, dims.L, _lib.current_stream()), "tok")
     torch.cuda.synchronize()
     assert int(eng.err_flag.item()) & _lib.BT_DEV_ERR_BLOCK_RANGE and torch.equal(eng.out_ids, before)
-    eng.err_flag.zero_()
+    with torch.inference_mode():
+        eng.err_flag.zero_()
     again = model.generate(prompt, max_length=16)
     assert torch.equal(again, out)
 
