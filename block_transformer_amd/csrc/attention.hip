@@ -376,7 +376,7 @@ __global__ __launch_bounds__(256) void local_attend_kernel(const bf16* __restric
                     d = fmaf(q[2 * i], __uint_as_float(w[i] << 16), d);
                     d = fmaf(q[2 * i + 1], __uint_as_float(w[i] & 0xffff0000u), d);
                 }
-                d = wave_sum<16>(d);                                   // all 16 lanes of the row group hold the score
+                d = row16_sum_dpp(d);                                  // all 16 lanes of the row group hold the score (== wave_sum<16>, bit for bit)
                 const int r = u * 4 + sub;
                 const bool vis = r < nk && (mrow == nullptr || mrow[r] != 0);
                 sc[u] = vis ? d : -INFINITY;

@@ -143,6 +143,18 @@ __device__ inline float wave_max(float v) {
     return v;
 }
 
+// 16-lane butterfly sum on the DPP path (no LDS round trips): stage for stage the partners of wave_sum<16>'s xor 8 / 4 / 2 / 1 --
+// row_ror:8 IS lane ^ 8 inside a 16-lane row; after it lanes j and j ^ 8 hold the same value, so row_ror:4 delivers the value
+// lane ^ 4 holds; quad_perm gives ^ 2 and ^ 1 exactly -- and fp32 addition commutes, so the result is bit-identical to
+// wave_sum<16> at ~1/10 of its latency (4 ds_bpermute round trips -> 4 VALU instructions).
+__device__ inline float row16_sum_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, false));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, false));    // quad_perm [1,0,3,2]
+    return v;
+}
+
 // ---- per-family kernel timer (core.hip) ------------------------------------------------------------------------
 extern bool g_prof_on;
 void prof_push(int family, hipEvent_t a, hipEvent_t b);
@@ -188,12 +200,22 @@ int few_rows_qkv_h4(hipStream_t s, int64_t B, int q_len, int heads, int head_dim
                     const int32_t* pos_table, const float* cos_tab, const float* sin_tab, const void* h4_w, const void* h4_b,
                     void* h4, int64_t I);
 
+// ---- <= 4 rows, token-decoder local window: attention computed inside the residual-stream GEMV (gemm.hip, round 4) --------------
+bool few_rows_attn_res_ok(int64_t M, int q_len, int heads, int head_dim, int64_t H, int64_t I, int pos0_host, int64_t n_max);
+int few_rows_attn_res(hipStream_t s, int64_t M, int q_len, int heads, int64_t I, const void* h4, const void* h_w, const void* h_b,
+                      const void* qkv, int64_t ld_qkv, const void* kc, const void* vc, int64_t n_max, int pos0_host,
+                      const void* dense_w, const void* dense_b, void* x, int64_t ldx);
+
 // ---- mid-batch (17 .. 256 rows) decoder-layer pieces (gemm.hip), used by bt_decoder_forward (engine.hip) -------------------
 bool mid_rows_ok(int64_t M, int64_t H, int64_t I, int head_dim, int rot);
 int64_t mid_slab_bytes(int64_t M, int64_t H, int64_t I);
 int mid_qkv(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, const void* x, int64_t ldx, const void* w,
             const void* bias, void* qkv, int64_t ld_qkv, void* kc, void* vc, int64_t n_max, const int32_t* pos0_dev, int pos0_host,
             const int32_t* pos_table, const float* cos_tab, const float* sin_tab, void* slabs, int64_t slab_bytes, int* counters);
+int mid_qkv_gelu(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, const void* x1, const void* qkv_w, const void* qkv_b,
+                 void* qkv, int64_t ld_qkv, void* kc, void* vc, int64_t n_max, const int32_t* pos0_dev, int pos0_host,
+                 const int32_t* pos_table, const float* cos_tab, const float* sin_tab, const void* x2, const void* h4_w,
+                 const void* h4_b, void* h4, int64_t I, void* slabs, int64_t slab_bytes, int* counters, bool* done);
 int mid_gelu(hipStream_t s, int64_t M, int64_t N, int64_t K, const void* x, int64_t ldx, const void* w, const void* bias, void* out,
              int64_t ldo, void* slabs, int64_t slab_bytes, int* counters);
 constexpr int64_t MID_COUNTER_BYTES = 4096;   // one int per 64 x 64 tile of a <= 256-row GEMM with N <= 16384

@@ -118,14 +118,21 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
             const bt_layer_weights& lw = w->layers_host[l];
             char* kc = reinterpret_cast<char*>(attn->k_cache) + (int64_t)l * attn->layer_stride * es;
             char* vc = reinterpret_cast<char*>(attn->v_cache) + (int64_t)l * attn->layer_stride * es;
-            BT_TRY(mid_qkv(hs, B, q_len, dims->heads, dims->head_dim, ln1, H, lw.qkv_w, lw.qkv_b, qkv, 3 * H, kc, vc, attn->n_max,
-                           attn->pos0_dev, attn->pos0_host, attn->pos_table, attn->cos_tab, attn->sin_tab, scratch, slab_room,
-                           counters));
+            // parallel residual: the QKV projection (LN1 rows) and the MLP up-projection (LN2 rows) read the same layer input and
+            // neither depends on the attention -> one split-K launch + one reduce launch for both (round 4)
+            bool dual = false;
+            BT_TRY(mid_qkv_gelu(hs, B, q_len, dims->heads, dims->head_dim, ln1, lw.qkv_w, lw.qkv_b, qkv, 3 * H, kc, vc, attn->n_max,
+                                attn->pos0_dev, attn->pos0_host, attn->pos_table, attn->cos_tab, attn->sin_tab, ln2, lw.h4_w,
+                                lw.h4_b, h4, I, scratch, slab_room, counters, &dual));
+            if (!dual)
+                BT_TRY(mid_qkv(hs, B, q_len, dims->heads, dims->head_dim, ln1, H, lw.qkv_w, lw.qkv_b, qkv, 3 * H, kc, vc, attn->n_max,
+                               attn->pos0_dev, attn->pos0_host, attn->pos_table, attn->cos_tab, attn->sin_tab, scratch, slab_room,
+                               counters));
             // the attention output overwrites ln1 (its only reader, the QKV GEMM, is done); ln2 stays until the MLP has read it
             BT_TRY(attention_impl(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc, attn->n_max,
                                 attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H, attn->n_split,
                                 attn->split_ws, attn->split_ws_bytes, skip, stream));
-            BT_TRY(mid_gelu(hs, M, I, H, ln2, H, lw.h4_w, lw.h4_b, h4, I, scratch, slab_room, counters));
+            if (!dual) BT_TRY(mid_gelu(hs, M, I, H, ln2, H, lw.h4_w, lw.h4_b, h4, I, scratch, slab_room, counters));
             const bool more = l + 1 < dims->layers;
             const bt_layer_weights& nx = w->layers_host[more ? l + 1 : l];
             // x += h4 W2^T + b2 + att Wd^T + bd, then LN1 / LN2 of the NEXT layer (att == ln1 is free again after this GEMM)
@@ -156,6 +163,15 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
                 BT_TRY(bt_ln_qkv_rope_append(dtype, B, q_len, dims->heads, dims->head_dim, dims->rot, x, H, lw.ln1_w, lw.ln1_b,
                                              dims->ln_eps, lw.qkv_w, lw.qkv_b, qkv, 3 * H, kc, vc, attn->n_max, attn->pos0_dev,
                                              attn->pos0_host, attn->pos_table, attn->cos_tab, attn->sin_tab, stream));
+            }
+            // token decoder (local window, host-known position, no mask): the attention runs INSIDE the residual-stream GEMV -- every
+            // workgroup recomputes the <= 12-key window of all heads from L2 -- so the layer is 2 launches
+            if (dual && attn->mode == 0 && !attn->pos0_dev && !attn->mask && !skip && attn->n_split <= 1 && lw.h_b && lw.dense_b &&
+                aligned16(h4) && aligned16(lw.h_w) && aligned16(lw.dense_w) && aligned16(qkv) && aligned16(kc) && aligned16(vc) &&
+                few_rows_attn_res_ok(M, q_len, dims->heads, dims->head_dim, H, I, attn->pos0_host, attn->n_max)) {
+                BT_TRY(few_rows_attn_res((hipStream_t)stream, M, q_len, dims->heads, I, h4, lw.h_w, lw.h_b, qkv, 3 * H, kc, vc,
+                                         attn->n_max, attn->pos0_host, lw.dense_w, lw.dense_b, x, H));
+                continue;
             }
             BT_TRY(attention_impl(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc, attn->n_max,
                                 attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H, attn->n_split,

@@ -315,6 +315,18 @@ struct Seg2 {
     int K;
 };
 
+// the token decoder's local-window attention as the PRODUCER of a GEMV's second operand (gemv_body<..., ATT>): the window is so
+// small (<= 12 cached rows of 256 B per head) that every workgroup of the residual-stream GEMV recomputes all heads from L2
+// instead of waiting for a separate attention launch
+struct LocalAtt {
+    const bf16* qkv;   // [M, ld_qkv]: rotated q of the new rows
+    const bf16* kc;    // local cache K,V[B][heads][n_max][128] of this layer
+    const bf16* vc;
+    int64_t ld_qkv, n_max;
+    int pos0, q_len, heads;
+    float scale;
+};
+
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int GROUP_M = 8;
 
@@ -399,22 +411,20 @@ __device__ inline void wait_vmcnt_n() {
 // plain slab stores -> every wave s_waitcnt vmcnt(0) -> barrier -> lane 0: release fence, vmcnt(0), relaxed agent
 // fetch_add; the last arriver: lane 0 acquire fence -> barrier -> plain loads.  `counters` (one int per tile) must be zero at
 // launch; the last arriver puts its counter back to zero (agent-scope store), bt_decoder_forward also clears them per pass.
-template <int TBM, int TBN, bool SPLITK = false, int NS = 2, bool FUSE = false>
-__global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restrict__ A, int64_t lda,
-                                                            const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
-                                                            int K, int tiles_m, int tiles_n,
-                                                            float* __restrict__ partial = nullptr, const Seg2 s2 = Seg2{},
-                                                            int slices1 = 1 << 30, int* __restrict__ counters = nullptr) {
+// The body is a device function of the tile coordinates (and of the LDS ring the kernel owns) so that TWO problems of the same
+// tile shape can share one launch (gemm_bf16_mfma_dual_kernel below).
+template <int TBM, int TBN, bool SPLITK, int NS, bool FUSE>
+__device__ __forceinline__ void gemm_mfma_body(char* smem, const int tm, const int tn, const bf16* __restrict__ A, int64_t lda,
+                                               const bf16* __restrict__ W, int64_t ldw, const EpiArgs& ep, int K, int tiles_n,
+                                               float* __restrict__ partial, const Seg2& s2, int slices1,
+                                               int* __restrict__ counters) {
     const int M = ep.M, N = ep.N;
     constexpr int A_BYTES = TBM * BK * 2, W_BYTES = TBN * BK * 2, STAGE = A_BYTES + W_BYTES;
     constexpr int FM = TBM / 32, FN = TBN / 32;  // 16x16 fragments per wave along m / n
     constexpr int IPT = TBM / 32 + TBN / 32;     // LDS-DMA instructions per wave and K-tile
     static_assert(NS >= 2 && NS <= 4, "ring depth");
-    __shared__ __attribute__((aligned(16))) char smem[NS * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    int tm, tn;
-    tile_coords(tiles_m, tiles_n, tm, tn);
     const int m0 = tm * TBM, n0 = tn * TBN;
     if (SPLITK) {  // this workgroup's K slice (K here is the slice length; the operands are advanced to the slice start).
         // Slices >= slices1 belong to the optional second operand pair (out = A.W^T + A2.W2^T: the two residual-stream
@@ -582,11 +592,56 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restr
     }
 }
 
+template <int TBM, int TBN, bool SPLITK = false, int NS = 2, bool FUSE = false>
+__global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restrict__ A, int64_t lda,
+                                                            const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
+                                                            int K, int tiles_m, int tiles_n,
+                                                            float* __restrict__ partial = nullptr, const Seg2 s2 = Seg2{},
+                                                            int slices1 = 1 << 30, int* __restrict__ counters = nullptr) {
+    __shared__ __attribute__((aligned(16))) char smem[NS * (TBM + TBN) * BK * 2];
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n, tm, tn);
+    gemm_mfma_body<TBM, TBN, SPLITK, NS, FUSE>(smem, tm, tn, A, lda, W, ldw, ep, K, tiles_n, partial, s2, slices1, counters);
+}
+
+// Two problems with the same M, K and K slicing in ONE launch (round 4; the mid-batch decoder layer: the QKV projection reads
+// LN1(x), the MLP up-projection LN2(x) of the same x, and with the parallel residual neither depends on the attention): tile
+// columns [0, tiles_n1) belong to problem 1, the rest to problem 2; each keeps its own operands, epilogue arguments and slab
+// region.  One launch ramps up and drains once and gives the K-slice choice 224 instead of 96 / 128 tiles to fill the chip with.
+struct GemmSide {
+    const bf16* A;
+    const bf16* W;
+    int64_t lda, ldw;
+    float* partial;
+    int* counters;
+};
+struct DualArgs {
+    GemmSide g[2];
+    EpiArgs ep[2];
+};
+// (out of line: with the body inlined into a kernel that picks its operands at run time this compiler's simplifycfg pass crashes;
+//  one call per workgroup costs nothing against a ~10 us tile)
+__device__ __attribute__((noinline)) void gemm_mfma_body_64x64_split4(char* smem, int tm, int tn, const bf16* A, int64_t lda,
+                                                                     const bf16* W, int64_t ldw, const EpiArgs& ep, int K,
+                                                                     int tiles_n, float* partial, int* counters) {
+    gemm_mfma_body<64, 64, true, 4, false>(smem, tm, tn, A, lda, W, ldw, ep, K, tiles_n, partial, Seg2{}, 1 << 30, counters);
+}
+__global__ __launch_bounds__(256) void gemm_bf16_mfma_dual_kernel(const DualArgs a, int K, int tiles_m, int tiles_n1, int tiles_n2) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * (64 + 64) * BK * 2];
+    int tm, tn;
+    tile_coords(tiles_m, tiles_n1 + tiles_n2, tm, tn);
+    // ONE inlined body; the side is picked by a workgroup-uniform INDEX into the kernel-argument arrays (scalar loads at a computed
+    // offset).  Conditional struct copies or two inlined bodies crash this compiler's simplifycfg.
+    const int side = tn >= tiles_n1 ? 1 : 0;
+    const GemmSide& g = a.g[side];
+    gemm_mfma_body_64x64_split4(smem, tm, tn - side * tiles_n1, g.A, g.lda, g.W, g.ldw, a.ep[side], K, side ? tiles_n2 : tiles_n1,
+                                g.partial, g.counters);
+}
+
 // sum the K-slice partials and apply the shared epilogue (bias, GELU, residual): 8 columns per thread, 16-byte accesses
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int slices, const EpiArgs ep) {
+__device__ __forceinline__ void splitk_reduce_body(const int64_t idx, const float* __restrict__ partial, int slices, const EpiArgs& ep) {
     const int M = ep.M, N = ep.N;
     const int cpr = N / 8;
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)M * cpr) return;
     const int m = (int)(idx / cpr), n = (int)(idx - (int64_t)m * cpr) * 8;
     float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -618,6 +673,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     }
     store_vec<bf16>(ep.out + (int64_t)m * ep.ldo + n, v);
 }
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int slices, const EpiArgs ep) {
+    splitk_reduce_body((int64_t)blockIdx.x * 256 + threadIdx.x, partial, slices, ep);
+}
 
 // ---- fused reduce kernels of the mid-batch path (17 .. 256 rows, bt_decoder_forward) ----------------------------------------
 // The split-K GEMM above leaves fp32 slabs [slices][M][N]; these kernels sum them and do everything the layer needs next at
@@ -636,10 +694,9 @@ __device__ inline void sum_slabs8(const float* __restrict__ partial, int slices,
 
 // QKV: + bias, partial RoPE (rot == 32: pairs (e, e + 16) of the first 32 dims of q and k), q -> qkv buffer, (k_rot, v) -> cache
 // rows pos0 + t.  One thread = one row x 8 columns (one 16-byte output); a thread in a rotated zone also sums its partner's 8.
-__global__ __launch_bounds__(256) void mid_reduce_qkv_kernel(const float* __restrict__ partial, int slices, const EpiArgs ep) {
+__device__ __forceinline__ void mid_reduce_qkv_body(const int64_t idx, const float* __restrict__ partial, int slices, const EpiArgs& ep) {
     const int M = ep.M, N = ep.N;
     const int cpr = N / 8;
-    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)M * cpr) return;
     const int m = (int)(idx / cpr), n = (int)(idx - (int64_t)m * cpr) * 8;
     const int64_t slab = (int64_t)M * N;
@@ -684,6 +741,15 @@ __global__ __launch_bounds__(256) void mid_reduce_qkv_kernel(const float* __rest
     bf16* dst = part == 0 ? ep.out + (int64_t)m * ep.ldo + n
                           : (part == 1 ? ep.q.kc : ep.q.vc) + ((b * ep.q.heads + head) * ep.q.n_max + pos0 + t) * D + el;
     store_vec<bf16>(dst, v);
+}
+__global__ __launch_bounds__(256) void mid_reduce_qkv_kernel(const float* __restrict__ partial, int slices, const EpiArgs ep) {
+    mid_reduce_qkv_body((int64_t)blockIdx.x * 256 + threadIdx.x, partial, slices, ep);
+}
+// both reductions behind the dual GEMM in one launch: workgroups [0, nb1) finish the QKV slabs, the rest the h->4h slabs
+__global__ __launch_bounds__(256) void mid_reduce_qkv_gelu_kernel(const float* __restrict__ p1, const EpiArgs ep1, int nb1,
+                                                                 const float* __restrict__ p2, const EpiArgs ep2, int slices) {
+    if ((int)blockIdx.x < nb1) mid_reduce_qkv_body((int64_t)blockIdx.x * 256 + threadIdx.x, p1, slices, ep1);
+    else splitk_reduce_body((int64_t)(blockIdx.x - nb1) * 256 + threadIdx.x, p2, slices, ep2);
 }
 
 // Residual stream: x[m, :] += sum(slabs) + bias + bias2 (in place, rounded to bf16 like the unfused epilogues), then the NEXT
@@ -2452,7 +2518,11 @@ constexpr int T21_SMEM = 2 * T21_STAGE;
 constexpr int T21_PATCH_PITCH = 80;                // 32 columns x 2 B + 16 pad
 constexpr int T21_WAIT = 6;
 
-template <bool RES, bool PRIO = true>
+// SAFE: a ring slot is refilled by LDS-DMA one barrier after its last fragment read was ISSUED; group 1's reads of a slot
+// are issued right before the barrier after which group 0 issues that slot's refill, and nothing but latency (a DMA's L2 round
+// trip >> a queued ds_read) orders them.  With SAFE group 1 drains its LDS queue (s_waitcnt lgkmcnt(0)) before those two barriers
+// -- the MFMAs behind them need the fragments anyway, so the wait only moves in front of the barrier.  Cost: profiles/r4_t21_safe_ab.jsonl.
+template <bool RES, bool PRIO = true, bool SAFE = true>
 __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_kernel(const bf16* __restrict__ A, int64_t lda,
                                                                    const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
                                                                    int K, int tiles_m, int tiles_n) {
@@ -2543,6 +2613,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_kernel(const bf16* 
         }
         if (t + 1 < nk) issue_a(I1{});              // A1 of K-tile t + 1 (cursor at t + 1)
         if (grp1) wait(steady);
+        if (SAFE && grp1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // A0 / W reads done before group 0 may refill them
         cbarrier();
         __builtin_amdgcn_sched_barrier(0);
         if (PRIO) __builtin_amdgcn_s_setprio(1);
@@ -2569,6 +2640,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_kernel(const bf16* 
             issue_w();
         }
         if (grp1) wait(t + 4 <= nk);                // (its wait for phase 0 of K-tile t + 1: steady while t + 1 <= nk - 3)
+        if (SAFE && grp1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // A1 reads done before group 0 may refill the slot
         cbarrier();
         __builtin_amdgcn_sched_barrier(0);
         if (PRIO) __builtin_amdgcn_s_setprio(1);
@@ -2667,13 +2739,134 @@ __device__ inline float dot8_bf16(const uint4& w, const uint4& x, float acc) {
 // q to the qkv buffer / k, v to their KV-cache rows itself: removes the RoPE + append launch.  Small-batch decode is
 // launch-bound (~5 us per dependent launch): 7 -> 5 launches per layer.
 
+// local-window attention of the (sequence, head) items of a <= 2-row step into LDS rows xs_att[m][head * 128 + ..] (bf16, the
+// layout the GEMV stages its x rows in).  One wave per item with local_attend_kernel's lane mapping and arithmetic (keep in sync:
+// tests/test_model_gpu.py::test_few_rows_fused_attention_is_bit_identical compares the two).  The items of a wave (it = j * 4 + wave)
+// are spread over the GEMV's first-segment K chunks, <= ATT_HPW per chunk: `issue` goes out right BEFORE the chunk's weight-row
+// loads (L2 hits retire first: the wait leaves the HBM stream in flight), `finish` runs in their shadow.
+constexpr int ATT_HPW = 2;
+template <int U>
+struct LocalAttRegs {
+    uint4 kq[ATT_HPW][U], vq[ATT_HPW][U], qq[ATT_HPW][2];
+};
+
+template <int U>
+__device__ __forceinline__ void local_att_issue(const LocalAtt& la, int items, int j0, int j1, int lane, int wave, LocalAttRegs<U>& r) {
+    constexpr int D = 128;
+    const int c = lane & 15, sub = lane >> 4;
+    const int nk_all = la.pos0 + la.q_len;
+#pragma unroll
+    for (int h = 0; h < ATT_HPW; ++h) {
+        int it = (j0 + h < j1 ? j0 + h : j0) * 4 + wave;
+        it = it < items ? it : items - 1;
+        const int b = it / la.heads, head = it - b * la.heads;
+        const bf16* kb = la.kc + ((int64_t)b * la.heads + head) * la.n_max * D + c * 8;
+        const bf16* vb = la.vc + ((int64_t)b * la.heads + head) * la.n_max * D + c * 8;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            int row = u * 4 + sub;
+            row = row < nk_all ? row : nk_all - 1;
+            r.kq[h][u] = *reinterpret_cast<const uint4*>(kb + (int64_t)row * D);
+            r.vq[h][u] = *reinterpret_cast<const uint4*>(vb + (int64_t)row * D);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int tt = t < la.q_len ? t : la.q_len - 1;
+            r.qq[h][t] = *reinterpret_cast<const uint4*>(la.qkv + ((int64_t)b * la.q_len + tt) * la.ld_qkv + (int64_t)head * 3 * D + c * 8);
+        }
+    }
+}
+
+template <int U>
+__device__ __forceinline__ void local_att_finish(const LocalAtt& la, int items, int j0, int j1, int lane, int wave,
+                                                 const LocalAttRegs<U>& r, char* xs_att) {
+    constexpr int D = 128;
+    const int c = lane & 15, sub = lane >> 4;
+#pragma unroll
+    for (int h = 0; h < ATT_HPW; ++h) {
+        if (j0 + h >= j1) break;
+        const int it = (j0 + h) * 4 + wave;
+        if (it >= items) break;
+        const int b = it / la.heads, head = it - b * la.heads;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (t >= la.q_len) break;
+            const int nk = la.pos0 + t + 1;
+            float q[8];
+            {
+                const uint32_t w[4] = {r.qq[h][t].x, r.qq[h][t].y, r.qq[h][t].z, r.qq[h][t].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    q[2 * i] = __uint_as_float(w[i] << 16) * la.scale;
+                    q[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u) * la.scale;
+                }
+            }
+            float sc[U];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const uint32_t w[4] = {r.kq[h][u].x, r.kq[h][u].y, r.kq[h][u].z, r.kq[h][u].w};
+                float d = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    d = fmaf(q[2 * i], __uint_as_float(w[i] << 16), d);
+                    d = fmaf(q[2 * i + 1], __uint_as_float(w[i] & 0xffff0000u), d);
+                }
+                d = row16_sum_dpp(d);
+                const int row = u * 4 + sub;
+                sc[u] = row < nk ? d : -INFINITY;
+                mx = fmaxf(mx, sc[u]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            float l = 0.f;
+            float acc[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float p = (mx == -INFINITY) ? 0.f : __expf(sc[u] - mx);
+                l += p;
+                const uint32_t w[4] = {r.vq[h][u].x, r.vq[h][u].y, r.vq[h][u].z, r.vq[h][u].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[2 * i] = fmaf(p, __uint_as_float(w[i] << 16), acc[2 * i]);
+                    acc[2 * i + 1] = fmaf(p, __uint_as_float(w[i] & 0xffff0000u), acc[2 * i + 1]);
+                }
+            }
+            l += __shfl_xor(l, 16, 64);
+            l += __shfl_xor(l, 32, 64);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                acc[i] += __shfl_xor(acc[i], 16, 64);
+                acc[i] += __shfl_xor(acc[i], 32, 64);
+            }
+            if (sub == 0) {
+                const float inv = l > 0.f ? 1.0f / l : 0.f;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[i] *= inv;
+                store_vec<bf16>(reinterpret_cast<bf16*>(xs_att) + (b * la.q_len + t) * GV_KC + head * D + c * 8, acc);
+            }
+        }
+    }
+}
+
 // The body is a device function of the workgroup index so that two GEMVs reading the same x can share ONE launch
 // (gemv_qkv_h4_kernel below): workgroups [0, nq) run one instantiation, the rest the other.
-template <int MR, int RW, bool LN = false, bool QKV = false>
+// ATT = U > 0 (round 4): the second operand pair's x rows (the attention output) are not read from memory but computed here, by
+// every workgroup, from the local KV window (see LocalAtt; U = row batches of 4 keys, 2 or 3): wave w takes the (sequence, head)
+// items w, w + 4, ... with exactly local_attend_kernel's lane mapping and arithmetic (attention.hip -- 16 lanes x 16 B per row, the
+// same fmaf / shuffle order, bf16 rounding of the result), so the fused layer is bit-identical to attention launch + GEMV.  Its
+// loads are issued right behind the first two chunks of W rows and it is evaluated in their shadow; the result sits in LDS until
+// the last chunk consumes it: the layer loses a dependent launch (~5 us at batch 1) for ~1 us of prologue.
+template <int MR, int RW, bool LN = false, bool QKV = false, int ATT = 0>
 __device__ __forceinline__ void gemv_body(const int bid, const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W,
-                                          int64_t ldw, const EpiArgs& ep, int K, const LnPro& ln, const Seg2& s2) {
+                                          int64_t ldw, const EpiArgs& ep, int K, const LnPro& ln, const Seg2& s2,
+                                          const LocalAtt& la = LocalAtt{}) {
     static_assert(!QKV || RW == 2, "QKV mode works on row pairs");
+    static_assert(ATT == 0 || (!LN && !QKV && RW == 1), "the attention producer feeds the residual-stream GEMV");
     __shared__ __attribute__((aligned(16))) char xs[MR * GV_KC * 2];
+    __shared__ __attribute__((aligned(16))) char xs_att[ATT ? MR * GV_KC * 2 : 16];
     __shared__ float red[2][4][MR];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int M = ep.M, N = ep.N;
@@ -2733,19 +2926,42 @@ __device__ __forceinline__ void gemv_body(const int bid, const bf16* __restrict_
         const int kw = min(GV_KC, (second ? s2.K : K) - kc);
         // thread t owns the 16-byte piece t of every x row of the chunk (kw / 8 <= 256 pieces per row)
         const bool own = tid < kw / 8;
+        const bool from_att = ATT && second;           // this chunk's x rows were produced into xs_att by the prologue below
         uint4 xv[MR];
 #pragma unroll
         for (int m = 0; m < MR; ++m)   // unconditional (clamped) loads, see load_w; rows >= M are zeroed when staged
-            xv[m] = *reinterpret_cast<const uint4*>(Xs + (int64_t)min(m, M - 1) * ldxs + kc + (own ? tid : 0) * 8);
+            xv[m] = *reinterpret_cast<const uint4*>((from_att ? X : Xs + kc) + (int64_t)min(m, M - 1) * (from_att ? ldx : ldxs) +
+                                                    (own ? tid : 0) * 8);
+        // ATT: this chunk's share of the wave's attention items -- loads BEFORE the weight rows, arithmetic behind them
+        LocalAttRegs<(ATT > 0 ? ATT : 1)> ar;
+        int aj0 = 0, aj1 = 0, a_items = 0;
+        if constexpr (ATT > 0) {
+            if (!second) {
+                a_items = (M / la.q_len) * la.heads;
+                const int ipw = (a_items + 3) / 4, nfc = K / GV_KC;
+                const int ipc = (ipw + nfc - 1) / nfc;       // <= ATT_HPW (few_rows_attn_res_ok)
+                aj0 = min((kg / GV_KC) * ipc, ipw);
+                aj1 = min(aj0 + ipc, ipw);
+                if (aj1 > aj0) local_att_issue<ATT>(la, a_items, aj0, aj1, lane, wave, ar);
+                if (kg == 0) {   // rows >= M (and columns >= heads * 128) of the staged operand are zero: the GEMV multiplies all MR rows
+                    for (int i = tid * 8; i < MR * GV_KC; i += 256 * 8)
+                        if (i >= M * GV_KC || (i % GV_KC) >= la.heads * 128) *reinterpret_cast<uint4*>(xs_att + i * 2) = uint4{0, 0, 0, 0};
+                }
+            }
+        }
         if (!PIPE || kg == 0) load_w(BUF, kg, true);                                    // this chunk's rows (first chunk / no pipeline)
         if (PIPE) load_w(std::integral_constant<int, (buf + 1) % NBUF>{}, kg + GV_KC, kg + GV_KC < k_all);   // next chunk's rows
+        if constexpr (ATT > 0) {
+            if (!second && aj1 > aj0) local_att_finish<ATT>(la, a_items, aj0, aj1, lane, wave, ar, xs_att);
+        }
         __syncthreads();                               // previous chunk fully consumed
-        if (own) {
+        if (own && !from_att) {
 #pragma unroll
             for (int m = 0; m < MR; ++m)
                 *reinterpret_cast<uint4*>(xs + (m * GV_KC + tid * 8) * 2) = m < M ? xv[m] : uint4{0, 0, 0, 0};
         }
         __syncthreads();
+        const char* xsrc = from_att ? xs_att : xs;
         if (LN) {   // K <= GV_KC: the chunk is the whole row.  Thread t owns the 16-byte piece t of every row.
             float v[MR][8];
             float part[MR];
@@ -2800,7 +3016,7 @@ __device__ __forceinline__ void gemv_body(const int bid, const bf16* __restrict_
             if (j * 512 < kw) {
 #pragma unroll
                 for (int m = 0; m < MR; ++m) {
-                    const uint4 xq = *reinterpret_cast<const uint4*>(xs + (m * GV_KC + j * 512 + lane * 8) * 2);
+                    const uint4 xq = *reinterpret_cast<const uint4*>(xsrc + (m * GV_KC + j * 512 + lane * 8) * 2);
 #pragma unroll
                     for (int r = 0; r < RW; ++r) acc[r][m] = dot8_bf16(wv[buf][r][j], xq, acc[r][m]);
                 }
@@ -2886,6 +3102,13 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__
                                                        int64_t ldw, const EpiArgs ep, int K, const LnPro ln,
                                                        const Seg2 s2 = Seg2{}) {
     gemv_body<MR, RW, LN, QKV>(blockIdx.x, X, ldx, W, ldw, ep, K, ln, s2);
+}
+
+// x += h4 . W2^T + b2 + attention(local window) . Wd^T + bd : the attention output never exists in memory (gemv_body<..., ATT = U>)
+template <int MR, int U>
+__global__ __launch_bounds__(256) void gemv_attn_res_kernel(const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W,
+                                                           int64_t ldw, const EpiArgs ep, int K, const Seg2 s2, const LocalAtt la) {
+    gemv_body<MR, 1, false, false, U>(blockIdx.x, X, ldx, W, ldw, ep, K, LnPro{}, s2, la);
 }
 
 // Parallel residual: the layer's QKV projection (LN1 prologue, RoPE + KV append) and its MLP up-projection (LN2 prologue, GELU)
@@ -3262,7 +3485,9 @@ BT_KNOB bool g_no_qkv_fusion = false;
 // also for several slices -- measured SLOWER (B = 64: 42.7k -> 36.5k tok/s): every slice pays an agent-scope release fence over
 // its freshly dirtied 16 KiB slab (guide: ~6.5 us) on a ~10 us GEMM; kept for A/B only
 BT_KNOB int g_mid_fuse = 1;
+BT_KNOB bool g_mid_dual = true;   // 17..256 rows: QKV and h->4h split-K GEMMs of a layer in one launch, their reductions in one (false: A/B)
 BT_KNOB bool g_mid_rows = true;   // 17..256-row stacks take the slab + fused-reduce path (false: A/B against the unfused launches)
+BT_KNOB bool g_few_attn = true;   // <= 4 rows, local window: the attention is computed inside the residual-stream GEMV (false: A/B)
 BT_KNOB bool g_few_dual = true;   // <= 4 rows: QKV and h->4h GEMVs of a layer in one launch (false: two launches, A/B)
 BT_KNOB int g_small_stages = 0;   // LDS ring depth of the 128^2 / 128x64 / 64x64 kernels: 0 = per-tile default, 2..4 forced (A/B)
 BT_KNOB int g_gemm_variant = 0;   // 0 auto; 1 force 128^2; 2/3 256^2 four-phase ring (plain/staggered); 4-8 timing ablations; 9/10 256^2
@@ -3510,6 +3735,13 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
             if (g_small_stages == 9) {
                 if (residual) BT_LAUNCH_T21(true, false);
                 else BT_LAUNCH_T21(false, false);
+            } else if (g_small_stages == 8) {   /* A/B: round-3 form without group 1's lgkmcnt(0) in front of the refill barriers */
+                if (residual)
+                    hipLaunchKernelGGL((gemm_bf16_mfma256x128_kernel<true, true, false>), dim3(tiles_m * tiles_n), dim3(512), 0, s,
+                                       (const bf16*)A, lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);
+                else
+                    hipLaunchKernelGGL((gemm_bf16_mfma256x128_kernel<false, true, false>), dim3(tiles_m * tiles_n), dim3(512), 0, s,
+                                       (const bf16*)A, lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);
             } else
 #endif
             if (residual) BT_LAUNCH_T21(true, true);
@@ -3981,6 +4213,60 @@ int few_rows_qkv_h4(hipStream_t s, int64_t B, int q_len, int heads, int head_dim
     return BT_OK;
 }
 
+bool few_rows_attn_res_ok(int64_t M, int q_len, int heads, int head_dim, int64_t H, int64_t I, int pos0_host, int64_t n_max) {
+    if (!(g_few_attn && !g_force_generic && g_gemm_variant != 22 && M >= 1 && M <= 2 && q_len >= 1 && q_len <= 2 && M % q_len == 0 &&
+          head_dim == 128 && H == (int64_t)heads * 128 && H % 512 == 0 && H <= GV_KC && I % GV_KC == 0 && pos0_host >= 0 &&
+          pos0_host + q_len <= 12 && n_max <= 64))
+        return false;
+    // a wave's (sequence, head) items are spread over the first segment's K chunks, at most ATT_HPW per chunk
+    const int64_t ipw = ceil_div((M / q_len) * heads, 4), nfc = I / GV_KC;
+    return ceil_div(ipw, nfc) <= ATT_HPW;
+}
+
+int few_rows_attn_res(hipStream_t s, int64_t M, int q_len, int heads, int64_t I, const void* h4, const void* h_w, const void* h_b,
+                      const void* qkv, int64_t ld_qkv, const void* kc, const void* vc, int64_t n_max, int pos0_host,
+                      const void* dense_w, const void* dense_b, void* x, int64_t ldx) {
+    const int64_t H = (int64_t)heads * 128;
+    EpiArgs ep{};
+    ep.bias = (const bf16*)h_b;
+    ep.res = (const bf16*)x;
+    ep.ldr = ldx;
+    ep.out = (bf16*)x;
+    ep.ldo = ldx;
+    ep.M = (int)M;
+    ep.N = (int)H;
+    ep.act = BT_ACT_NONE;
+    ep.q = QkvEpi{};
+    Seg2 s2;
+    s2.x = nullptr;                       // produced in LDS
+    s2.w = (const bf16*)dense_w;
+    s2.bias = (const bf16*)dense_b;
+    s2.ldx = H;
+    s2.ldw = H;
+    s2.K = (int)H;
+    LocalAtt la;
+    la.qkv = (const bf16*)qkv;
+    la.kc = (const bf16*)kc;
+    la.vc = (const bf16*)vc;
+    la.ld_qkv = ld_qkv;
+    la.n_max = n_max;
+    la.pos0 = pos0_host;
+    la.q_len = q_len;
+    la.heads = heads;
+    la.scale = 1.0f / sqrtf(128.0f);
+    ProfScope ps(BT_PROF_LINEAR_MFMA, s);
+    const unsigned grid = (unsigned)ceil_div(H, 4);
+#define BT_LAUNCH_AR(MR_, U_)                                                                                                    \
+    hipLaunchKernelGGL((gemv_attn_res_kernel<MR_, U_>), dim3(grid), dim3(256), 0, s, (const bf16*)h4, I, (const bf16*)h_w, I, ep, \
+                       (int)I, s2, la)
+    const bool u2 = pos0_host + q_len <= 8;
+    if (M <= 1) { if (u2) BT_LAUNCH_AR(1, 2); else BT_LAUNCH_AR(1, 3); }
+    else { if (u2) BT_LAUNCH_AR(2, 2); else BT_LAUNCH_AR(2, 3); }
+#undef BT_LAUNCH_AR
+    BT_LAUNCH_CHECK("fused local attention + residual GEMV launch");
+    return BT_OK;
+}
+
 }  // namespace bt
 
 // ---- mid-batch path (17 .. 256 rows): split-K slabs + fused reduces; called by bt_decoder_forward (engine.hip) ------------------
@@ -4013,6 +4299,10 @@ int64_t mid_slab_bytes(int64_t M, int64_t H, int64_t I) {
         if (ks == 0) return -1;
         const int64_t sl = sh[1] / ks + (sh[2] ? sh[2] / ks : 0);
         worst = std::max(worst, sl * M * sh[0] * 4);
+    }
+    {   // the dual QKV + h->4h launch keeps both problems' slabs at once
+        const int ks = mid_slice_len(tm * (ceil_div(3 * H, 64) + ceil_div(I, 64)), H, 0);
+        if (ks > 0) worst = std::max(worst, (H / ks) * M * (3 * H + I) * 4);
     }
     return worst;
 }
@@ -4092,6 +4382,69 @@ int mid_qkv(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, const 
     return BT_OK;
 }
 
+// QKV projection (LN1 rows) and MLP up-projection (LN2 rows) of a layer as ONE split-K launch + ONE reduce launch
+int mid_qkv_gelu(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, const void* x1, const void* qkv_w, const void* qkv_b,
+                 void* qkv, int64_t ld_qkv, void* kc, void* vc, int64_t n_max, const int32_t* pos0_dev, int pos0_host,
+                 const int32_t* pos_table, const float* cos_tab, const float* sin_tab, const void* x2, const void* h4_w,
+                 const void* h4_b, void* h4, int64_t I, void* slabs, int64_t slab_bytes, int* counters, bool* done) {
+    const int64_t H = (int64_t)heads * head_dim, M = B * q_len, N1 = 3 * H, N2 = I, K = H;
+    *done = false;
+    if (!g_mid_dual || g_mid_fuse == 2 || N1 % 64 != 0 || N2 % 64 != 0) return BT_OK;
+    const int tiles_m = (int)ceil_div(M, 64), t1 = (int)(N1 / 64), t2 = (int)(N2 / 64);
+    const int ks = mid_slice_len((int64_t)tiles_m * (t1 + t2), K, 0);
+    if (ks <= 0) return BT_OK;
+    const int slices = (int)(K / ks);
+    // one K slice already fills the chip (M >~ 100): the separate launches run their fused epilogues directly (no slabs, no reduce)
+    // and a shared launch only lengthens the critical path -- measured: B = 128 62.2k -> 59.3k, B = 256 78.7k -> 72.3k tok/s with a
+    // fused dual launch (profiles/r4_bench_sm_b*.json) -> the shared launch is for the multi-slice regime (M <= 64 at 1.2B dims)
+    if (slices < 2 || g_mid_fuse == 0) return BT_OK;
+    if ((int64_t)slices * M * (N1 + N2) * 4 > slab_bytes) return BT_OK;
+    EpiArgs e1{};
+    e1.bias = (const bf16*)qkv_b;
+    e1.out = (bf16*)qkv;
+    e1.ldo = ld_qkv;
+    e1.M = (int)M;
+    e1.N = (int)N1;
+    e1.q.kc = (bf16*)kc;
+    e1.q.vc = (bf16*)vc;
+    e1.q.n_max = n_max;
+    e1.q.pos0_dev = pos0_dev;
+    e1.q.pos_table = pos_table;
+    e1.q.cos_tab = cos_tab;
+    e1.q.sin_tab = sin_tab;
+    e1.q.pos0_host = pos0_host;
+    e1.q.q_len = q_len;
+    e1.q.heads = heads;
+    e1.q.head_dim = head_dim;
+    e1.q.enabled = 1;
+    EpiArgs e2{};
+    e2.bias = (const bf16*)h4_b;
+    e2.out = (bf16*)h4;
+    e2.ldo = I;
+    e2.M = (int)M;
+    e2.N = (int)N2;
+    e2.act = BT_ACT_GELU;
+    float* p1 = (float*)slabs;
+    float* p2 = p1 + (int64_t)slices * M * N1;
+    DualArgs da;
+    da.g[0] = GemmSide{(const bf16*)x1, (const bf16*)qkv_w, H, K, p1, counters};
+    da.g[1] = GemmSide{(const bf16*)x2, (const bf16*)h4_w, H, K, p2, counters ? counters + tiles_m * t1 : nullptr};
+    da.ep[0] = e1;
+    da.ep[1] = e2;
+    {
+        ProfScope ps(BT_PROF_LINEAR_MFMA, s);
+        // slab mode: plain stores of the fp32 partial tiles (the epilogue arguments only carry M and N)
+        hipLaunchKernelGGL(gemm_bf16_mfma_dual_kernel, dim3(tiles_m * (t1 + t2), slices), dim3(256), 0, s, da, ks, tiles_m, t1, t2);
+        BT_LAUNCH_CHECK("mid-batch dual GEMM launch");
+    }
+    *done = true;
+    ProfScope ps(BT_PROF_ROPE, s);
+    const int nb1 = (int)ceil_div(M * (N1 / 8), 256), nb2 = (int)ceil_div(M * (N2 / 8), 256);
+    hipLaunchKernelGGL(mid_reduce_qkv_gelu_kernel, dim3(nb1 + nb2), dim3(256), 0, s, p1, e1, nb1, p2, e2, slices);
+    BT_LAUNCH_CHECK("mid-batch QKV + GELU reduce launch");
+    return BT_OK;
+}
+
 int mid_gelu(hipStream_t s, int64_t M, int64_t N, int64_t K, const void* x, int64_t ldx, const void* w, const void* bias, void* out,
              int64_t ldo, void* slabs, int64_t slab_bytes, int* counters) {
     int slices = 0;
@@ -4154,6 +4507,8 @@ extern "C" void bt_debug_skinny_rows(int n) { g_skinny_rows = n; }
 extern "C" void bt_debug_small_stages(int n) { g_small_stages = n; }
 extern "C" void bt_debug_mid_rows(int on) { g_mid_rows = on != 0; }
 extern "C" void bt_debug_few_dual(int on) { g_few_dual = on != 0; }
+extern "C" void bt_debug_few_attn(int on) { g_few_attn = on != 0; }
 extern "C" void bt_debug_mid_fuse(int mode) { g_mid_fuse = mode; }
+extern "C" void bt_debug_mid_dual(int on) { g_mid_dual = on != 0; }
 extern "C" void bt_debug_no_qkv_fusion(int on) { g_no_qkv_fusion = on != 0; }
 #endif

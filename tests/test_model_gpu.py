@@ -1624,3 +1624,86 @@ def test_few_rows_dual_launch_is_bit_identical(B, dbg_lib):
     assert torch.equal(a, b) and torch.equal(ctx_a, ctx_b)
     del model
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("L", [4, 8])
+@pytest.mark.parametrize("B", [1, 2, 4])
+def test_few_rows_fused_attention_is_bit_identical(B, L, dbg_lib):
+    """Round 4: <= 4 rows, token decoder: the local-window attention is computed INSIDE the residual-stream GEMV (gemv_attn_res_kernel:
+    every workgroup recomputes the <= 12-key window of all heads with local_attend_kernel's lane mapping and arithmetic), so the
+    layer is 2 launches.  == attention launch + bt_linear2, bit for bit: tokens and the last context embedding equal, graphs on
+    (what the engine runs) and off.  L = 4 -> window <= 5 keys (U = 2), L = 8 -> <= 9 keys (U = 3); B = 1 / 2 / 4 -> step 0 has
+    M = 2 / 4 / 8 rows (8 rows = MFMA streamer, not this path), steps 1.. have M = 1 / 2 / 4."""
+    import dataclasses
+    base = named_dims("block_main_b4_1.2b" if L == 4 else "block_main_b8_1.2b")
+    dims = dataclasses.replace(base, name=f"b{L}_1.2b_2layer", bd=dataclasses.replace(base.bd, layers=2),
+                               td=dataclasses.replace(base.td, layers=2))
+    sd = random_state_dict(dims, seed=5, include_unused_embed_in=False)
+    model = load_block_transformer_from_dims(dims, "fp32", keep_unused_embed_in=False)
+    model.load_state_dict(sd, strict=True)
+    model = model.bfloat16().to(DEV)
+    model.token_decoder.generation_config.eos_token_id = None
+    prompt = torch.randint(0, dims.vocab, (B, 64), generator=torch.Generator().manual_seed(B)).to(DEV)
+    outs = {}
+    try:
+        for fuse in (1, 0):
+            dbg_lib.bt_debug_few_attn(fuse)
+            for graphs in (True, False):
+                model._engine = None
+                model.use_graphs = graphs
+                out = model.generate(prompt, max_length=64 + 5 * L).cpu()
+                outs[(fuse, graphs)] = (out, model._engine.ctx.float().cpu().clone())
+    finally:
+        dbg_lib.bt_debug_few_attn(1)
+        model.use_graphs = True
+        model._engine = None
+    ref_out, ref_ctx = outs[(0, False)]
+    for key, (out, ctx) in outs.items():
+        assert torch.equal(out, ref_out) and torch.equal(ctx, ref_ctx), key
+    assert len({tuple(r.tolist()) for r in ref_out[:, 64:]}) == B or B == 1
+    del model
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("B", [24, 64, 128, 256])
+def test_mid_batch_dual_gemm_matches_separate_launches(B, dbg_lib):
+    """Round 4: 17..256 rows: the layer's QKV projection and MLP up-projection as ONE split-K launch (gemm_bf16_mfma_dual_kernel) and
+    their reductions as one (mid_reduce_qkv_gelu_kernel; none at all when one K slice fills the chip, B = 256) against the two
+    launches each of round 2 (bt_debug_mid_dual(0)).  The K slicing may differ (224 instead of 96 / 128 tiles per row block), so
+    equality is up to fp32 summation order: first tokens equal except rare bf16 near-ties; both against the fp32 oracle,
+    margin-aware; graphs on == off for the dual path, bit for bit."""
+    import dataclasses
+    base = named_dims("block_main_b4_1.2b")
+    dims = dataclasses.replace(base, name="b4_1.2b_2layer", bd=dataclasses.replace(base.bd, layers=2),
+                               td=dataclasses.replace(base.td, layers=2))
+    sd = random_state_dict(dims, seed=5, include_unused_embed_in=False)
+    model = load_block_transformer_from_dims(dims, "fp32", keep_unused_embed_in=False)
+    model.load_state_dict(sd, strict=True)
+    model = model.bfloat16().to(DEV)
+    model.token_decoder.generation_config.eos_token_id = None
+    prompt = torch.randint(0, dims.vocab, (B, 32), generator=torch.Generator().manual_seed(B)).to(DEV)
+    try:
+        dbg_lib.bt_debug_mid_dual(1)
+        dual = model.generate(prompt, max_length=48).cpu()
+        model._engine = None
+        model.use_graphs = False
+        dual_eager = model.generate(prompt, max_length=48).cpu()
+        model.use_graphs = True
+        dbg_lib.bt_debug_mid_dual(0)
+        model._engine = None
+        sep = model.generate(prompt, max_length=48).cpu()
+    finally:
+        dbg_lib.bt_debug_mid_dual(1)
+        model.use_graphs = True
+        model._engine = None
+    assert torch.equal(dual, dual_eager)
+    assert torch.equal(dual[:, :32], prompt.cpu())
+    assert (dual[:, 32] == sep[:, 32]).float().mean() >= 0.9, (dual[:, 32] == sep[:, 32]).float().mean()
+    sd16 = {k: v.bfloat16().float() for k, v in sd.items()}
+    o = oracle_from_dims(dims, sd16)
+    rows = torch.linspace(0, B - 1, 8).long()
+    for name, out in (("dual", dual), ("separate", sep)):
+        _, ref_lg = oracle_block_logits(o, prompt.cpu()[rows], out[rows, 32:36])
+        assert_tokens_within_noise(ref_lg, out[rows, 32:36], 3e-2, 1e-2, f"mid-batch dual GEMM B={B} {name}")
+    del model
+    torch.cuda.empty_cache()

@@ -1,0 +1,65 @@
+#!/usr/bin/env python
+"""Same-box, same-process A/B of the small- / mid-batch launch structures through the debug library (round 4):
+    few_attn  : <= 2 rows, token decoder: local attention inside the residual-stream GEMV (1) vs its own launch (0)
+    mid_dual  : 17..64 rows: QKV + h->4h split-K GEMMs in one launch and one reduce (1) vs two each (0)
+Prints one JSON line per (batch, knob setting): end-to-end tokens/s of generate(prefill 2048 / decode 128), best of --reps.
+
+    python tools/ab_small_batch.py --knob few_attn --batches 1,2 [--reps 3]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from block_transformer_amd import _lib  # noqa: E402
+from block_transformer_amd.config import get_max_length, named_dims  # noqa: E402
+from block_transformer_amd.model.utils import load_block_transformer_from_dims  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--knob", choices=["few_attn", "mid_dual"], required=True)
+    ap.add_argument("--batches", default="1,2")
+    ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--prefill", type=int, default=2048)
+    ap.add_argument("--decode", type=int, default=128)
+    args = ap.parse_args()
+    _lib.use_debug_library(True)
+    hooks = _lib.lib()
+    setter = {"few_attn": hooks.bt_debug_few_attn, "mid_dual": hooks.bt_debug_mid_dual}[args.knob]
+    dims = named_dims("block_main_b4_1.2b")
+    torch.manual_seed(1234)
+    with torch.device("cuda"):
+        model = load_block_transformer_from_dims(dims, "bf16", keep_unused_embed_in=False)
+    model.eval()
+    model.token_decoder.generation_config.eos_token_id = None
+    ml = get_max_length(dims.L, args.prefill, args.decode)
+    for B in (int(b) for b in args.batches.split(",")):
+        ids = torch.randint(0, dims.vocab, (B, args.prefill), generator=torch.Generator().manual_seed(B)).cuda()
+        best = {0: 1e9, 1: 1e9}
+        for rep in range(args.reps):
+            for on in (1, 0):                     # interleaved: same box state for both settings
+                setter(on)
+                model._engine = None              # captured graphs hold the launch sequence
+                model.generate(ids, max_length=ml)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(3):
+                    model.generate(ids, max_length=ml)
+                torch.cuda.synchronize()
+                best[on] = min(best[on], (time.perf_counter() - t0) / 3)
+        setter(1)
+        for on in (1, 0):
+            print(json.dumps({"knob": args.knob, "on": on, "batch": B, "prefill": args.prefill, "decode": args.decode,
+                              "ms_per_generate": round(best[on] * 1e3, 3), "tokens_per_s": round(B * args.decode / best[on], 1)}),
+                  flush=True)
+        model.release_buffers()
+
+
+if __name__ == "__main__":
+    main()

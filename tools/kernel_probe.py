@@ -467,9 +467,10 @@ def main():
             for mode, res_ in (("bias", None), ("bias_res", r)):
                 rec = {"op": "t21", "M": M, "N": N, "K": K, "mode": mode}
                 for rep in range(3):
-                    for name, v, st in (("t256x128_us", 0, 0), ("t256x128_no_setprio_us", 0, 9), ("t128x128_us", 1, 0)):
+                    for name, v, st in (("t256x128_us", 0, 0), ("t256x128_r3_no_lgkm_wait_us", 0, 8), ("t256x128_no_setprio_us", 0, 9),
+                                        ("t128x128_us", 1, 0)):
                         hooks.bt_debug_gemm_variant(v)
-                        hooks.bt_debug_small_stages(st)     # 9: the 256 x 128 kernel without s_setprio around its MFMA clusters (A/B)
+                        hooks.bt_debug_small_stages(st)     # 9: without s_setprio around its MFMA clusters; 8: round-3 form (SAFE = false)
                         ms = timed(lambda: ops.linear(x, w, b, res_, out=out), 20)
                         rec.setdefault(name, []).append(round(ms * 1e3, 1))
                     hooks.bt_debug_gemm_variant(0)
