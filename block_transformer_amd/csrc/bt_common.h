@@ -215,7 +215,8 @@ int mid_qkv(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, const 
 int mid_qkv_gelu(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, const void* x1, const void* qkv_w, const void* qkv_b,
                  void* qkv, int64_t ld_qkv, void* kc, void* vc, int64_t n_max, const int32_t* pos0_dev, int pos0_host,
                  const int32_t* pos_table, const float* cos_tab, const float* sin_tab, const void* x2, const void* h4_w,
-                 const void* h4_b, void* h4, int64_t I, void* slabs, int64_t slab_bytes, int* counters, bool* done);
+                 const void* h4_b, void* h4, int64_t I, void* slabs, int64_t slab_bytes, int* counters, bool* done, void* att,
+                 int64_t ld_att, bool* attn_done);   // att != NULL: the caller allows the local-window attention inside the reduce launch
 int mid_gelu(hipStream_t s, int64_t M, int64_t N, int64_t K, const void* x, int64_t ldx, const void* w, const void* bias, void* out,
              int64_t ldo, void* slabs, int64_t slab_bytes, int* counters);
 constexpr int64_t MID_COUNTER_BYTES = 4096;   // one int per 64 x 64 tile of a <= 256-row GEMM with N <= 16384

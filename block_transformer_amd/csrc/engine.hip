@@ -120,18 +120,21 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
             char* vc = reinterpret_cast<char*>(attn->v_cache) + (int64_t)l * attn->layer_stride * es;
             // parallel residual: the QKV projection (LN1 rows) and the MLP up-projection (LN2 rows) read the same layer input and
             // neither depends on the attention -> one split-K launch + one reduce launch for both (round 4)
-            bool dual = false;
+            bool dual = false, attn_done = false;
+            // (att == ln1 is read by the GEMM of this very call: the reduce launch that may write the attention output runs behind it)
+            const bool local_win = attn->mode == 0 && !attn->mask && !skip && attn->n_split <= 1;
             BT_TRY(mid_qkv_gelu(hs, B, q_len, dims->heads, dims->head_dim, ln1, lw.qkv_w, lw.qkv_b, qkv, 3 * H, kc, vc, attn->n_max,
                                 attn->pos0_dev, attn->pos0_host, attn->pos_table, attn->cos_tab, attn->sin_tab, ln2, lw.h4_w,
-                                lw.h4_b, h4, I, scratch, slab_room, counters, &dual));
+                                lw.h4_b, h4, I, scratch, slab_room, counters, &dual, local_win ? att : nullptr, H, &attn_done));
             if (!dual)
                 BT_TRY(mid_qkv(hs, B, q_len, dims->heads, dims->head_dim, ln1, H, lw.qkv_w, lw.qkv_b, qkv, 3 * H, kc, vc, attn->n_max,
                                attn->pos0_dev, attn->pos0_host, attn->pos_table, attn->cos_tab, attn->sin_tab, scratch, slab_room,
                                counters));
             // the attention output overwrites ln1 (its only reader, the QKV GEMM, is done); ln2 stays until the MLP has read it
-            BT_TRY(attention_impl(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc, attn->n_max,
-                                attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H, attn->n_split,
-                                attn->split_ws, attn->split_ws_bytes, skip, stream));
+            if (!attn_done)
+                BT_TRY(attention_impl(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc, attn->n_max,
+                                    attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H, attn->n_split,
+                                    attn->split_ws, attn->split_ws_bytes, skip, stream));
             if (!dual) BT_TRY(mid_gelu(hs, M, I, H, ln2, H, lw.h4_w, lw.h4_b, h4, I, scratch, slab_room, counters));
             const bool more = l + 1 < dims->layers;
             const bt_layer_weights& nx = w->layers_host[more ? l + 1 : l];

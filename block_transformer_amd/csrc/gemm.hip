@@ -752,6 +752,140 @@ __global__ __launch_bounds__(256) void mid_reduce_qkv_gelu_kernel(const float* _
     else splitk_reduce_body((int64_t)(blockIdx.x - nb1) * 256 + threadIdx.x, p2, slices, ep2);
 }
 
+// The same launch with the token decoder's local-window attention folded in (round 4): a WAVE per (sequence, head) sums the q / k / v
+// slab columns of its head (lanes 0-15 q, 16-31 k, 32-47 v: one 8-column piece each), adds the bias, rotates (the rotate-half partner
+// piece sits two lanes away), appends (k, v) to the cache rows pos0 + t -- value for value what mid_reduce_qkv_body writes -- and
+// then attends: lanes 0-15 hold the query row exactly as local_attend_kernel lays it out (16 lanes x 8 dims), the cached rows
+// (< pos0, written by earlier launches) are loaded 16 B per lane, the rows of this call come over from lanes 16-47 by shuffle, the
+// score is a 16-lane DPP butterfly and the <= KMAX-key softmax runs sequentially in registers.  The q rows are not written at all
+// and no attention launch follows: a 17..64-row token-decoder layer is 4 launches.  (Block decoder: global cache -> stays separate.)
+template <int KMAX>
+__device__ __forceinline__ void mid_reduce_qkv_attn_body(const int item, const float* __restrict__ partial, int slices, const EpiArgs& ep,
+                                                         bf16* __restrict__ att, int64_t ld_att, float scale) {
+    constexpr int D = 128;
+    const int lane = threadIdx.x & 63;
+    const int heads = ep.q.heads, q_len = ep.q.q_len, N = ep.N;
+    const int n_seq = ep.M / q_len;
+    if (item >= n_seq * heads) return;
+    const int b = item / heads, head = item - b * heads;
+    const int part = lane >> 4, c = lane & 15;                  // part 3 (lanes 48-63) only takes part in the shuffles
+    const int pos0 = ep.q.pos0_host;
+    const int64_t slab = (int64_t)ep.M * N;
+    const int n = head * 3 * D + (part < 3 ? part : 0) * D + c * 8;
+    const bf16* kbase = ep.q.kc + ((int64_t)b * heads + head) * ep.q.n_max * D + c * 8;
+    const bf16* vbase = ep.q.vc + ((int64_t)b * heads + head) * ep.q.n_max * D + c * 8;
+    // cached rows of earlier calls (lanes 0-15 use them; every lane loads: clamped, L2-resident)
+    uint4 kq[KMAX - 1], vq[KMAX - 1];
+#pragma unroll
+    for (int r = 0; r < KMAX - 1; ++r) {
+        const int rr = r < pos0 ? r : (pos0 > 0 ? pos0 - 1 : 0);
+        kq[r] = *reinterpret_cast<const uint4*>(kbase + (int64_t)rr * D);
+        vq[r] = *reinterpret_cast<const uint4*>(vbase + (int64_t)rr * D);
+    }
+    float knew[2][8], vnew[2][8];                               // this call's rows, as seen by lanes 0-15 (bf16-rounded)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        if (t >= q_len) break;
+        const int m = b * q_len + t;
+        float v[8];
+        sum_slabs8(partial, slices, slab, (int64_t)m * N + n, v);
+        if (ep.bias) {
+            float bv[8];
+            load_vec<bf16>(ep.bias + n, bv);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] += bv[i];
+        }
+        // partial RoPE (rot == 32): pieces 0, 1 (dims 0-15) pair with pieces 2, 3 (dims 16-31) of q and k
+        float w[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w[i] = __shfl_xor(v[i], 2, 64);
+        if (part < 2 && c < 4) {
+            const bool lo = c < 2;
+            const int rpos = ep.q.pos_table ? ep.q.pos_table[pos0 + t] : pos0 + t;
+            const int e0 = (lo ? c : c - 2) * 8;
+            const float* ct = ep.q.cos_tab + (int64_t)rpos * 16 + e0;
+            const float* st = ep.q.sin_tab + (int64_t)rpos * 16 + e0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float cs = ct[i], sn = st[i];
+                v[i] = lo ? v[i] * cs - w[i] * sn : v[i] * cs + w[i] * sn;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = bf16_to_f32(f32_to_bf16(v[i]));   // what the unfused path stores and reads back
+        if (part == 1 || part == 2)
+            store_vec<bf16>((part == 1 ? ep.q.kc : ep.q.vc) + (((int64_t)b * heads + head) * ep.q.n_max + pos0 + t) * D + c * 8, v);
+        // hand k / v of this row to lanes 0-15
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            knew[t][i] = __shfl(v[i], c + 16, 64);
+            vnew[t][i] = __shfl(v[i], c + 32, 64);
+        }
+        // ---- attention of row t over pos0 + t + 1 keys (meaningful in lanes 0-15; the others compute along harmlessly) ----
+        float q[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = v[i] * scale;
+        float sc[KMAX + 1];
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < KMAX - 1; ++r) {
+            const uint32_t kw[4] = {kq[r].x, kq[r].y, kq[r].z, kq[r].w};
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                d = fmaf(q[2 * i], __uint_as_float(kw[i] << 16), d);
+                d = fmaf(q[2 * i + 1], __uint_as_float(kw[i] & 0xffff0000u), d);
+            }
+            d = row16_sum_dpp(d);
+            sc[r] = r < pos0 ? d : -INFINITY;
+            mx = fmaxf(mx, sc[r]);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            float d = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) d = fmaf(q[i], knew[tt <= t ? tt : t][i], d);
+            d = row16_sum_dpp(d);
+            sc[KMAX - 1 + tt] = tt <= t ? d : -INFINITY;
+            mx = fmaxf(mx, sc[KMAX - 1 + tt]);
+        }
+        float l = 0.f, acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int r = 0; r < KMAX - 1; ++r) {
+            const float p = __expf(sc[r] - mx);                  // masked rows: exp(-inf) = 0
+            l += p;
+            const uint32_t vw[4] = {vq[r].x, vq[r].y, vq[r].z, vq[r].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[2 * i] = fmaf(p, __uint_as_float(vw[i] << 16), acc[2 * i]);
+                acc[2 * i + 1] = fmaf(p, __uint_as_float(vw[i] & 0xffff0000u), acc[2 * i + 1]);
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const float p = __expf(sc[KMAX - 1 + tt] - mx);
+            l += p;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = fmaf(p, vnew[tt <= t ? tt : t][i], acc[i]);
+        }
+        if (part == 0) {
+            const float inv = 1.0f / l;                          // the row's own key is always visible: l >= 1
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] *= inv;
+            store_vec<bf16>(att + (int64_t)m * ld_att + head * D + c * 8, acc);
+        }
+    }
+}
+template <int KMAX>
+__global__ __launch_bounds__(256) void mid_reduce_qkv_attn_gelu_kernel(const float* __restrict__ p1, const EpiArgs ep1, int nb1,
+                                                                      const float* __restrict__ p2, const EpiArgs ep2, int slices,
+                                                                      bf16* __restrict__ att, int64_t ld_att, float scale) {
+    if ((int)blockIdx.x < nb1) mid_reduce_qkv_attn_body<KMAX>((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), p1, slices, ep1, att, ld_att, scale);
+    else splitk_reduce_body((int64_t)(blockIdx.x - nb1) * 256 + threadIdx.x, p2, slices, ep2);
+}
+
 // Residual stream: x[m, :] += sum(slabs) + bias + bias2 (in place, rounded to bf16 like the unfused epilogues), then the NEXT
 // layer's two LayerNorms of the new row (ln1 / ln2; skipped when ln.w == nullptr).  One workgroup per row, 8 columns per
 // thread and 2048-column chunk, the row stays in registers (H <= 8192).
@@ -3104,12 +3238,14 @@ __global__ __launch_bounds__(256) void gemv_bf16_kernel(const bf16* __restrict__
     gemv_body<MR, RW, LN, QKV>(blockIdx.x, X, ldx, W, ldw, ep, K, ln, s2);
 }
 
+#ifdef BT_DEBUG_HOOKS   // measured, not adopted (see g_few_attn): A/B and bit-identity test only
 // x += h4 . W2^T + b2 + attention(local window) . Wd^T + bd : the attention output never exists in memory (gemv_body<..., ATT = U>)
 template <int MR, int U>
 __global__ __launch_bounds__(256) void gemv_attn_res_kernel(const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W,
                                                            int64_t ldw, const EpiArgs ep, int K, const Seg2 s2, const LocalAtt la) {
     gemv_body<MR, 1, false, false, U>(blockIdx.x, X, ldx, W, ldw, ep, K, LnPro{}, s2, la);
 }
+#endif
 
 // Parallel residual: the layer's QKV projection (LN1 prologue, RoPE + KV append) and its MLP up-projection (LN2 prologue, GELU)
 // both read the SAME x and do not depend on each other -> one launch streams both weight matrices (58 MB at 1.2B dims)
@@ -3485,9 +3621,14 @@ BT_KNOB bool g_no_qkv_fusion = false;
 // also for several slices -- measured SLOWER (B = 64: 42.7k -> 36.5k tok/s): every slice pays an agent-scope release fence over
 // its freshly dirtied 16 KiB slab (guide: ~6.5 us) on a ~10 us GEMM; kept for A/B only
 BT_KNOB int g_mid_fuse = 1;
+BT_KNOB bool g_mid_attn = true;   // ... and the token decoder's local-window attention inside that reduce launch (false: A/B)
 BT_KNOB bool g_mid_dual = true;   // 17..256 rows: QKV and h->4h split-K GEMMs of a layer in one launch, their reductions in one (false: A/B)
 BT_KNOB bool g_mid_rows = true;   // 17..256-row stacks take the slab + fused-reduce path (false: A/B against the unfused launches)
-BT_KNOB bool g_few_attn = true;   // <= 4 rows, local window: the attention is computed inside the residual-stream GEMV (false: A/B)
+// <= 2 rows, local window: the attention computed inside the residual-stream GEMV.  Built and A/B-measured in round 4
+// (profiles/r4_ab_few_attn.jsonl, same box, interleaved): B = 1 1695 vs 1725 tok/s, B = 2 2950 vs 2921 -- a wash: the per-workgroup
+// attention arithmetic (latency chains of ~28 cross-lane ops per item, redundantly in 512 workgroups) costs what the dependent
+// launch cost.  Off; the kernel and its bit-identity test live in the debug library only.
+BT_KNOB bool g_few_attn = false;
 BT_KNOB bool g_few_dual = true;   // <= 4 rows: QKV and h->4h GEMVs of a layer in one launch (false: two launches, A/B)
 BT_KNOB int g_small_stages = 0;   // LDS ring depth of the 128^2 / 128x64 / 64x64 kernels: 0 = per-tile default, 2..4 forced (A/B)
 BT_KNOB int g_gemm_variant = 0;   // 0 auto; 1 force 128^2; 2/3 256^2 four-phase ring (plain/staggered); 4-8 timing ablations; 9/10 256^2
@@ -4213,6 +4354,14 @@ int few_rows_qkv_h4(hipStream_t s, int64_t B, int q_len, int heads, int head_dim
     return BT_OK;
 }
 
+#ifndef BT_DEBUG_HOOKS
+bool few_rows_attn_res_ok(int64_t, int, int, int, int64_t, int64_t, int, int64_t) { return false; }
+int few_rows_attn_res(hipStream_t, int64_t, int, int, int64_t, const void*, const void*, const void*, const void*, int64_t, const void*,
+                      const void*, int64_t, int, const void*, const void*, void*, int64_t) {
+    set_error("fused local attention + residual GEMV: debug library only");
+    return BT_ERR_UNSUPPORTED;
+}
+#else
 bool few_rows_attn_res_ok(int64_t M, int q_len, int heads, int head_dim, int64_t H, int64_t I, int pos0_host, int64_t n_max) {
     if (!(g_few_attn && !g_force_generic && g_gemm_variant != 22 && M >= 1 && M <= 2 && q_len >= 1 && q_len <= 2 && M % q_len == 0 &&
           head_dim == 128 && H == (int64_t)heads * 128 && H % 512 == 0 && H <= GV_KC && I % GV_KC == 0 && pos0_host >= 0 &&
@@ -4266,6 +4415,7 @@ int few_rows_attn_res(hipStream_t s, int64_t M, int q_len, int heads, int64_t I,
     BT_LAUNCH_CHECK("fused local attention + residual GEMV launch");
     return BT_OK;
 }
+#endif  // BT_DEBUG_HOOKS
 
 }  // namespace bt
 
@@ -4386,9 +4536,11 @@ int mid_qkv(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, const 
 int mid_qkv_gelu(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, const void* x1, const void* qkv_w, const void* qkv_b,
                  void* qkv, int64_t ld_qkv, void* kc, void* vc, int64_t n_max, const int32_t* pos0_dev, int pos0_host,
                  const int32_t* pos_table, const float* cos_tab, const float* sin_tab, const void* x2, const void* h4_w,
-                 const void* h4_b, void* h4, int64_t I, void* slabs, int64_t slab_bytes, int* counters, bool* done) {
+                 const void* h4_b, void* h4, int64_t I, void* slabs, int64_t slab_bytes, int* counters, bool* done, void* att,
+                 int64_t ld_att, bool* attn_done) {
     const int64_t H = (int64_t)heads * head_dim, M = B * q_len, N1 = 3 * H, N2 = I, K = H;
     *done = false;
+    if (attn_done) *attn_done = false;
     if (!g_mid_dual || g_mid_fuse == 2 || N1 % 64 != 0 || N2 % 64 != 0) return BT_OK;
     const int tiles_m = (int)ceil_div(M, 64), t1 = (int)(N1 / 64), t2 = (int)(N2 / 64);
     const int ks = mid_slice_len((int64_t)tiles_m * (t1 + t2), K, 0);
@@ -4438,8 +4590,25 @@ int mid_qkv_gelu(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, c
         BT_LAUNCH_CHECK("mid-batch dual GEMM launch");
     }
     *done = true;
+    const int nb2 = (int)ceil_div(M * (N2 / 8), 256);
+    // token decoder (local window at a host-known position, no mask): the attention rides in the same launch
+    if (att && attn_done && g_mid_attn && !pos0_dev && head_dim == 128 && q_len <= 2 && pos0_host >= 0 && pos0_host + q_len <= 12 &&
+        n_max >= pos0_host + q_len && aligned16(kc) && aligned16(vc) && aligned16(att) && ld_att % 8 == 0) {
+        ProfScope ps(BT_PROF_ATTN_ROWS, s);
+        const int nb1 = (int)ceil_div(B * heads, 4);
+        const float scale = 1.0f / sqrtf(128.0f);
+        if (pos0_host + q_len <= 8)
+            hipLaunchKernelGGL((mid_reduce_qkv_attn_gelu_kernel<8>), dim3(nb1 + nb2), dim3(256), 0, s, p1, e1, nb1, p2, e2, slices,
+                               (bf16*)att, ld_att, scale);
+        else
+            hipLaunchKernelGGL((mid_reduce_qkv_attn_gelu_kernel<12>), dim3(nb1 + nb2), dim3(256), 0, s, p1, e1, nb1, p2, e2, slices,
+                               (bf16*)att, ld_att, scale);
+        BT_LAUNCH_CHECK("mid-batch QKV + attention + GELU reduce launch");
+        *attn_done = true;
+        return BT_OK;
+    }
     ProfScope ps(BT_PROF_ROPE, s);
-    const int nb1 = (int)ceil_div(M * (N1 / 8), 256), nb2 = (int)ceil_div(M * (N2 / 8), 256);
+    const int nb1 = (int)ceil_div(M * (N1 / 8), 256);
     hipLaunchKernelGGL(mid_reduce_qkv_gelu_kernel, dim3(nb1 + nb2), dim3(256), 0, s, p1, e1, nb1, p2, e2, slices);
     BT_LAUNCH_CHECK("mid-batch QKV + GELU reduce launch");
     return BT_OK;
@@ -4510,5 +4679,6 @@ extern "C" void bt_debug_few_dual(int on) { g_few_dual = on != 0; }
 extern "C" void bt_debug_few_attn(int on) { g_few_attn = on != 0; }
 extern "C" void bt_debug_mid_fuse(int mode) { g_mid_fuse = mode; }
 extern "C" void bt_debug_mid_dual(int on) { g_mid_dual = on != 0; }
+extern "C" void bt_debug_mid_attn(int on) { g_mid_attn = on != 0; }
 extern "C" void bt_debug_no_qkv_fusion(int on) { g_no_qkv_fusion = on != 0; }
 #endif

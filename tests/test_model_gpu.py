@@ -1665,45 +1665,56 @@ def test_few_rows_fused_attention_is_bit_identical(B, L, dbg_lib):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("B", [24, 64, 128, 256])
-def test_mid_batch_dual_gemm_matches_separate_launches(B, dbg_lib):
-    """Round 4: 17..256 rows: the layer's QKV projection and MLP up-projection as ONE split-K launch (gemm_bf16_mfma_dual_kernel) and
-    their reductions as one (mid_reduce_qkv_gelu_kernel; none at all when one K slice fills the chip, B = 256) against the two
-    launches each of round 2 (bt_debug_mid_dual(0)).  The K slicing may differ (224 instead of 96 / 128 tiles per row block), so
-    equality is up to fp32 summation order: first tokens equal except rare bf16 near-ties; both against the fp32 oracle,
-    margin-aware; graphs on == off for the dual path, bit for bit."""
+@pytest.mark.parametrize("B,L", [(24, 4), (64, 4), (128, 4), (256, 4), (32, 8)])
+def test_mid_batch_dual_gemm_matches_separate_launches(B, L, dbg_lib):
+    """Round 4: 17..64 rows: the layer's QKV projection and MLP up-projection as ONE split-K launch (gemm_bf16_mfma_dual_kernel), their
+    reductions as one launch, and -- token decoder -- the local-window attention inside that reduce launch
+    (mid_reduce_qkv_attn_gelu_kernel: 4 launches per layer), against (a) the same without the attention fold and (b) the two
+    launches each of round 2 (bt_debug_mid_dual(0)).  The K slicing may differ (224 instead of 96 / 128 tiles per row block) and the
+    folded softmax runs sequentially instead of over four lane groups, so equality is up to fp32 summation order: first tokens
+    equal except rare bf16 near-ties; every variant against the fp32 oracle, margin-aware; graphs on == off for the production
+    path, bit for bit.  B = 128 / 256: one K slice fills the chip, the separate fused-epilogue launches stay (all variants equal).
+    L = 8: windows of up to 9 keys (KMAX = 12 instantiation)."""
     import dataclasses
-    base = named_dims("block_main_b4_1.2b")
-    dims = dataclasses.replace(base, name="b4_1.2b_2layer", bd=dataclasses.replace(base.bd, layers=2),
+    base = named_dims("block_main_b4_1.2b" if L == 4 else "block_main_b8_1.2b")
+    dims = dataclasses.replace(base, name=f"b{L}_1.2b_2layer", bd=dataclasses.replace(base.bd, layers=2),
                                td=dataclasses.replace(base.td, layers=2))
     sd = random_state_dict(dims, seed=5, include_unused_embed_in=False)
     model = load_block_transformer_from_dims(dims, "fp32", keep_unused_embed_in=False)
     model.load_state_dict(sd, strict=True)
     model = model.bfloat16().to(DEV)
     model.token_decoder.generation_config.eos_token_id = None
-    prompt = torch.randint(0, dims.vocab, (B, 32), generator=torch.Generator().manual_seed(B)).to(DEV)
+    P = 8 * L
+    prompt = torch.randint(0, dims.vocab, (B, P), generator=torch.Generator().manual_seed(B)).to(DEV)
+    outs = {}
     try:
+        for name, dual, attn in (("dual+attn", 1, 1), ("dual", 1, 0), ("separate", 0, 0)):
+            dbg_lib.bt_debug_mid_dual(dual)
+            dbg_lib.bt_debug_mid_attn(attn)
+            model._engine = None
+            outs[name] = model.generate(prompt, max_length=P + 4 * L).cpu()
         dbg_lib.bt_debug_mid_dual(1)
-        dual = model.generate(prompt, max_length=48).cpu()
+        dbg_lib.bt_debug_mid_attn(1)
         model._engine = None
         model.use_graphs = False
-        dual_eager = model.generate(prompt, max_length=48).cpu()
-        model.use_graphs = True
-        dbg_lib.bt_debug_mid_dual(0)
-        model._engine = None
-        sep = model.generate(prompt, max_length=48).cpu()
+        eager = model.generate(prompt, max_length=P + 4 * L).cpu()
     finally:
         dbg_lib.bt_debug_mid_dual(1)
+        dbg_lib.bt_debug_mid_attn(1)
         model.use_graphs = True
         model._engine = None
-    assert torch.equal(dual, dual_eager)
-    assert torch.equal(dual[:, :32], prompt.cpu())
-    assert (dual[:, 32] == sep[:, 32]).float().mean() >= 0.9, (dual[:, 32] == sep[:, 32]).float().mean()
+    assert torch.equal(outs["dual+attn"], eager)
+    assert torch.equal(outs["dual+attn"][:, :P], prompt.cpu())
+    if B > 64:
+        assert torch.equal(outs["dual+attn"], outs["separate"]) and torch.equal(outs["dual"], outs["separate"])
+    for name in ("dual+attn", "dual"):
+        agree = (outs[name][:, P] == outs["separate"][:, P]).float().mean()
+        assert agree >= 0.9, (name, agree)
     sd16 = {k: v.bfloat16().float() for k, v in sd.items()}
     o = oracle_from_dims(dims, sd16)
     rows = torch.linspace(0, B - 1, 8).long()
-    for name, out in (("dual", dual), ("separate", sep)):
-        _, ref_lg = oracle_block_logits(o, prompt.cpu()[rows], out[rows, 32:36])
-        assert_tokens_within_noise(ref_lg, out[rows, 32:36], 3e-2, 1e-2, f"mid-batch dual GEMM B={B} {name}")
+    for name, out in outs.items():
+        _, ref_lg = oracle_block_logits(o, prompt.cpu()[rows], out[rows, P:P + L])
+        assert_tokens_within_noise(ref_lg, out[rows, P:P + L], 3e-2, 1e-2, f"mid-batch B={B} L={L} {name}")
     del model
     torch.cuda.empty_cache()

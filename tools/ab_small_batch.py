@@ -2,6 +2,7 @@
 """Same-box, same-process A/B of the small- / mid-batch launch structures through the debug library (round 4):
     few_attn  : <= 2 rows, token decoder: local attention inside the residual-stream GEMV (1) vs its own launch (0)
     mid_dual  : 17..64 rows: QKV + h->4h split-K GEMMs in one launch and one reduce (1) vs two each (0)
+    mid_attn  : 17..64 rows, token decoder: local attention inside that reduce launch (1) vs its own launch (0)
 Prints one JSON line per (batch, knob setting): end-to-end tokens/s of generate(prefill 2048 / decode 128), best of --reps.
 
     python tools/ab_small_batch.py --knob few_attn --batches 1,2 [--reps 3]
@@ -23,7 +24,7 @@ from block_transformer_amd.model.utils import load_block_transformer_from_dims  
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--knob", choices=["few_attn", "mid_dual"], required=True)
+    ap.add_argument("--knob", choices=["few_attn", "mid_dual", "mid_attn"], required=True)
     ap.add_argument("--batches", default="1,2")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--prefill", type=int, default=2048)
@@ -31,7 +32,7 @@ def main():
     args = ap.parse_args()
     _lib.use_debug_library(True)
     hooks = _lib.lib()
-    setter = {"few_attn": hooks.bt_debug_few_attn, "mid_dual": hooks.bt_debug_mid_dual}[args.knob]
+    setter = {"few_attn": hooks.bt_debug_few_attn, "mid_dual": hooks.bt_debug_mid_dual, "mid_attn": hooks.bt_debug_mid_attn}[args.knob]
     dims = named_dims("block_main_b4_1.2b")
     torch.manual_seed(1234)
     with torch.device("cuda"):
