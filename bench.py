@@ -68,7 +68,7 @@ def algorithmic_counts(dims, B: int, P: int, D: int, itemsize: int = 2):
         per_row_rest = d.hidden * d.hidden + 2 * d.hidden * d.inter
         return stack_flops(d, rows) - 2 * (rows - seqs) * per_row_rest
 
-    few_rows = B * E <= 16                                          # small-batch fused path runs every layer on every row
+    few_rows = B * E <= 256                                         # the small- / mid-batch paths (<= 256 rows) run every layer on every row
     lin = stack_flops(bd, B * nb)                                   # prefill
     lin_exec = stack_flops_tail(bd, B * nb, B) if nb > 1 else lin
     lin += n_roll * stack_flops(bd, B)                              # block-decoder steps

@@ -13,11 +13,15 @@
 
 using namespace bt;
 
-// rows up to which a stack takes the fused single-launch projections (the entry points accept <= 64; beyond ~16 rows
-// split-K + reduce is faster).  Compile-time constants in the product library; the debug build (-DBT_DEBUG_HOOKS,
-// libbt_hip_dbg.so: tests and A/B probes only) can flip them at run time.
+// rows up to which a stack takes the fused single-launch weight-streaming projections (GEMV for <= 4 rows, MFMA streamer for
+// <= 64).  Round 4: 2 -- once the slab path lost three of its seven launches per layer (dual GEMM, merged reduce, folded local
+// attention) it beats the streamer launches from 3 rows up (same box, interleaved, profiles/r4_ab_few_max4.jsonl +
+// r4_ab_few_cutoffs.jsonl: B = 3 3.47k -> 4.28k, B = 4 4.78k -> 5.2-5.7k, B = 5 4.94k -> 6.99k, B = 8 7.54k -> 10.9k,
+// B = 16 14.1k -> 20.3k tok/s); 1- and 2-row steps stay on the GEMVs (B = 1: 1.72k vs 1.34k on the slab path).  Compile-time
+// constants in the product library; the debug build (-DBT_DEBUG_HOOKS, libbt_hip_dbg.so: tests and A/B probes only) can flip
+// them at run time.
 #ifdef BT_DEBUG_HOOKS
-static int g_few_rows_max = 16;
+static int g_few_rows_max = 2;
 extern "C" void bt_debug_few_rows_max(int n) { g_few_rows_max = n; }
 static bool g_no_few_rows_fusion = false;   // run 1..16-row stacks through the unfused launch sequence (A/B, parity)
 extern "C" void bt_debug_no_few_rows_fusion(int on) { g_no_few_rows_fusion = on != 0; }
@@ -28,7 +32,7 @@ extern "C" void bt_debug_no_few_rows_fusion(int on) { g_no_few_rows_fusion = on 
 static bool g_lin2_large = false;
 extern "C" void bt_debug_lin2_large(int on) { g_lin2_large = on != 0; }
 #else
-static constexpr int g_few_rows_max = 16;
+static constexpr int g_few_rows_max = 2;
 static constexpr bool g_no_few_rows_fusion = false;
 static constexpr bool g_lin2_large = false;
 #endif
@@ -95,8 +99,8 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
     const bool few_rows = dtype == BT_BF16 && M <= g_few_rows_max && (M > 4 ? (H % 32 == 0 && I % 32 == 0) : (H % 512 == 0 && H <= 2048)) &&
                           dims->rot == 32 &&
                           dims->head_dim % 32 == 0 && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) && !g_no_few_rows_fusion;
-    // 17 .. 256 rows (mid-batch decode): split-K slabs + fused reduce kernels -- 7 launches per layer instead of 11, no
-    // separate LayerNorm / RoPE / KV-append launch (the step is bound by its count of dependent launches).  Like the few-rows
+    // 3 .. 256 rows (small- / mid-batch decode): split-K slabs + fused reduce kernels -- 4 (token decoder) or 5 launches per layer
+    // instead of 11, no separate LayerNorm / RoPE / KV-append launch (the step is bound by its count of dependent launches).  Like the few-rows
     // path it runs every layer on every row (the tail-only shortcut is not worth a second launch sequence here).
     const bool mid_rows = dtype == BT_BF16 && !few_rows && mid_rows_ok(M, H, I, dims->head_dim, dims->rot) && scratch &&
                           mid_slab_bytes(M, H, I) >= 0 && mid_slab_bytes(M, H, I) + MID_COUNTER_BYTES <= sk_bytes &&

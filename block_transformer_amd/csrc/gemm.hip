@@ -781,6 +781,9 @@ __device__ __forceinline__ void mid_reduce_qkv_attn_body(const int item, const f
         const int rr = r < pos0 ? r : (pos0 > 0 ? pos0 - 1 : 0);
         kq[r] = *reinterpret_cast<const uint4*>(kbase + (int64_t)rr * D);
         vq[r] = *reinterpret_cast<const uint4*>(vbase + (int64_t)rr * D);
+        // rows this call has not reached yet get weight exactly 0 below -- but 0 x (never-written memory, possibly NaN / Inf) is not
+        // 0: they must not enter the sums as data (at pos0 = 0 the clamped row is the one this very wave is about to write)
+        if (r >= pos0) kq[r] = vq[r] = uint4{0, 0, 0, 0};
     }
     float knew[2][8], vnew[2][8];                               // this call's rows, as seen by lanes 0-15 (bf16-rounded)
 #pragma unroll
@@ -4435,7 +4438,8 @@ static int mid_slice_len(int64_t tiles, int64_t K1, int64_t K2) {
 }
 
 bool mid_rows_ok(int64_t M, int64_t H, int64_t I, int head_dim, int rot) {
-    return M >= 17 && M <= 256 && rot == 32 && head_dim % 32 == 0 && H % 256 == 0 && I % 256 == 0 && H <= 8192 &&
+    // (bt_decoder_forward sends stacks of <= g_few_rows_max rows to the weight-streaming GEMV / MFMA-streamer launches first)
+    return M >= 1 && M <= 256 && rot == 32 && head_dim % 32 == 0 && H % 256 == 0 && I % 256 == 0 && H <= 8192 &&
            !g_force_generic && g_gemm_variant == 0 && g_mid_rows;
 }
 

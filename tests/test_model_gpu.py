@@ -1476,9 +1476,9 @@ def test_decoder_forward_rejects_cache_overflow_before_any_launch(B, q_len):
     assert rc == 0, lib().bt_last_error()
 
 
-@pytest.mark.parametrize("M", [17, 32, 64, 128, 256])
+@pytest.mark.parametrize("M", [3, 4, 6, 8, 16, 17, 32, 64, 128, 256])
 def test_mid_rows_decoder_stack_vs_fp32_oracle(M, dbg_lib):
-    """17 .. 256 rows through bt_decoder_forward: the split-K slab GEMMs + fused reduces (bias + RoPE + KV append; bias +
+    """3 .. 256 rows through bt_decoder_forward (round 4: the slab path starts at 3 rows): the split-K slab GEMMs + fused reduces (bias + RoPE + KV append; bias +
     GELU; both residual projections + residual + next-layer LayerNorm pair).  A decode step (q = 1 against a 40-row cache
     built by a prefill) and a q = 2 call, hidden states and the appended K/V rows against the fp32 oracle on the same
     bf16-rounded weights and inputs (bf16 tolerance), and against the unfused launch sequence (bt_debug_mid_rows(0))."""
@@ -1716,5 +1716,41 @@ def test_mid_batch_dual_gemm_matches_separate_launches(B, L, dbg_lib):
     for name, out in outs.items():
         _, ref_lg = oracle_block_logits(o, prompt.cpu()[rows], out[rows, P:P + L])
         assert_tokens_within_noise(ref_lg, out[rows, P:P + L], 3e-2, 1e-2, f"mid-batch B={B} L={L} {name}")
+    del model
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("B", [1, 2, 5, 24, 64, 300])
+def test_unwritten_cache_rows_never_enter_the_attention(B):
+    """Round 4 (found by test_greedy_tokens_do_not_depend_on_keeping_logits on the folded mid-batch attention): a masked or not yet
+    written cache row gets softmax weight exactly 0, but 0 x NaN is NaN -- every attention path must keep such rows out of its sums
+    as DATA, not only as weights.  The engine's global and local KV caches are poisoned with NaN between two generate() calls of
+    the same prompt (prefill and decode rewrite exactly the rows they own): identical tokens, all batch-size paths (GEMV + local
+    kernel, slab path with the folded attention, large M with flash prefill), graphs on and off."""
+    import dataclasses
+    base = named_dims("block_main_b4_1.2b")
+    dims = dataclasses.replace(base, name="b4_1.2b_2layer", bd=dataclasses.replace(base.bd, layers=2),
+                               td=dataclasses.replace(base.td, layers=2))
+    sd = random_state_dict(dims, seed=6, include_unused_embed_in=False)
+    model = load_block_transformer_from_dims(dims, "fp32", keep_unused_embed_in=False)
+    model.load_state_dict(sd, strict=True)
+    model = model.bfloat16().to(DEV)
+    model.token_decoder.generation_config.eos_token_id = None
+    prompt = torch.randint(0, dims.vocab, (B, 30), generator=torch.Generator().manual_seed(B)).to(DEV)   # P % L != 0: left-padded block
+    try:
+        for graphs in (True, False):
+            model.use_graphs = graphs
+            model._engine = None
+            want = model.generate(prompt, max_length=50).cpu()
+            eng = model._engine
+            with torch.inference_mode():
+                for t_ in (eng.glob.k, eng.glob.v, eng.tok.local.k, eng.tok.local.v):
+                    t_.fill_(float("nan"))
+            got = model.generate(prompt, max_length=50).cpu()
+            assert torch.equal(got, want), (graphs, (got != want).nonzero()[:4])
+            assert int(got.min()) >= 0 and int(got.max()) < dims.vocab
+    finally:
+        model.use_graphs = True
+        model._engine = None
     del model
     torch.cuda.empty_cache()
