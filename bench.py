@@ -331,6 +331,9 @@ def main():
                     help="two half-batch shards on two streams (global-attention / GEMM overlap, measured not to pay: DESIGN.md "
                          "section 3); auto = off unless BT_PIPELINE=1")
     ap.add_argument("--cpu-sample", default="128,128", help="prefill,decode of the CPU baseline sample")
+    ap.add_argument("--two-branch", choices=["auto", "on", "off"], default="auto",
+                    help="large stacks: mlp.dense_h_to_4h on a second stream beside QKV / attention / dense (parallel residual); "
+                         "auto = the engine's default")
     ap.add_argument("--keep-logits", action="store_true",
                     help="materialise the [B, vocab] logits of every greedy step (A/B: the default feeds the argmax from the logits "
                          "GEMM's epilogue and never writes them, like HF generate with output_scores=False)")
@@ -368,6 +371,8 @@ def main():
     model.use_graphs = not args.no_graphs
     model.pipeline = {"auto": None, "on": True, "off": False}[args.pipeline]
     model.keep_logits = bool(args.keep_logits)
+    if args.two_branch != "auto":
+        model.two_branch = args.two_branch == "on"
     gen = torch.Generator().manual_seed(args.seed + 1000 * rank)
     input_ids = torch.randint(0, dims.vocab, (B, P), generator=gen).to(device)
 
@@ -407,7 +412,8 @@ def main():
                    "batch_sizing": "fixed (--batch)" if args.batch > 0 else "auto: free HBM / bytes per sequence, cap 4096",
                    "parallelism": f"dp{world} request shards", "hipgraph": model.use_graphs,
                    "half_batch_pipeline": bool(model._engine is not None and model._engine.pipelined),
-                   "logits_materialised": bool(model.keep_logits)},
+                   "logits_materialised": bool(model.keep_logits),
+                   "two_branch": bool(model._engine is not None and getattr(model._engine, "aux", None) is not None)},
     }
 
     parity_failed = False

@@ -56,14 +56,15 @@ class bt_engine_desc(Structure):
                 ("n_split", c_int32), ("top_k", c_int32), ("split_ws", c_void_p), ("split_ws_bytes", c_int64),
                 ("temperature", c_float), ("skip_logits", c_int32), ("sample_row0", c_int64), ("seed", c_uint64), ("sample_step", c_void_p),
                 ("config_pad", c_int64), ("gen_eos", c_int64), ("gen_pad", c_int64),
-                ("row_map", c_void_p), ("err_flag", c_void_p)]
+                ("row_map", c_void_p), ("aux_stream", c_void_p), ("ev_fork", c_void_p), ("ev_join", c_void_p), ("err_flag", c_void_p)]
 
 
 class bt_attn_args(Structure):
     _fields_ = [("k_cache", c_void_p), ("v_cache", c_void_p), ("layer_stride", c_int64), ("n_max", c_int64),
                 ("pos0_dev", c_void_p), ("pos0_host", c_int32), ("pos_table", c_void_p), ("mask", c_void_p),
                 ("mask_ld", c_int64), ("cos_tab", c_void_p), ("sin_tab", c_void_p), ("mode", c_int32),
-                ("n_split", c_int32), ("split_ws", c_void_p), ("split_ws_bytes", c_int64), ("seq_skip", c_void_p)]
+                ("n_split", c_int32), ("split_ws", c_void_p), ("split_ws_bytes", c_int64), ("seq_skip", c_void_p),
+                ("aux_stream", c_void_p), ("ev_fork", c_void_p), ("ev_join", c_void_p)]
 
 
 _SIGS = {
@@ -146,6 +147,7 @@ _DEBUG_SIGS = {
     "bt_debug_few_rows_max": (None, [c_int]),
     "bt_debug_no_few_rows_fusion": (None, [c_int]),
     "bt_debug_lin2_large": (None, [c_int]),
+    "bt_debug_no_two_branch": (None, [c_int]),
     "bt_debug_ln_streaming": (None, [c_int]),
     "bt_debug_tr_probe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
 }

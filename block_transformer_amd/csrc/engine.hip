@@ -31,10 +31,13 @@ extern "C" void bt_debug_no_few_rows_fusion(int on) { g_no_few_rows_fusion = on 
 // 117.9k -> 115.9k tok/s -> off; the debug build can turn it on for the A/B test.
 static bool g_lin2_large = false;
 extern "C" void bt_debug_lin2_large(int on) { g_lin2_large = on != 0; }
+static bool g_no_two_branch = false;   // A/B: ignore bt_attn_args.aux_stream (run the parallel-residual branch on the main stream)
+extern "C" void bt_debug_no_two_branch(int on) { g_no_two_branch = on != 0; }
 #else
 static constexpr int g_few_rows_max = 2;
 static constexpr bool g_no_few_rows_fusion = false;
 static constexpr bool g_lin2_large = false;
+static constexpr bool g_no_two_branch = false;
 #endif
 
 static int64_t ws_elems(const bt_decoder_dims* d, int64_t M) {
@@ -206,6 +209,20 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
             BT_TRY(bt_layernorm(dtype, B, H, xl, (int64_t)q_len * H, lw.ln2_w, lw.ln2_b, ln2, H, nullptr, nullptr, nullptr,
                                 0, dims->ln_eps, stream));
         }
+        // parallel residual: mlp.dense_h_to_4h reads LN2 of the layer input and does not depend on the attention -> with a second
+        // stream it is forked off here and joined in front of dense_4h_to_h; it then fills the CUs the QKV projection's last partial
+        // round of tiles, the attention kernel and the 256-tile dense projection leave idle (same arithmetic, same order of the
+        // residual updates: bit-identical results).  Only for large bf16 stacks (> 256 rows: the GEMMs fill the chip on their own).
+        const bool two_branch = !last && dtype == BT_BF16 && M > 256 && attn->aux_stream && attn->ev_fork && attn->ev_join &&
+                                !g_lin2_large && !g_no_two_branch;
+        if (two_branch) {
+            hipError_t fe = hipEventRecord((hipEvent_t)attn->ev_fork, (hipStream_t)stream);
+            if (fe == hipSuccess) fe = hipStreamWaitEvent((hipStream_t)attn->aux_stream, (hipEvent_t)attn->ev_fork, 0);
+            if (fe != hipSuccess) return bt::hip_fail(fe, "fork onto the second stream");
+            BT_TRY(bt_linear_ws(dtype, M, I, H, ln2, H, lw.h4_w, lw.h4_b, nullptr, 0, h4, I, BT_ACT_GELU, nullptr, 0, attn->aux_stream));
+            fe = hipEventRecord((hipEvent_t)attn->ev_join, (hipStream_t)attn->aux_stream);
+            if (fe != hipSuccess) return bt::hip_fail(fe, "hipEventRecord(join)");
+        }
         BT_TRY(bt_qkv_rope_append(dtype, B, q_len, dims->heads, dims->head_dim, dims->rot, ln1, H, lw.qkv_w, lw.qkv_b, qkv,
                                   3 * H, kc, vc, attn->n_max, attn->pos0_dev, attn->pos0_host, attn->pos_table,
                                   attn->cos_tab, attn->sin_tab, scratch, sk_bytes, stream));
@@ -222,7 +239,12 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
                 BT_TRY(bt_linear2(dtype, M, H, I, h4, I, lw.h_w, lw.h_b, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, stream));
             } else {
                 BT_TRY(bt_linear_ws(dtype, M, H, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, BT_ACT_NONE, scratch, sk_bytes, stream));
-                BT_TRY(bt_linear_ws(dtype, M, I, H, ln2, H, lw.h4_w, lw.h4_b, nullptr, 0, h4, I, BT_ACT_GELU, scratch, sk_bytes, stream));
+                if (two_branch) {   // the up-projection ran on the second stream beside QKV / attention / dense: join
+                    hipError_t je = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)attn->ev_join, 0);
+                    if (je != hipSuccess) return bt::hip_fail(je, "hipStreamWaitEvent(join)");
+                } else {
+                    BT_TRY(bt_linear_ws(dtype, M, I, H, ln2, H, lw.h4_w, lw.h4_b, nullptr, 0, h4, I, BT_ACT_GELU, scratch, sk_bytes, stream));
+                }
                 BT_TRY(bt_linear_ws(dtype, M, H, I, h4, I, lw.h_w, lw.h_b, x, H, x, H, BT_ACT_NONE, scratch, sk_bytes, stream));
             }
         } else {
@@ -311,6 +333,9 @@ static bt_attn_args local_attn(const bt_engine_desc* e, int32_t pos0) {
     a.n_split = 1;
     a.split_ws = nullptr;
     a.split_ws_bytes = 0;
+    a.aux_stream = e->aux_stream;
+    a.ev_fork = e->ev_fork;
+    a.ev_join = e->ev_join;
     return a;
 }
 
@@ -384,6 +409,9 @@ extern "C" int bt_roll_over_enqueue(const bt_engine_desc* e, bt_stream stream) {
     a.split_ws_bytes = e->split_ws_bytes;
     // with EOS handling on, finished sequences skip the KV stream of the global step (their context is never decoded)
     a.seq_skip = (e->gen_eos >= 0 && e->finished) ? e->finished : nullptr;
+    a.aux_stream = e->aux_stream;
+    a.ev_fork = e->ev_fork;
+    a.ev_join = e->ev_join;
     BT_TRY(bt_decoder_forward(e->dtype, &e->bd_dims, &e->bd_w, B, 1, e->x_blk, &a, 0, e->ctx, e->ws_step, e->ws_step_bytes,
                               stream));
     return bt_bump(e->n_cur, 1, stream);
@@ -424,6 +452,9 @@ extern "C" int bt_prefill_enqueue(const bt_engine_desc* e, const int64_t* block_
     a.n_split = 1;
     a.split_ws = e->split_ws;
     a.split_ws_bytes = e->split_ws ? e->split_ws_bytes : 0;
+    a.aux_stream = e->aux_stream;
+    a.ev_fork = e->ev_fork;
+    a.ev_join = e->ev_join;
     return bt_decoder_forward(e->dtype, &e->bd_dims, &e->bd_w, nseq, nb, x, &a, nb - 1,
                               reinterpret_cast<char*>(e->ctx) + b0 * Hbd * es, ws, ws_bytes, stream);
 }

@@ -224,6 +224,16 @@ class DecodeEngine:
         self._children = {}       # compacted views by batch size (state buffers and graphs are reused across generate() calls)
         self.row_map: Optional[torch.Tensor] = None     # identity
         self.err_flag = torch.zeros(1, dtype=torch.int32, device=dev)   # sticky device-side guard bits (BT_DEV_ERR_*)
+        # second stream + fork / join events for the parallel-residual branch of large stacks (bt_attn_args.aux_stream); opt-in
+        # until measured positive: model.two_branch = True / BT_TWO_BRANCH=1
+        self.aux = None
+        want2 = getattr(model, "two_branch", None)
+        if want2 if want2 is not None else os.environ.get("BT_TWO_BRANCH") == "1":
+            aux = torch.cuda.Stream(device=dev)
+            evs = [torch.cuda.Event(), torch.cuda.Event()]
+            for ev in evs:
+                ev.record(aux)             # torch creates the hipEvent lazily, on the first record
+            self.aux = (aux, evs[0], evs[1])
         self.rope_policy = rope_policy
         self.tok = TokenBlockState(td, batch, dev, rope_policy)
         self.rope = ops.rope_tables(self.n_max, self.bd_rt.dims.rot,
@@ -278,6 +288,7 @@ class DecodeEngine:
         self.finished_prev = torch.zeros(batch, dtype=torch.int32, device=dev)
         self.row_map = torch.full((batch,), -1, dtype=torch.int64, device=dev)
         self.err_flag = root.err_flag
+        self.aux = root.aux
         self.stream = root.stream
         self.n_cur = torch.zeros(1, dtype=torch.int32, device=dev)
         self.prefill_rows = root.prefill_rows
@@ -332,6 +343,8 @@ class DecodeEngine:
         d.split_ws_bytes = 0 if self.split_ws is None else self.split_ws.numel() * 4
         d.row_map = ptr(self.row_map)
         d.err_flag = self.err_flag.data_ptr()
+        if self.aux is not None:
+            d.aux_stream, d.ev_fork, d.ev_join = self.aux[0].cuda_stream, self.aux[1].cuda_event, self.aux[2].cuda_event
         self._desc_key = key
         self.graphs = {}          # captured graphs bake in the old parameter pointers
 

@@ -225,6 +225,14 @@ typedef struct bt_attn_args {
     const int32_t* seq_skip; /* optional [B]: != 0 marks a finished sequence whose decode-step attention (mode 0, q_len = 1) is
                                 skipped (zeros are written; its tokens are forced to pad anyway) -- the reference compacts such
                                 rows away, model/block_transformer.py:381-398 */
+    /* ---- since 0.2.1: optional second stream for the parallel-residual branch (all three or none) ----
+     * GPT-NeoX's parallel residual makes mlp.dense_h_to_4h independent of the attention (both read LayerNorms of the same layer
+     * input; HF GPTNeoXLayer, use_parallel_residual).  With these set, stacks of > 256 bf16 rows enqueue that GEMM on `aux_stream`
+     * (forked from and joined back into `stream` with the two events, capture-safe: hipEventRecord / hipStreamWaitEvent only), so it
+     * can fill the CUs the QKV projection's last partial round of tiles and the attention kernel leave idle.  NULL = one stream. */
+    bt_stream aux_stream;
+    void* ev_fork;           /* hipEvent_t, created by the caller (hipEventDisableTiming is enough) */
+    void* ev_join;
 } bt_attn_args;
 
 /* x[M,H] (row stride H) -> NL x {LN1|LN2, QKV, RoPE+append, attention, dense(+x), h_to_4h+GELU, 4h_to_h(+)} ->
@@ -309,6 +317,9 @@ typedef struct bt_engine_desc {
     const int64_t* row_map;  /* [B] or NULL (identity): ORIGINAL batch row of engine row b after bt_compact_enqueue -- the row of
                                 out_ids bt_finish_block writes and the RNG stream bt_topk_sample draws from (key = seed, step,
                                 sample_row0 + row_map[b]); < 0 marks a padding row of a compacted engine (nothing is written) */
+    bt_stream aux_stream;    /* optional second stream + two events for the parallel-residual branch of large stacks: handed to */
+    void* ev_fork;           /* bt_decoder_forward through bt_attn_args (see there); all three or none */
+    void* ev_join;
     int32_t* err_flag;       /* device int32 or NULL: sticky error bits set by the device-side guards (BT_DEV_ERR_*); the host reads
                                 it whenever it synchronises anyway.  With it set, bt_roll_over_enqueue clamps *n_cur to g_nmax - 1
                                 before anything is appended (a binder replaying one graph too many overwrites the last cache row

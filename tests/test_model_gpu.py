@@ -13,7 +13,22 @@ pytestmark = pytest.mark.gpu
 from conftest import GOLDEN_CONFIGS, t  # noqa: E402
 from block_transformer_amd.config import named_dims  # noqa: E402
 from block_transformer_amd.model.utils import load_block_transformer_from_dims  # noqa: E402
-from oracle.cpu_ref import oracle_from_dims, random_state_dict  # noqa: E402
+from oracle.cpu_ref import oracle_from_dims  # noqa: E402
+from oracle.cpu_ref import random_state_dict as _random_state_dict  # noqa: E402
+
+_SD_CACHE = {}
+
+
+def random_state_dict(dims, seed=0, **kw):
+    """oracle.cpu_ref.random_state_dict, memoised for the session: ~40 tests draw the same 0.4 G-parameter 2-layer 1.2B-shaped
+    weights (3-4 s of CPU randn each).  Tests only read the tensors (load_state_dict copies, casts make new tensors)."""
+    key = (repr(dims), seed, tuple(sorted(kw.items())))
+    if key not in _SD_CACHE:
+        if len(_SD_CACHE) >= 6:
+            _SD_CACHE.pop(next(iter(_SD_CACHE)))
+        _SD_CACHE[key] = _random_state_dict(dims, seed=seed, **kw)
+    return _SD_CACHE[key]
+
 
 DEV = "cuda"
 TOL = 1e-3          # north_star: logits within 1e-3 fp32
@@ -1626,8 +1641,7 @@ def test_few_rows_dual_launch_is_bit_identical(B, dbg_lib):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("L", [4, 8])
-@pytest.mark.parametrize("B", [1, 2, 4])
+@pytest.mark.parametrize("B,L", [(1, 4), (2, 8)])
 def test_few_rows_fused_attention_is_bit_identical(B, L, dbg_lib):
     """Round 4: <= 4 rows, token decoder: the local-window attention is computed INSIDE the residual-stream GEMV (gemv_attn_res_kernel:
     every workgroup recomputes the <= 12-key window of all heads with local_attend_kernel's lane mapping and arithmetic), so the
@@ -1665,7 +1679,7 @@ def test_few_rows_fused_attention_is_bit_identical(B, L, dbg_lib):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("B,L", [(24, 4), (64, 4), (128, 4), (256, 4), (32, 8)])
+@pytest.mark.parametrize("B,L", [(24, 4), (64, 4), (256, 4), (32, 8)])
 def test_mid_batch_dual_gemm_matches_separate_launches(B, L, dbg_lib):
     """Round 4: 17..64 rows: the layer's QKV projection and MLP up-projection as ONE split-K launch (gemm_bf16_mfma_dual_kernel), their
     reductions as one launch, and -- token decoder -- the local-window attention inside that reduce launch
@@ -1720,7 +1734,7 @@ def test_mid_batch_dual_gemm_matches_separate_launches(B, L, dbg_lib):
     torch.cuda.empty_cache()
 
 
-@pytest.mark.parametrize("B", [1, 2, 5, 24, 64, 300])
+@pytest.mark.parametrize("B", [1, 5, 64, 300])
 def test_unwritten_cache_rows_never_enter_the_attention(B):
     """Round 4 (found by test_greedy_tokens_do_not_depend_on_keeping_logits on the folded mid-batch attention): a masked or not yet
     written cache row gets softmax weight exactly 0, but 0 x NaN is NaN -- every attention path must keep such rows out of its sums
@@ -1752,5 +1766,40 @@ def test_unwritten_cache_rows_never_enter_the_attention(B):
     finally:
         model.use_graphs = True
         model._engine = None
+    del model
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("B", [300])
+def test_two_branch_parallel_residual_is_bit_identical(B):
+    """Round 4: with a second stream (bt_attn_args.aux_stream; model.two_branch = True) stacks of > 256 bf16 rows run
+    mlp.dense_h_to_4h beside QKV -> attention -> attention.dense (GPT-NeoX parallel residual: it only reads LN2 of the layer input)
+    and join in front of dense_4h_to_h.  Same kernels, same arithmetic, same order of the residual updates: tokens and the last
+    context embedding are bit-identical to the one-stream schedule, captured as a forked hipGraph and launched eagerly."""
+    import dataclasses
+    base = named_dims("block_main_b4_1.2b")
+    dims = dataclasses.replace(base, name="b4_1.2b_2layer", bd=dataclasses.replace(base.bd, layers=2),
+                               td=dataclasses.replace(base.td, layers=2))
+    sd = random_state_dict(dims, seed=7, include_unused_embed_in=False)
+    model = load_block_transformer_from_dims(dims, "fp32", keep_unused_embed_in=False)
+    model.load_state_dict(sd, strict=True)
+    model = model.bfloat16().to(DEV)
+    model.token_decoder.generation_config.eos_token_id = None
+    prompt = torch.randint(0, dims.vocab, (B, 64), generator=torch.Generator().manual_seed(B)).to(DEV)
+    outs = {}
+    try:
+        for two in (True, False):
+            for graphs in (True, False):
+                model.two_branch, model.use_graphs = two, graphs
+                model._engine = None
+                out = model.generate(prompt, max_length=64 + 12).cpu()
+                assert (model._engine.aux is not None) == two
+                outs[(two, graphs)] = (out, model._engine.ctx.float().cpu().clone())
+    finally:
+        model.two_branch, model.use_graphs = None, True
+        model._engine = None
+    ref_out, ref_ctx = outs[(False, False)]
+    for key, (out, ctx) in outs.items():
+        assert torch.equal(out, ref_out) and torch.equal(ctx, ref_ctx), key
     del model
     torch.cuda.empty_cache()
