@@ -140,6 +140,7 @@ _DEBUG_SIGS = {
     "bt_debug_mid_dual": (None, [c_int]),
     "bt_debug_mid_attn": (None, [c_int]),
     "bt_debug_mid_tile": (None, [c_int]),
+    "bt_debug_mid_force2": (None, [c_int]),
     "bt_debug_no_qkv_fusion": (None, [c_int]),
     "bt_debug_flash_variant": (None, [c_int]),
     "bt_debug_attn_nt": (None, [c_int]),

@@ -3624,6 +3624,7 @@ BT_KNOB bool g_no_qkv_fusion = false;
 // also for several slices -- measured SLOWER (B = 64: 42.7k -> 36.5k tok/s): every slice pays an agent-scope release fence over
 // its freshly dirtied 16 KiB slab (guide: ~6.5 us) on a ~10 us GEMM; kept for A/B only
 BT_KNOB int g_mid_fuse = 1;
+BT_KNOB bool g_mid_force2 = true;    // two K slices for the dual launch also where one fills the chip (65..224 rows); false: A/B
 BT_KNOB int g_mid_tile = 0;       // fused one-slice QKV / h->4h GEMMs at >= 128 rows: 0 = 64 x 64 tiles, 1 = 128 x 64, 2 = 128 x 128 (A/B)
 BT_KNOB bool g_mid_attn = true;   // ... and the token decoder's local-window attention inside that reduce launch (false: A/B)
 BT_KNOB bool g_mid_dual = true;   // 17..256 rows: QKV and h->4h split-K GEMMs of a layer in one launch, their reductions in one (false: A/B)
@@ -4457,7 +4458,7 @@ int64_t mid_slab_bytes(int64_t M, int64_t H, int64_t I) {
     }
     {   // the dual QKV + h->4h launch keeps both problems' slabs at once
         const int ks = mid_slice_len(tm * (ceil_div(3 * H, 64) + ceil_div(I, 64)), H, 0);
-        if (ks > 0) worst = std::max(worst, (H / ks) * M * (3 * H + I) * 4);
+        if (ks > 0) worst = std::max(worst, std::max<int64_t>(H / ks, 2) * M * (3 * H + I) * 4);   // (two slices are forced up to 224 rows)
     }
     return worst;
 }
@@ -4563,10 +4564,16 @@ int mid_qkv_gelu(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, c
     const int tiles_m = (int)ceil_div(M, 64), t1 = (int)(N1 / 64), t2 = (int)(N2 / 64);
     const int ks = mid_slice_len((int64_t)tiles_m * (t1 + t2), K, 0);
     if (ks <= 0) return BT_OK;
-    const int slices = (int)(K / ks);
-    // one K slice already fills the chip (M >~ 100): the separate launches run their fused epilogues directly (no slabs, no reduce)
-    // and a shared launch only lengthens the critical path -- measured: B = 128 62.2k -> 59.3k, B = 256 78.7k -> 72.3k tok/s with a
-    // fused dual launch (profiles/r4_bench_sm_b*.json) -> the shared launch is for the multi-slice regime (M <= 64 at 1.2B dims)
+    int slices = (int)(K / ks);
+    int ks_use = ks;
+    // one K slice already fills the chip (M >~ 100).  A shared launch with both FUSED epilogues only lengthens the critical path there
+    // (measured: B = 128 62.2k -> 59.3k, B = 256 78.7k -> 72.3k tok/s, profiles/r4_bench_dual_fused_mode_b*.json), but the 4-launch
+    // structure itself still pays up to ~200 rows when the shared launch is cut into TWO K slices (slabs + the merged reduce with the
+    // attention folded in): B = 96 +6.8 %, 128 +5.7 %, 192 +3.1 %, 256 -0.2 % (profiles/r4_ab_mid_force2.jsonl) -> forced up to 224 rows
+    if (slices < 2 && g_mid_force2 && M <= 224 && K % 128 == 0) {
+        slices = 2;
+        ks_use = (int)(K / 2);
+    }
     if (slices < 2 || g_mid_fuse == 0) return BT_OK;
     if ((int64_t)slices * M * (N1 + N2) * 4 > slab_bytes) return BT_OK;
     EpiArgs e1{};
@@ -4604,7 +4611,7 @@ int mid_qkv_gelu(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, c
     {
         ProfScope ps(BT_PROF_LINEAR_MFMA, s);
         // slab mode: plain stores of the fp32 partial tiles (the epilogue arguments only carry M and N)
-        hipLaunchKernelGGL(gemm_bf16_mfma_dual_kernel, dim3(tiles_m * (t1 + t2), slices), dim3(256), 0, s, da, ks, tiles_m, t1, t2);
+        hipLaunchKernelGGL(gemm_bf16_mfma_dual_kernel, dim3(tiles_m * (t1 + t2), slices), dim3(256), 0, s, da, ks_use, tiles_m, t1, t2);
         BT_LAUNCH_CHECK("mid-batch dual GEMM launch");
     }
     *done = true;
@@ -4699,5 +4706,6 @@ extern "C" void bt_debug_mid_fuse(int mode) { g_mid_fuse = mode; }
 extern "C" void bt_debug_mid_dual(int on) { g_mid_dual = on != 0; }
 extern "C" void bt_debug_mid_attn(int on) { g_mid_attn = on != 0; }
 extern "C" void bt_debug_mid_tile(int v) { g_mid_tile = v; }
+extern "C" void bt_debug_mid_force2(int on) { g_mid_force2 = on != 0; }
 extern "C" void bt_debug_no_qkv_fusion(int on) { g_no_qkv_fusion = on != 0; }
 #endif
