@@ -24,7 +24,7 @@ def random_state_dict(dims, seed=0, **kw):
     weights (3-4 s of CPU randn each).  Tests only read the tensors (load_state_dict copies, casts make new tensors)."""
     key = (repr(dims), seed, tuple(sorted(kw.items())))
     if key not in _SD_CACHE:
-        if len(_SD_CACHE) >= 6:
+        if len(_SD_CACHE) >= 10:
             _SD_CACHE.pop(next(iter(_SD_CACHE)))
         _SD_CACHE[key] = _random_state_dict(dims, seed=seed, **kw)
     return _SD_CACHE[key]
@@ -490,6 +490,9 @@ def test_checkpoint_roundtrip_safetensors(gpu_model, tmp_path):
     assert torch.equal(out.cpu(), t(fx, "g9_1_tokens"))
 
 
+_SMOKE_MODELS = {}
+
+
 @pytest.mark.parametrize("name", ["block_main_b4_5", "block_main_b4_19", "block_main_b4_85", "block_main_b4_300",
                                   "block_main_b4_800", "block_main_b4_1.2b", "block_main_b8_1.2b"])
 @pytest.mark.parametrize("B,P,D", [(3, 38, 10), (8, 24, 8), (13, 16, 8), (100, 24, 8), (300, 16, 8)])
@@ -504,11 +507,15 @@ def test_generate_every_reference_config_smoke(name, B, P, D):
     # two layers per decoder keep the random-init 1.2B-class models cheap; widths / heads / head_dim are the real ones
     dims = dataclasses.replace(dims, bd=dataclasses.replace(dims.bd, layers=min(dims.bd.layers, 2)),
                                td=dataclasses.replace(dims.td, layers=min(dims.td.layers, 2)))
-    sd = random_state_dict(dims, seed=11, include_unused_embed_in=True)
-    model = load_block_transformer_from_dims(dims, "fp32")
-    model.load_state_dict(sd, strict=True)
-    model = model.bfloat16().to(DEV)
-    model.token_decoder.generation_config.eos_token_id = None
+    model = _SMOKE_MODELS.get(name)
+    if model is None:       # one bf16 model per architecture for the five (B, P, D) cases (building it is 4 of the 5 seconds)
+        sd = random_state_dict(dims, seed=11, include_unused_embed_in=True)
+        model = load_block_transformer_from_dims(dims, "fp32")
+        model.load_state_dict(sd, strict=True)
+        model = model.bfloat16().to(DEV)
+        model.token_decoder.generation_config.eos_token_id = None
+        _SMOKE_MODELS[name] = model
+    model._engine = None
     prompt = torch.randint(1, dims.vocab, (B, P), generator=torch.Generator().manual_seed(B + P)).to(DEV)
     out = model.generate(prompt, max_length=P + D)
     pad = (-P) % dims.L      # the reference counts max_length on the left-padded sequence and strips the pad afterwards
