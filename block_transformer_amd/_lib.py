@@ -135,6 +135,7 @@ _DEBUG_SIGS = {
     "bt_debug_small_stages": (None, [c_int]),
     "bt_debug_mid_rows": (None, [c_int]),
     "bt_debug_few_dual": (None, [c_int]),
+    "bt_debug_few_persist": (None, [c_int]),
     "bt_debug_few_attn": (None, [c_int]),
     "bt_debug_mid_fuse": (None, [c_int]),
     "bt_debug_mid_dual": (None, [c_int]),

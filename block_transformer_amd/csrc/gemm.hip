@@ -3262,6 +3262,209 @@ __global__ __launch_bounds__(256) void gemv_qkv_h4_kernel(const bf16* __restrict
     else gemv_body<MR, 2, true, false>(blockIdx.x - nq, X, ldx, Wh, K, eph, K, ln2, Seg2{});
 }
 
+// ---- persistent form of the [QKV | h->4h] GEMV launch (round 4) ---------------------------------------------------------------
+// gemv_qkv_h4_kernel starts 1792 workgroups of 32 KiB of weights each (1.2B dims), and every one of them stages x and runs the
+// LayerNorm prologue (an L2 round trip for x, three block reductions, gamma / beta loads: ~3 us) in front of ~1 us of streaming: seven
+// prologues per CU.  Here ~2 workgroups per CU stay resident: x is staged and normalised ONCE per workgroup, then the workgroup walks
+// its row groups with the next group's weight rows in flight (second register buffer) while the current group is multiplied, reduced
+// and written -- no barrier after the prologue, the waves free-run.  Row-for-row the arithmetic of gemv_body<MR, 2, true, QKV>
+// (same piece ownership, same LayerNorm, same dot / butterfly order, same epilogues): bit-identical results
+// (tests/test_model_gpu.py::test_few_rows_persistent_gemv_is_bit_identical).
+template <int MR, bool QKV>
+__device__ __forceinline__ void gemv_ln_persist_body(const int bid0, const int stride, const int n_groups,
+                                                     const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ W, int64_t ldw,
+                                                     const EpiArgs& ep, int K, const LnPro& ln) {
+    constexpr int RW = 2;
+    __shared__ __attribute__((aligned(16))) char xs[MR * GV_KC * 2];
+    __shared__ float red[2][4][MR];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int M = ep.M, N = ep.N;
+    const int kw = K;                                  // K <= GV_KC, multiple of 512: the one chunk is the whole row
+    const bool own = tid < kw / 8;
+    auto rows_of = [&](int bid, int (&rows)[RW]) {
+        if (QKV) {
+            const int p = bid * 4 + wave;
+            rows[0] = (p >> 4) * 32 + (p & 15);
+            rows[1] = rows[0] + 16;
+        } else {
+            const int n_blk = bid * (4 * RW);
+            rows[0] = n_blk + wave;
+            rows[1] = n_blk + wave + 4;
+        }
+    };
+    uint4 wv[2][RW][GV_KC / 512];
+    auto load_w = [&](auto BUF, int bid, bool live) {   // unconditional loads (see gemv_body::load_w)
+        constexpr int buf = decltype(BUF)::value;
+        int rows[RW];
+        rows_of(live ? bid : 0, rows);
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int n = rows[r] < N ? rows[r] : N - 1;
+            const bf16* wp = (live ? W + (int64_t)n * ldw : X) + lane * 8;
+#pragma unroll
+            for (int j = 0; j < GV_KC / 512; ++j) wv[buf][r][j] = load_w16<true>(wp + min(j * 512, kw - 512));
+        }
+    };
+    // ---- prologue: x pieces first, the first group's rows right behind them, LayerNorm in their shadow ----
+    uint4 xv[MR];
+#pragma unroll
+    for (int m = 0; m < MR; ++m) xv[m] = *reinterpret_cast<const uint4*>(X + (int64_t)min(m, M - 1) * ldx + (own ? tid : 0) * 8);
+    load_w(std::integral_constant<int, 0>{}, bid0, bid0 < n_groups);
+    if (own) {
+#pragma unroll
+        for (int m = 0; m < MR; ++m) *reinterpret_cast<uint4*>(xs + (m * GV_KC + tid * 8) * 2) = m < M ? xv[m] : uint4{0, 0, 0, 0};
+    }
+    __syncthreads();
+    {
+        float v[MR][8];
+        float part[MR];
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            part[m] = 0.f;
+            if (own) {
+                load_vec<bf16>(reinterpret_cast<const bf16*>(xs + (m * GV_KC + tid * 8) * 2), v[m]);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) part[m] += v[m][i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) v[m][i] = 0.f;
+            }
+            part[m] = wave_sum(part[m]);
+            if (lane == 0) red[0][wave][m] = part[m];
+        }
+        __syncthreads();
+        float mean[MR];
+#pragma unroll
+        for (int m = 0; m < MR; ++m) {
+            mean[m] = (red[0][0][m] + red[0][1][m] + red[0][2][m] + red[0][3][m]) / (float)kw;
+            float sq = 0.f;
+            if (own) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float d = v[m][i] - mean[m];
+                    sq = fmaf(d, d, sq);
+                }
+            }
+            sq = wave_sum(sq);
+            if (lane == 0) red[1][wave][m] = sq;
+        }
+        __syncthreads();
+        if (own) {
+            float gam[8], bet[8];
+            load_vec<bf16>(ln.w + tid * 8, gam);
+            load_vec<bf16>(ln.b + tid * 8, bet);
+#pragma unroll
+            for (int m = 0; m < MR; ++m) {
+                const float rstd = rsqrtf((red[1][0][m] + red[1][1][m] + red[1][2][m] + red[1][3][m]) / (float)kw + ln.eps);
+                float y[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) y[i] = (v[m][i] - mean[m]) * rstd * gam[i] + bet[i];
+                store_vec<bf16>(reinterpret_cast<bf16*>(xs + (m * GV_KC + tid * 8) * 2), y);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- row groups: xs is read-only from here on, no barrier ----
+    auto group = [&](auto BUF, int bid) {
+        constexpr int buf = decltype(BUF)::value;
+        load_w(std::integral_constant<int, 1 - buf>{}, bid + stride, bid + stride < n_groups);   // next group's rows
+        int rows[RW];
+        rows_of(bid, rows);
+        float acc[RW][MR];
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int m = 0; m < MR; ++m) acc[r][m] = 0.f;
+#pragma unroll
+        for (int j = 0; j < GV_KC / 512; ++j) {
+            if (j * 512 < kw) {
+#pragma unroll
+                for (int m = 0; m < MR; ++m) {
+                    const uint4 xq = *reinterpret_cast<const uint4*>(xs + (m * GV_KC + j * 512 + lane * 8) * 2);
+#pragma unroll
+                    for (int r = 0; r < RW; ++r) acc[r][m] = dot8_bf16(wv[buf][r][j], xq, acc[r][m]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+            for (int m = 0; m < MR; ++m) acc[r][m] = wave_sum(acc[r][m]);
+        if (QKV) {
+            float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+            for (int m = 0; m < MR; ++m)
+                if (lane == m) {
+                    v0 = acc[0][m];
+                    v1 = acc[RW - 1][m];
+                }
+            const int n0 = rows[0], n1 = rows[RW - 1];
+            if (lane < M && n1 < N) {
+                const int m = lane;
+                if (ep.bias) {
+                    v0 += bf16_to_f32(ep.bias[n0].x);
+                    v1 += bf16_to_f32(ep.bias[n1].x);
+                }
+                const int D = ep.q.head_dim;
+                const int head = n0 / (3 * D);
+                const int within = n0 - head * 3 * D;
+                const int part = within / D;
+                const int el = within - part * D;
+                const int64_t b = m / ep.q.q_len;
+                const int t = m - (int)b * ep.q.q_len;
+                const int pos0 = ep.q.pos0_dev ? *ep.q.pos0_dev : ep.q.pos0_host;
+                if (part < 2 && el < 16) {
+                    const int rpos = ep.q.pos_table ? ep.q.pos_table[pos0 + t] : pos0 + t;
+                    const float c = ep.q.cos_tab[(int64_t)rpos * 16 + el], sn = ep.q.sin_tab[(int64_t)rpos * 16 + el];
+                    const float x1 = v0, x2 = v1;
+                    v0 = x1 * c - x2 * sn;
+                    v1 = x2 * c + x1 * sn;
+                }
+                bf16* dst = part == 0 ? ep.out + (int64_t)m * ep.ldo + n0
+                                      : (part == 1 ? ep.q.kc : ep.q.vc) + ((b * ep.q.heads + head) * ep.q.n_max + pos0 + t) * D + el;
+                dst[0].x = f32_to_bf16(v0);
+                dst[16].x = f32_to_bf16(v1);
+            }
+        } else {
+            float mine = 0.f;
+            int my_r = 0, my_m = 0;
+#pragma unroll
+            for (int r = 0; r < RW; ++r)
+#pragma unroll
+                for (int m = 0; m < MR; ++m)
+                    if (lane == r * MR + m) {
+                        mine = acc[r][m];
+                        my_r = r;
+                        my_m = m;
+                    }
+            if (lane < RW * MR) {
+                const int n = my_r == 0 ? rows[0] : rows[1];
+                if (my_m < M && n < N) {
+                    float v = mine;
+                    if (ep.bias) v += bf16_to_f32(ep.bias[n].x);
+                    if (ep.act == BT_ACT_GELU) v = gelu_tail2(v2f{v, v}).x;
+                    if (ep.res) v += bf16_to_f32(ep.res[(int64_t)my_m * ep.ldr + n].x);
+                    ep.out[(int64_t)my_m * ep.ldo + n].x = f32_to_bf16(v);
+                }
+            }
+        }
+    };
+    for (int bid = bid0; bid < n_groups; bid += 2 * stride) {
+        group(std::integral_constant<int, 0>{}, bid);
+        if (bid + stride < n_groups) group(std::integral_constant<int, 1>{}, bid + stride);
+    }
+}
+
+// workgroups [0, gq) walk the nq QKV row groups, the others the nh h->4h row groups
+template <int MR>
+__global__ __launch_bounds__(256) void gemv_qkv_h4_persist_kernel(const bf16* __restrict__ X, int64_t ldx, const bf16* __restrict__ Wq,
+                                                                 const EpiArgs epq, const LnPro ln1, int nq, int gq,
+                                                                 const bf16* __restrict__ Wh, const EpiArgs eph, const LnPro ln2,
+                                                                 int nh, int K) {
+    if ((int)blockIdx.x < gq) gemv_ln_persist_body<MR, true>(blockIdx.x, gq, nq, X, ldx, Wq, K, epq, K, ln1);
+    else gemv_ln_persist_body<MR, false>(blockIdx.x - gq, gridDim.x - gq, nh, X, ldx, Wh, K, eph, K, ln2);
+}
+
 // ---- MFMA weight streamer for 5 .. 64 rows (mid-batch decode) ----------------------------------------------------------------
 // Same contract as gemv_bf16_kernel (one launch, W streamed once at HBM speed, LayerNorm / RoPE+append / second operand
 // pair folded in), but the products run on the matrix pipe -- at 8+ rows the GEMV's per-row VALU work is slower than the
@@ -3634,6 +3837,7 @@ BT_KNOB bool g_mid_rows = true;   // 17..256-row stacks take the slab + fused-re
 // attention arithmetic (latency chains of ~28 cross-lane ops per item, redundantly in 512 workgroups) costs what the dependent
 // launch cost.  Off; the kernel and its bit-identity test live in the debug library only.
 BT_KNOB bool g_few_attn = false;
+BT_KNOB bool g_few_persist = true;   // <= 2 rows: the [QKV | h->4h] launch as ~2 resident workgroups per CU walking the row groups (false: A/B)
 BT_KNOB bool g_few_dual = true;   // <= 4 rows: QKV and h->4h GEMVs of a layer in one launch (false: two launches, A/B)
 BT_KNOB int g_small_stages = 0;   // LDS ring depth of the 128^2 / 128x64 / 64x64 kernels: 0 = per-tile default, 2..4 forced (A/B)
 BT_KNOB int g_gemm_variant = 0;   // 0 auto; 1 force 128^2; 2/3 256^2 four-phase ring (plain/staggered); 4-8 timing ablations; 9/10 256^2
@@ -4348,6 +4552,20 @@ int few_rows_qkv_h4(hipStream_t s, int64_t B, int q_len, int heads, int head_dim
     }
     const int nq = (int)ceil_div(3 * H / 2, 4);        // one wave per (n, n + 16) pair, 4 pairs per workgroup
     const int nh = (int)ceil_div(I, 4 * 2);            // RW = 2 rows per wave, 4 waves
+    if (g_few_persist && M <= 2) {
+        // ~2 resident workgroups per CU walk the row groups (x staged and normalised once per workgroup): groups per workgroup
+        // chosen so that both sides divide evenly where they can (1.2B dims: 768 + 1024 groups -> 192 + 256 workgroups x 4)
+        const int per = (int)std::max<int64_t>(1, ceil_div((int64_t)nq + nh, 2 * (int64_t)num_cus()));
+        const int gq = (int)ceil_div(nq, per), gh = (int)ceil_div(nh, per);
+#define BT_LAUNCH_PDUAL(MR_)                                                                                                         \
+    hipLaunchKernelGGL((gemv_qkv_h4_persist_kernel<MR_>), dim3(gq + gh), dim3(256), 0, s, (const bf16*)x, ldx, (const bf16*)qkv_w, epq, \
+                       l1, nq, gq, (const bf16*)h4_w, eph, l2, nh, (int)H)
+        if (M <= 1) BT_LAUNCH_PDUAL(1);
+        else BT_LAUNCH_PDUAL(2);
+#undef BT_LAUNCH_PDUAL
+        BT_LAUNCH_CHECK("persistent fused QKV + h->4h GEMV launch");
+        return BT_OK;
+    }
 #define BT_LAUNCH_DUAL(MR_)                                                                                                  \
     hipLaunchKernelGGL((gemv_qkv_h4_kernel<MR_>), dim3(nq + nh), dim3(256), 0, s, (const bf16*)x, ldx, (const bf16*)qkv_w, epq, \
                        l1, nq, (const bf16*)h4_w, eph, l2, (int)H)
@@ -4701,6 +4919,7 @@ extern "C" void bt_debug_skinny_rows(int n) { g_skinny_rows = n; }
 extern "C" void bt_debug_small_stages(int n) { g_small_stages = n; }
 extern "C" void bt_debug_mid_rows(int on) { g_mid_rows = on != 0; }
 extern "C" void bt_debug_few_dual(int on) { g_few_dual = on != 0; }
+extern "C" void bt_debug_few_persist(int on) { g_few_persist = on != 0; }
 extern "C" void bt_debug_few_attn(int on) { g_few_attn = on != 0; }
 extern "C" void bt_debug_mid_fuse(int mode) { g_mid_fuse = mode; }
 extern "C" void bt_debug_mid_dual(int on) { g_mid_dual = on != 0; }

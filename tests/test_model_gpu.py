@@ -1810,3 +1810,39 @@ def test_two_branch_parallel_residual_is_bit_identical(B):
         assert torch.equal(out, ref_out) and torch.equal(ctx, ref_ctx), key
     del model
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_few_rows_persistent_gemv_is_bit_identical(B, dbg_lib):
+    """Round 4: <= 2 rows: the [QKV | h->4h] launch as ~2 resident workgroups per CU that stage and LayerNorm x once and walk their
+    row groups with the next group's weight rows in flight (gemv_qkv_h4_persist_kernel) == one workgroup per row group
+    (gemv_qkv_h4_kernel), bit for bit -- same piece ownership, LayerNorm, dot / butterfly order and epilogues: tokens and the last
+    context embedding equal, graphs on and off.  B = 1: M = 1 (steps 1..) and 2 (step 0); B = 2: M = 2 and (step 0) 4 rows -> slab path."""
+    import dataclasses
+    base = named_dims("block_main_b4_1.2b")
+    dims = dataclasses.replace(base, name="b4_1.2b_2layer", bd=dataclasses.replace(base.bd, layers=2),
+                               td=dataclasses.replace(base.td, layers=2))
+    sd = random_state_dict(dims, seed=5, include_unused_embed_in=False)
+    model = load_block_transformer_from_dims(dims, "fp32", keep_unused_embed_in=False)
+    model.load_state_dict(sd, strict=True)
+    model = model.bfloat16().to(DEV)
+    model.token_decoder.generation_config.eos_token_id = None
+    prompt = torch.randint(0, dims.vocab, (B, 64), generator=torch.Generator().manual_seed(B)).to(DEV)
+    outs = {}
+    try:
+        for persist in (1, 0):
+            dbg_lib.bt_debug_few_persist(persist)
+            for graphs in (True, False):
+                model._engine = None
+                model.use_graphs = graphs
+                out = model.generate(prompt, max_length=96).cpu()
+                outs[(persist, graphs)] = (out, model._engine.ctx.float().cpu().clone())
+    finally:
+        dbg_lib.bt_debug_few_persist(1)
+        model.use_graphs = True
+        model._engine = None
+    ref_out, ref_ctx = outs[(0, False)]
+    for key, (out, ctx) in outs.items():
+        assert torch.equal(out, ref_out) and torch.equal(ctx, ref_ctx), key
+    del model
+    torch.cuda.empty_cache()

@@ -24,7 +24,7 @@ from block_transformer_amd.model.utils import load_block_transformer_from_dims  
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--knob", choices=["few_attn", "mid_dual", "mid_attn", "few_max4", "mid_tile", "mid_force2"], required=True)
+    ap.add_argument("--knob", choices=["few_attn", "mid_dual", "mid_attn", "few_max4", "mid_tile", "mid_force2", "few_persist"], required=True)
     ap.add_argument("--batches", default="1,2")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--cutoffs", default="", help="few_max4: compare these few-rows cutoffs (e.g. 16,4,2,1,0); mid_tile: tile variants "
@@ -37,7 +37,7 @@ def main():
     setter = {"few_attn": hooks.bt_debug_few_attn, "mid_dual": hooks.bt_debug_mid_dual, "mid_attn": hooks.bt_debug_mid_attn,
               # 5..16-row stacks: split-K slab path (on: few-rows cutoff 4) vs the MFMA weight streamer launches (off: cutoff 16)
               "few_max4": lambda on: hooks.bt_debug_few_rows_max(4 if on else 16), "mid_tile": hooks.bt_debug_mid_tile,
-              "mid_force2": hooks.bt_debug_mid_force2}[args.knob]
+              "mid_force2": hooks.bt_debug_mid_force2, "few_persist": hooks.bt_debug_few_persist}[args.knob]
     dims = named_dims("block_main_b4_1.2b")
     torch.manual_seed(1234)
     with torch.device("cuda"):
