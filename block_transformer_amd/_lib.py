@@ -147,6 +147,7 @@ _DEBUG_SIGS = {
     "bt_debug_attn_nt": (None, [c_int]),
     "bt_debug_attn_persist": (None, [c_int]),
     "bt_debug_local_kernel": (None, [c_int]),
+    "bt_debug_attn_wide": (None, [c_int]),
     "bt_debug_few_rows_max": (None, [c_int]),
     "bt_debug_no_few_rows_fusion": (None, [c_int]),
     "bt_debug_lin2_large": (None, [c_int]),

@@ -141,11 +141,12 @@ __global__ __launch_bounds__(NW * 64) void attend_rows_kernel(const T* __restric
     constexpr int V = Elem<T>::VEC;
     constexpr int LPR = D / V;     // lanes per K/V row
     constexpr int RPW = 64 / LPR;  // rows per wave-instruction
-    constexpr int U = 4;           // independent 16-byte loads in flight per lane
+    constexpr int U = NW >= 16 ? 8 : 4;   // independent 16-byte loads in flight per lane (the 16-wave form covers 512 keys per sweep)
+    constexpr int RED = NW > 4 ? NW : 4;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* red = smem;             // [NW]
-    float* ored = smem + 4;        // [NW][D]  cross-wave output reduce
-    float* sc = smem + 4 + NW * D; // [cap] scores / probabilities of this split
+    float* red = smem;               // [NW]
+    float* ored = smem + RED;        // [NW][D]  cross-wave output reduce
+    float* sc = smem + RED + NW * D; // [cap] scores / probabilities of this split
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = lane % LPR, sub = lane / LPR;
@@ -1335,6 +1336,12 @@ static int g_local_kernel = 1;   // A/B hook: 0 = the token-decoder window runs 
 static constexpr int g_attn_persist = 0;
 static constexpr int g_local_kernel = 1;
 #endif
+#ifdef BT_DEBUG_HOOKS
+static int g_attn_wide = 1;      // A/B hook: 0 = tiny batches keep split-N + combine for the global step
+extern "C" void bt_debug_attn_wide(int on) { g_attn_wide = on; }
+#else
+static constexpr int g_attn_wide = 1;
+#endif
 
 template <typename T, int D>
 static int launch_attend(int64_t B, int q_len, int heads, const void* qkv, int64_t ld_qkv, const void* kc, const void* vc,
@@ -1360,6 +1367,18 @@ static int launch_attend(int64_t B, int q_len, int heads, const void* qkv, int64
             BT_LAUNCH_CHECK("bt_attention(local window) launch");
             return BT_OK;
         }
+    }
+    // a handful of (sequence, head) items against a long cache (batch 1-4 block-decoder steps): split-N over 8-16 small workgroups
+    // plus a combine launch is two dependent launches of ~7 + ~5 us; ONE 16-wave workgroup per item sweeps 512 keys per pass with
+    // 8 loads in flight per lane and combines in LDS (round 4; the split request and its workspace are then simply not used)
+    if (g_attn_wide && n_split > 1 && sizeof(T) == 2 && (int64_t)B * heads * q_len <= 64 && !seq_skip &&
+        (16 + 16 * D + n_max) * sizeof(float) <= 64 * 1024) {
+        const size_t shm = (16 + 16 * D + n_max) * sizeof(float);
+        hipLaunchKernelGGL((attend_rows_kernel<T, D, 16>), dim3((unsigned)(B * heads * q_len), 1), dim3(1024), shm, s, (const T*)qkv,
+                           ld_qkv, (const T*)kc, (const T*)vc, n_max, pos0_dev, pos0_host, mask, mask_ld, (T*)out, ldo, ws, q_len,
+                           heads, 1, scale);
+        BT_LAUNCH_CHECK("bt_attention(rows, 16 waves) launch");
+        return BT_OK;
     }
     if (n_max <= 64 && n_split == 1) {
         const size_t shm = (4 + 1 * D + cap) * sizeof(float);
