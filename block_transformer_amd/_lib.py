@@ -120,6 +120,9 @@ _SIGS = {
     "bt_event_record": (c_int, [c_void_p, c_void_p]),
     "bt_event_elapsed_ms": (c_int, [c_void_p, c_void_p, POINTER(c_float)]),
     "bt_event_destroy": (c_int, [c_void_p]),
+    "bt_ceiling_copy": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_void_p]),
+    "bt_ceiling_mfma_flops": (c_int64, [c_int32, c_int32]),
+    "bt_ceiling_mfma": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int32, c_int32, c_void_p]),
     "bt_prof_enable": (c_int, [c_int]),
     "bt_prof_collect": (c_int, [POINTER(ctypes.c_double), POINTER(c_int64), c_int]),
     "bt_prof_trace": (c_int, [POINTER(ctypes.c_double), POINTER(ctypes.c_double), POINTER(ctypes.c_int32), c_int64,

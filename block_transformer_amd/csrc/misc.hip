@@ -2,6 +2,8 @@
 // kernels.  All HBM-bound byte/index work: coalesced 16-byte accesses, one wave or one workgroup per row.
 #include "bt_common.h"
 
+#include <algorithm>
+
 namespace bt {
 
 // ---- bt_embed_rows ----------------------------------------------------------------------------------------------------
@@ -528,6 +530,97 @@ extern "C" int bt_bump(int32_t* counter, int32_t delta, bt_stream stream) {
     BT_CHECK_ARG(counter, "bt_bump: null pointer");
     hipLaunchKernelGGL(bump_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, counter, delta);
     BT_LAUNCH_CHECK("bt_bump launch");
+    return BT_OK;
+}
+
+// ---- empirical ceilings of the box (bench.py `ceilings`, SURVEY.md section 8d: "measure empirical ceilings on the box ... and report
+// against both"; the reference's harness measures its run's own numbers in-run, measure_generation_time.py:143-161) -------------------
+// bt_ceiling_copy: dst[0 .. bytes) = src, 16 bytes per lane, four independent loads in flight per lane and iteration, grid-stride;
+// flags bit 0 = non-temporal loads and stores.  HBM rate = 2 * bytes / time (bytes read + bytes written).
+template <bool NT>
+__global__ __launch_bounds__(256) void ceiling_copy_kernel(const u32x4_t* __restrict__ src, u32x4_t* __restrict__ dst, int64_t n16) {
+    const int64_t stride = (int64_t)gridDim.x * 1024;
+    for (int64_t i = (int64_t)blockIdx.x * 1024 + threadIdx.x; i < n16; i += stride) {
+        u32x4_t v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = i + u * 256;
+            const int64_t jc = j < n16 ? j : n16 - 1;   // unconditional (clamped) loads: all four go out before the first store
+            v[u] = NT ? __builtin_nontemporal_load(src + jc) : src[jc];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int64_t j = i + u * 256;
+            if (j < n16) {
+                if (NT) __builtin_nontemporal_store(v[u], dst + j);
+                else dst[j] = v[u];
+            }
+        }
+    }
+}
+
+extern "C" int bt_ceiling_copy(void* dst, const void* src, int64_t bytes, int32_t flags, bt_stream stream) {
+    BT_CHECK_ARG(dst && src && bytes > 0 && bytes % 16 == 0 && aligned16(dst) && aligned16(src), "bt_ceiling_copy: 16-byte multiples only");
+    const int64_t n16 = bytes / 16;
+    const unsigned grid = (unsigned)std::min<int64_t>(ceil_div(n16, 1024), 256 * 32);
+    if (flags & 1)
+        hipLaunchKernelGGL(ceiling_copy_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const u32x4_t*)src, (u32x4_t*)dst, n16);
+    else
+        hipLaunchKernelGGL(ceiling_copy_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const u32x4_t*)src, (u32x4_t*)dst, n16);
+    BT_LAUNCH_CHECK("bt_ceiling_copy launch");
+    return BT_OK;
+}
+
+// bt_ceiling_mfma: a bare v_mfma_f32_16x16x32_bf16 loop on the caller's (random) bf16 data, operands in registers, 16 independent
+// accumulators per wave (no dependent-issue stalls), four operand pairings rotated through the unrolled body so consecutive MFMAs
+// toggle their inputs like a GEMM's do.  No LDS, no memory traffic inside the loop: what it reaches is the matrix pipe's rate at the
+// clock the part SUSTAINS under that load.  Each wave issues iters * 64 MFMAs of 16 * 16 * 32 * 2 flop; grid = workgroups of 4 waves.
+typedef short ceil_bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float ceil_f32x4_t __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void ceiling_mfma_kernel(const u32x4_t* __restrict__ data, float* __restrict__ out, int iters) {
+    const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    ceil_bf16x8_t a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a[i] = __builtin_bit_cast(ceil_bf16x8_t, data[gid * 8 + i]);
+        b[i] = __builtin_bit_cast(ceil_bf16x8_t, data[gid * 8 + 4 + i]);
+    }
+    ceil_f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = ceil_f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    // (inline asm: with the builtin this compiler permutes the 16 accumulators through ~80 v_accvgpr moves per trip)
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(a[(i + r) & 3]), "v"(b[(j + r) & 3]));
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");   // the last MFMAs' results before the VALU reads below (inline asm is not hazard-checked)
+    ceil_f32x4_t sum = ceil_f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sum += acc[i][j];
+    out[gid] = sum[0] + sum[1] + sum[2] + sum[3];
+}
+
+extern "C" int64_t bt_ceiling_mfma_flops(int32_t workgroups, int32_t iters) {
+    return (int64_t)workgroups * 4 * (int64_t)iters * 64 * (16 * 16 * 32 * 2);
+}
+
+extern "C" int bt_ceiling_mfma(const void* data, int64_t data_bytes, void* out, int64_t out_bytes, int32_t workgroups, int32_t iters,
+                               bt_stream stream) {
+    BT_CHECK_ARG(data && out && aligned16(data) && workgroups > 0 && iters > 0 && data_bytes >= (int64_t)workgroups * 256 * 128 &&
+                     out_bytes >= (int64_t)workgroups * 256 * 4,
+                 "bt_ceiling_mfma: data (workgroups * 256 * 128 bytes, 16-byte aligned) and out (workgroups * 256 floats) required");
+    hipLaunchKernelGGL(ceiling_mfma_kernel, dim3((unsigned)workgroups), dim3(256), 0, (hipStream_t)stream, (const u32x4_t*)data,
+                       (float*)out, iters);
+    BT_LAUNCH_CHECK("bt_ceiling_mfma launch");
     return BT_OK;
 }
 

@@ -417,16 +417,26 @@ class DecodeEngine:
             self.graphs[what] = g
         g.launch()
 
-    def token_block_streamed(self, count: int, streamer, n_real: Optional[int] = None):
-        """Eager token block with one host callback per token (HF streamer protocol, inference_demo.py:69-83).  ``n_real``:
-        rows of a compacted engine that carry a sequence (the streamer sees those, like the reference's token decoder)."""
+    def token_block_streamed(self, count: int, streamer, n_real: Optional[int] = None, eos_on: bool = False):
+        """Eager token block with one host callback per token (HF streamer protocol, inference_demo.py:69-83).  The streamer gets
+        exactly the rows the reference hands it in EVERY block -- the ``decode_mask`` rows, i.e. the sequences that were unfinished
+        when the block started (model/block_transformer.py:389-398) -- whether or not the engine has been compacted (one
+        protocol before and after a compaction), in ascending ORIGINAL row order; ``block_start`` also receives those original row
+        indices (``row_map`` of a compacted engine) so a batch streamer can attribute rows.  ``n_real``: rows of a compacted engine
+        that carry a sequence."""
         d = ctypes.byref(self.desc)
         n = self.B if n_real is None else n_real
-        streamer.block_start(n)
+        live = None                                             # None = every one of the n rows
+        if eos_on:
+            live = (self.finished[:n] == 0).nonzero().flatten()  # the reference's decode_mask of this iteration (a host sync per
+            if int(live.numel()) == n:                           # block, which the EOS loop makes anyway)
+                live = None
+        rows = torch.arange(n, device=self.tok.raw.device) if live is None else live
+        streamer.block_start(int(rows.numel()), rows if self.row_map is None else self.row_map[rows])
         for t in range(count):
             fin = count if t == count - 1 else 0
             check(lib().bt_token_block_enqueue(d, t, t + 1, fin, current_stream()), "bt_token_block_enqueue")
-            streamer.put(self.tok.raw[:n, t])
+            streamer.put(self.tok.raw[:n, t] if live is None else self.tok.raw[live, t])
         streamer.block_end()
 
     # ---- the generate loop -------------------------------------------------------------------------------------------------
@@ -459,7 +469,7 @@ class DecodeEngine:
                 if per_iter:
                     timers.mark_iter("token_decoder_start")
                 if streamer is not None:
-                    eng.token_block_streamed(count, streamer, n_real)
+                    eng.token_block_streamed(count, streamer, n_real, eos_on=gen_eos >= 0)
                 elif fused_step and not last and count == L:
                     eng.launch("step", L, True)
                     n_blocks += 1

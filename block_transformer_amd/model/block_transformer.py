@@ -314,8 +314,17 @@ class _BlockStreamer:
     def put(self, t: torch.Tensor):
         self.s.put(t.cpu())
 
-    def block_start(self, n=None):
-        """``n``: rows the token decoder runs on (the live rows once the batch has been compacted; reference :389-398)."""
+    def block_start(self, n=None, rows=None):
+        """``n``: rows the token decoder runs on in this block = the reference's ``decode_mask`` rows (:389-398): the sequences that
+        were unfinished when the block started, in ascending original row order -- before and after a compaction alike.  ``rows``:
+        their ORIGINAL batch row indices; published as ``streamer.bt_rows`` (LongTensor on the CPU) before the placeholder is put,
+        so a batch streamer can attribute the rows of every later ``put`` of the block (the HF protocol itself has no row
+        identity; the reference's streamer sees the same compacted rows without one)."""
+        if rows is not None:
+            try:
+                self.s.bt_rows = rows.detach().cpu()
+            except AttributeError:      # a streamer with __slots__: the protocol works without the attribution
+                pass
         self.s.put(torch.full((self.B if n is None else n, 1), self.eos, dtype=torch.long))
 
     def block_end(self):

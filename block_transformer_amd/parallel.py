@@ -33,6 +33,19 @@ def parse_cpulist(text: str) -> List[int]:
     return sorted(cpus)
 
 
+def _is_amdgpu(dev_dir: str) -> bool:
+    """True when a /sys/class/drm/card*/device directory is an AMD GPU function: bound to the amdgpu driver, or PCI vendor 0x1002."""
+    try:
+        if os.path.basename(os.path.realpath(os.path.join(dev_dir, "driver"))) == "amdgpu":
+            return True
+    except OSError:
+        pass
+    try:
+        return int(open(os.path.join(dev_dir, "vendor")).read().strip(), 16) == 0x1002
+    except (OSError, ValueError):
+        return False
+
+
 def gpu_numa_cpus(local_rank: int, sysfs_root: str = "/sys") -> Tuple[Optional[int], List[int]]:
     """(NUMA node, CPU ids local to it) of the GPU ``local_rank`` drives, from sysfs: the PCI function of the torch device
     (``pci_domain_id:pci_bus_id:pci_device_id.0``) when torch exposes it, else the local_rank-th ``/sys/class/drm/card*`` that
@@ -48,6 +61,7 @@ def gpu_numa_cpus(local_rank: int, sysfs_root: str = "/sys") -> Tuple[Optional[i
     try:
         cards = sorted((c for c in os.listdir(drm) if c.startswith("card") and c[4:].isdigit()), key=lambda c: int(c[4:]))
         cards = [os.path.join(drm, c, "device") for c in cards if os.path.exists(os.path.join(drm, c, "device", "numa_node"))]
+        cards = [d for d in cards if _is_amdgpu(d)]     # not a BMC / ASPEED VGA function that also has a numa_node file
         if local_rank < len(cards):
             dev_dirs.append(cards[local_rank])
     except OSError:
@@ -70,11 +84,14 @@ def gpu_numa_cpus(local_rank: int, sysfs_root: str = "/sys") -> Tuple[Optional[i
     return None, []
 
 
-def bind_to_gpu_numa_node(local_rank: int, world: int, sysfs_root: str = "/sys") -> Optional[dict]:
+def bind_to_gpu_numa_node(local_rank: int, local_world: int, sysfs_root: str = "/sys") -> Optional[dict]:
     """Pin this rank's host threads to the CPUs of its GPU's NUMA node (small batches are host-launch bound: 52 launches per
     block step at B = 1, and a rank scheduled on the far socket pays cross-socket latency on every one).  Ranks sharing a node
-    split its CPUs evenly by local rank.  No-op (returns None) when sysfs has no NUMA information, the intersection with the
-    current affinity mask is empty, or BT_NO_NUMA_BIND=1."""
+    split its CPUs evenly by local rank.  ``local_world`` = the number of ranks on THIS node (LOCAL_WORLD_SIZE; the peer scan walks
+    local ranks only -- a multi-node job's global world size would index GPUs this node does not have).  The chosen binding is
+    logged once to stderr so a bad pin is visible.  sched_setaffinity(0) covers the calling thread and threads created later: call
+    it before the process group (and its helper threads) comes up, as init_distributed does.  No-op (returns None) when sysfs has
+    no NUMA information, the intersection with the current affinity mask is empty, or BT_NO_NUMA_BIND=1."""
     if os.environ.get("BT_NO_NUMA_BIND") == "1" or not hasattr(os, "sched_setaffinity"):
         return None
     node, cpus = gpu_numa_cpus(local_rank, sysfs_root)
@@ -83,19 +100,23 @@ def bind_to_gpu_numa_node(local_rank: int, world: int, sysfs_root: str = "/sys")
     allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
     if not allowed:
         return None
-    peers = [r for r in range(world) if gpu_numa_cpus(r, sysfs_root)[0] == node] or [local_rank]
+    peers = [r for r in range(max(1, local_world)) if gpu_numa_cpus(r, sysfs_root)[0] == node] or [local_rank]
     if local_rank in peers and len(peers) > 1 and len(allowed) >= len(peers):
         per = len(allowed) // len(peers)
         i = peers.index(local_rank)
         allowed = allowed[i * per:(i + 1) * per]
     os.sched_setaffinity(0, allowed)
+    import sys
+    print(f"[bt parallel] local rank {local_rank}: bound to NUMA node {node}, {len(allowed)} CPU(s) "
+          f"{allowed[0]}..{allowed[-1]} ({len(peers)} local rank(s) share the node)", file=sys.stderr, flush=True)
     return {"numa_node": node, "cpus": allowed}
 
 
 def init_distributed(backend: Optional[str] = None) -> Tuple[int, int, int]:
     rank, world, local = env_world()
     if world > 1:
-        bind_to_gpu_numa_node(local, world)
+        local_world = int(os.environ.get("LOCAL_WORLD_SIZE", 0)) or (torch.cuda.device_count() if torch.cuda.is_available() else world)
+        bind_to_gpu_numa_node(local, min(world, local_world))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")

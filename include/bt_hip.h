@@ -395,6 +395,17 @@ int bt_prof_collect(double* ms_out, int64_t* count_out, int n_fam); /* n_fam = B
  * the reference's harness (measure_generation_time.py:150-155): the harness counterpart writes these as trace events. */
 int bt_prof_trace(double* start_ms, double* dur_ms, int32_t* family, int64_t capacity, int64_t* n_out);
 
+/* ---- empirical ceilings of the box for bench.py's `ceilings` object (the reference's harness measures its
+ * numbers in-run the same way, measure_generation_time.py:143-161) -- measurement kernels, not on the decode path ----------------
+ * bt_ceiling_copy: dst[0, bytes) = src with 16 bytes per lane (flags bit 0: non-temporal loads / stores): HBM rate = 2 * bytes / t.
+ * bt_ceiling_mfma: `workgroups` x 4 waves each issue iters * 64 v_mfma_f32_16x16x32_bf16 on the 16-byte operand words found in
+ *   `data` (>= workgroups * 256 * 128 bytes; register operands, no memory traffic in the loop); bt_ceiling_mfma_flops() is the flop count of such a launch;
+ *   `out`: workgroups * 256 floats (keeps the results alive). */
+int bt_ceiling_copy(void* dst, const void* src, int64_t bytes, int32_t flags, bt_stream stream);
+int64_t bt_ceiling_mfma_flops(int32_t workgroups, int32_t iters);
+int bt_ceiling_mfma(const void* data, int64_t data_bytes, void* out, int64_t out_bytes, int32_t workgroups, int32_t iters,
+                    bt_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,6 +33,10 @@ def random_state_dict(dims, seed=0, **kw):
 DEV = "cuda"
 TOL = 1e-3          # north_star: logits within 1e-3 fp32
 TIGHT = 2e-4        # what the fp32 kernels actually achieve on these sizes (guards against silent regressions)
+# bf16 budget of the FULL-DEPTH (12 + 12 layer) comparisons against the fp32 oracle on the same bf16 weights: |error| <= BF16_REL *
+# max|reference| + BF16_ABS.  Round 5 ratchet: four rounds of boxes observed 1.1-1.8 % of max (ctx 0.037-0.061,
+# logits 0.044-0.057 at max|value| 3.4-4.2) against the old 3 % gate -- a kernel that doubled its error would still have passed.
+BF16_REL, BF16_ABS = 2.2e-2, 1e-2
 
 
 def maxabs(a, b):
@@ -710,7 +714,7 @@ def test_full_depth_1p2b_bf16_first_block_logits_vs_oracle(B):
     embedding and first-token logits against the fp32 CPU oracle on the same (bf16) weights (oracle on 2 of the B
     sequences: rows are independent).
     bf16 budget: 24 layers of bf16-rounded activations (2^-9 relative per rounding, ~10 roundings per layer,
-    accumulating as a random walk) -> |error| <= 3 % of max|value| + 0.01 absolute (observed on MI355X: 1.1-1.8 % of
+    accumulating as a random walk) -> |error| <= 2.2 % of max|value| + 0.01 absolute (BF16_REL / BF16_ABS; observed on MI355X: 1.1-1.8 % of
     max: ctx 0.041 / 0.061, logits 0.048 / 0.057 at max|value| 3.4-4.2); the greedy token must agree wherever the oracle's
     top-1 margin exceeds twice that budget."""
     model, dims, o = _full_1p2b()
@@ -724,8 +728,8 @@ def test_full_depth_1p2b_bf16_first_block_logits_vs_oracle(B):
     ctx = eng.ctx.float().cpu()[rows]
     logits = eng.tok.logits.float().cpu()[rows]
     ref_ctx, ref_lg = _oracle_first_token(o, prompt[rows])
-    budget_ctx = 3e-2 * ref_ctx.abs().max().item() + 1e-2
-    budget_lg = 3e-2 * ref_lg.abs().max().item() + 1e-2
+    budget_ctx = BF16_REL * ref_ctx.abs().max().item() + BF16_ABS
+    budget_lg = BF16_REL * ref_lg.abs().max().item() + BF16_ABS
     e_ctx, e_lg = (ctx - ref_ctx).abs().max().item(), (logits - ref_lg).abs().max().item()
     print(f"[full-depth bf16 B={B}] ctx err {e_ctx:.4f} (budget {budget_ctx:.4f}, max {ref_ctx.abs().max():.3f}); "
           f"logit err {e_lg:.4f} (budget {budget_lg:.4f}, max {ref_lg.abs().max():.3f})")
@@ -748,7 +752,7 @@ def test_full_depth_1p2b_bf16_benchmark_batch_decode_dispatch_vs_oracle():
     persistent kernel for h->4h / logits (+ fused argmax) and -- token step 0, q = 2 -> M = 8192 -- for everything; prefill =
     65536 rows through the persistent kernel + flash.  Three checkpoints, each against the fp32 CPU
     oracle on the same bf16 weights for 3 rows (rows are independent), same margin-aware budget as the B = 2 / 64 test
-    (3 % of max + 0.01):
+    (2.2 % of max + 0.01):
       (1) max_length = P + 1: context embedding + first-token logits (token step 0: q = 2, M = 8192);
       (2) max_length = P + 2: logits of token step 1 (q = 1, M = 4096: the 128^2 fused-QKV path), oracle teacher-forced on
           the GPU's own first token;
@@ -763,7 +767,7 @@ def test_full_depth_1p2b_bf16_benchmark_batch_decode_dispatch_vs_oracle():
     dev_prompt = prompt.to(DEV)
 
     def budget(ref):
-        return 3e-2 * ref.abs().max().item() + 1e-2
+        return BF16_REL * ref.abs().max().item() + BF16_ABS
 
     # (1) first block, token step 0
     got = model.generate(dev_prompt, max_length=P + 1).cpu()
@@ -774,7 +778,7 @@ def test_full_depth_1p2b_bf16_benchmark_batch_decode_dispatch_vs_oracle():
     print(f"[B=4096 step 0] ctx err {e_ctx:.4f} / {budget(ref_ctx):.4f}, logit err {e_lg:.4f} / {budget(ref_lg):.4f}")
     assert e_ctx <= budget(ref_ctx) and e_lg <= budget(ref_lg)
     assert torch.equal(got[rows, P], lg.argmax(-1))
-    assert_tokens_within_noise(ref_lg[:, None], got[rows, P:P + 1], 3e-2, 1e-2, "B=4096 step 0")
+    assert_tokens_within_noise(ref_lg[:, None], got[rows, P:P + 1], BF16_REL, BF16_ABS, "B=4096 step 0")
     assert torch.equal(got[:, :P], prompt)
     # (2) token step 1 (q = 1): teacher-forced oracle along the GPU's first token
     got2 = model.generate(dev_prompt, max_length=P + 2).cpu()
@@ -785,7 +789,7 @@ def test_full_depth_1p2b_bf16_benchmark_batch_decode_dispatch_vs_oracle():
     print(f"[B=4096 step 1] logit err {e1:.4f} / {budget(ref_blk[:, 1]):.4f}")
     assert e1 <= budget(ref_blk[:, 1])
     assert torch.equal(got2[rows, P + 1], lg1.argmax(-1))
-    assert_tokens_within_noise(ref_blk, got2[rows, P:P + 2], 3e-2, 1e-2, "B=4096 steps 0-1")
+    assert_tokens_within_noise(ref_blk, got2[rows, P:P + 2], BF16_REL, BF16_ABS, "B=4096 steps 0-1")
     # (3) second block: block-decoder decode step over the global KV
     got3 = model.generate(dev_prompt, max_length=P + L + 1).cpu()
     assert torch.equal(got3[:, :P + 2], got2)
@@ -797,7 +801,7 @@ def test_full_depth_1p2b_bf16_benchmark_batch_decode_dispatch_vs_oracle():
     assert e_ctx2 <= budget(ref_ctx2) and e_lg2 <= budget(ref_lg2)
     assert torch.equal(got3[rows, P + L], lg2.argmax(-1))
     _, ref_blk1 = oracle_block_logits(o, prompt[rows], got3[rows, P:P + L])
-    assert_tokens_within_noise(ref_blk1, got3[rows, P:P + L], 3e-2, 1e-2, "B=4096 first block")
+    assert_tokens_within_noise(ref_blk1, got3[rows, P:P + L], BF16_REL, BF16_ABS, "B=4096 first block")
     # every row was decoded (not just the sampled three): ids in range, rows differ
     assert int(got3.min()) >= 0 and int(got3.max()) < dims.vocab
     assert len({tuple(r.tolist()) for r in got3[:64, P:]}) > 8
@@ -812,7 +816,7 @@ def test_full_depth_1p2b_bf16_steady_state_decode_vs_oracle(B):
     UNSPLIT q = 1 global attention over 513 cached positions in every layer (B * heads >= 512) -- then token step 0 of block 2.
     B = 64 takes the mid-batch split-K stack, B = 512 the large-M stack the benchmark runs (128^2 / 256x128 / persistent GEMMs with
     the fused QKV + RoPE + append epilogue).  Context of block 2 and its first logits for 2 rows against the fp32 oracle prefilled on
-    prompt + the GPU's first block (same budget as the B = 4096 checkpoints: 3 % of max + 0.01), tokens margin-aware."""
+    prompt + the GPU's first block (same budget as the B = 4096 checkpoints: 2.2 % of max + 0.01), tokens margin-aware."""
     model, dims, o = _full_1p2b()
     model.pipeline = False
     model.use_graphs = True
@@ -826,16 +830,137 @@ def test_full_depth_1p2b_bf16_steady_state_decode_vs_oracle(B):
     ref_ctx2, ref_lg2 = _oracle_first_token(o, got[rows, :P + L])
 
     def budget(ref):
-        return 3e-2 * ref.abs().max().item() + 1e-2
+        return BF16_REL * ref.abs().max().item() + BF16_ABS
 
     e_ctx, e_lg = (ctx2 - ref_ctx2).abs().max().item(), (lg2 - ref_lg2).abs().max().item()
     print(f"[steady state B={B}: block 2 over 513 cached positions] ctx err {e_ctx:.4f} / {budget(ref_ctx2):.4f}, "
           f"logit err {e_lg:.4f} / {budget(ref_lg2):.4f}")
     assert e_ctx <= budget(ref_ctx2) and e_lg <= budget(ref_lg2)
     assert torch.equal(got[rows, P + L], lg2.argmax(-1))
-    assert_tokens_within_noise(ref_lg2[:, None], got[rows, P + L:P + L + 1], 3e-2, 1e-2, f"steady state B={B} block 2")
+    assert_tokens_within_noise(ref_lg2[:, None], got[rows, P + L:P + L + 1], BF16_REL, BF16_ABS, f"steady state B={B} block 2")
     _, ref_blk1 = oracle_block_logits(o, prompt[rows], got[rows, P:P + L])
-    assert_tokens_within_noise(ref_blk1, got[rows, P:P + L], 3e-2, 1e-2, f"steady state B={B} first block")
+    assert_tokens_within_noise(ref_blk1, got[rows, P:P + L], BF16_REL, BF16_ABS, f"steady state B={B} first block")
+    assert torch.equal(got[:, :P], prompt)
+    assert int(got.min()) >= 0 and int(got.max()) < dims.vocab
+    model.release_buffers()
+
+
+def test_full_depth_1p2b_fp32_logits_within_1e3_of_oracle():
+    """The north-star tolerance, literally, on the north-star model (VERDICT r4 missing #1): "logits within 1e-3 fp32 of the reference
+    CPU eager path" on the fp32 instantiation of FULL-DEPTH block_main_b4_1.2b (12 + 12 layers, H = 2048, I = 8192: K = 8192
+    accumulations in every dense_4h_to_h, V = 50304; 9.7 GB of fp32 weights), B = 2, P = 2048 (512 block positions through the
+    row-wise prefill attention), max_length = P + L + 1: context embedding and logits (model/token_decoder/base.py:349) of block 1 and
+    of block 2 (roll-over + global attention over 513 cached positions) within 1e-3 of the oracle, every token equal."""
+    dims = named_dims("block_main_b4_1.2b")
+    torch.manual_seed(23)
+    with torch.device(DEV):
+        model = load_block_transformer_from_dims(dims, "fp32", keep_unused_embed_in=False)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            if n.endswith(".bias"):
+                p.normal_(0.0, 0.02)
+    model.token_decoder.generation_config.eos_token_id = None
+    model.keep_logits = True
+    model.use_graphs = True
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    o = oracle_from_dims(dims, sd)
+    B, P, L = 2, 2048, dims.L
+    prompt = torch.randint(0, dims.vocab, (B, P), generator=torch.Generator().manual_seed(2048))
+    try:
+        got1 = model.generate(prompt.to(DEV), max_length=P + 1).cpu()
+        eng = model._engine
+        ctx1, lg1 = eng.ctx.float().cpu(), eng.tok.logits.float().cpu()
+        ref_ctx1, ref_lg1 = _oracle_first_token(o, prompt)
+        e_ctx1, e_lg1 = (ctx1 - ref_ctx1).abs().max().item(), (lg1 - ref_lg1).abs().max().item()
+        print(f"[full-depth fp32 block 1] ctx err {e_ctx1:.2e} (max {ref_ctx1.abs().max():.3f}), logit err {e_lg1:.2e} "
+              f"(max {ref_lg1.abs().max():.3f})")
+        assert e_ctx1 <= TOL and e_lg1 <= TOL, (e_ctx1, e_lg1)
+        assert torch.equal(got1[:, P], ref_lg1.argmax(-1))
+        got = model.generate(prompt.to(DEV), max_length=P + L + 1).cpu()
+        eng = model._engine
+        assert int(eng.n_cur.item()) == P // L + 1
+        ctx2, lg2 = eng.ctx.float().cpu(), eng.tok.logits.float().cpu()
+        ref_ctx2, ref_lg2 = _oracle_first_token(o, got[:, :P + L])
+        e_ctx2, e_lg2 = (ctx2 - ref_ctx2).abs().max().item(), (lg2 - ref_lg2).abs().max().item()
+        print(f"[full-depth fp32 block 2 over 513 cached positions] ctx err {e_ctx2:.2e}, logit err {e_lg2:.2e}")
+        assert e_ctx2 <= TOL and e_lg2 <= TOL, (e_ctx2, e_lg2)
+        # every logit of the first block along the GPU's own tokens (token steps 1 .. L-1 over the local window) + the tokens themselves
+        _, ref_blk = oracle_block_logits(o, prompt, got[:, P:P + L])
+        assert torch.equal(got[:, P:P + L], ref_blk.argmax(-1))
+        assert torch.equal(got[:, P + L], ref_lg2.argmax(-1))
+        assert torch.equal(got[:, :P + 1], got1)
+    finally:
+        model.release_buffers()
+        del model
+        torch.cuda.empty_cache()
+
+
+_FULL_B8 = {}
+
+
+def _full_b8():
+    """block_main_b8_1.2b (BASELINE configs[4]: L = 8, embedder width 256, local window of 9 keys) at full depth, bf16, random init on
+    the GPU, and the fp32 CPU oracle on exactly those bf16 weights.  Built once per session."""
+    if not _FULL_B8:
+        dims = named_dims("block_main_b8_1.2b")
+        torch.manual_seed(29)
+        with torch.device(DEV):
+            model = load_block_transformer_from_dims(dims, "bf16", keep_unused_embed_in=False)
+        with torch.no_grad():
+            for n, p in model.named_parameters():
+                if n.endswith(".bias"):
+                    p.normal_(0.0, 0.02)
+        model.token_decoder.generation_config.eos_token_id = None
+        model.keep_logits = True
+        sd16 = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+        _FULL_B8["m"] = (model, dims, oracle_from_dims(dims, sd16))
+    return _FULL_B8["m"]
+
+
+@pytest.mark.parametrize("B", [64, 512])
+def test_full_depth_b8_1p2b_bf16_first_block_and_steady_state_vs_oracle(B):
+    """BASELINE configs[4] at its OWN size (VERDICT r4 missing #2): full-depth block_main_b8_1.2b, bf16, P = 2048 -> 256 prompt
+    positions of L = 8 tokens (embedder rows of width h_e = 256 concatenated: model/embedder/base.py:55-61), token-decoder window of
+    E + L - 1 = 9 keys, 8 token steps per block.  B = 64 takes the mid-batch split-K stack (folded local attention, KMAX = 12), B = 512
+    the large-M stack of the benchmark.  Two checkpoints against the fp32 oracle on the same bf16 weights (2 rows), budget
+    BF16_REL * max + BF16_ABS:
+      (1) max_length = P + 1: context embedding + first-token logits;
+      (2) max_length = P + L + 1: the whole first block margin-aware along the GPU's own tokens (token steps 1 .. 7 read 3 .. 9 local
+          keys), then roll-over (lookup of 8 ids x 256 columns, append at cache row 256, unsplit attention over 257 positions) and
+          context + first logits of block 2."""
+    model, dims, o = _full_b8()
+    assert dims.L == 8
+    model.pipeline = False
+    model.use_graphs = True
+    P, L = 2048, dims.L
+    prompt = torch.randint(0, dims.vocab, (B, P), generator=torch.Generator().manual_seed(8000 + B))
+    rows = [0, B - 1]
+
+    def budget(ref):
+        return BF16_REL * ref.abs().max().item() + BF16_ABS
+
+    got1 = model.generate(prompt.to(DEV), max_length=P + 1).cpu()
+    eng = model._engine
+    ctx, lg = eng.ctx.float().cpu()[rows], eng.tok.logits.float().cpu()[rows]
+    ref_ctx, ref_lg = _oracle_first_token(o, prompt[rows])
+    e_ctx, e_lg = (ctx - ref_ctx).abs().max().item(), (lg - ref_lg).abs().max().item()
+    print(f"[b8 full depth B={B} block 1] ctx err {e_ctx:.4f} / {budget(ref_ctx):.4f}, logit err {e_lg:.4f} / {budget(ref_lg):.4f}")
+    assert e_ctx <= budget(ref_ctx) and e_lg <= budget(ref_lg)
+    assert torch.equal(got1[rows, P], lg.argmax(-1))
+    got = model.generate(prompt.to(DEV), max_length=P + L + 1).cpu()
+    eng = model._engine
+    assert int(eng.n_cur.item()) == P // L + 1
+    assert torch.equal(got[:, :P + 1], got1)
+    ctx2, lg2 = eng.ctx.float().cpu()[rows], eng.tok.logits.float().cpu()[rows]
+    ref_ctx2, ref_lg2 = _oracle_first_token(o, got[rows, :P + L])
+    e_ctx2, e_lg2 = (ctx2 - ref_ctx2).abs().max().item(), (lg2 - ref_lg2).abs().max().item()
+    print(f"[b8 full depth B={B} block 2 over 257 cached positions] ctx err {e_ctx2:.4f} / {budget(ref_ctx2):.4f}, "
+          f"logit err {e_lg2:.4f} / {budget(ref_lg2):.4f}")
+    assert e_ctx2 <= budget(ref_ctx2) and e_lg2 <= budget(ref_lg2)
+    assert torch.equal(got[rows, P + L], lg2.argmax(-1))
+    assert_tokens_within_noise(ref_lg2[:, None], got[rows, P + L:P + L + 1], BF16_REL, BF16_ABS, f"b8 B={B} block 2")
+    _, ref_blk1 = oracle_block_logits(o, prompt[rows], got[rows, P:P + L])
+    assert_tokens_within_noise(ref_blk1, got[rows, P:P + L], BF16_REL, BF16_ABS, f"b8 B={B} first block (8 token steps)")
     assert torch.equal(got[:, :P], prompt)
     assert int(got.min()) >= 0 and int(got.max()) < dims.vocab
     model.release_buffers()
@@ -1063,10 +1188,14 @@ def test_compaction_under_sampling_and_streamer(gpu_model, stream):
 
     class Rec:
         def __init__(self):
-            self.shapes = []
+            self.shapes, self.blocks = [], []          # blocks: (original rows, [token tensors]) per block
 
         def put(self, v):
             self.shapes.append(tuple(v.shape))
+            if v.dim() == 2:                           # the per-block placeholder: bt_rows was published just before it
+                self.blocks.append((self.bt_rows.clone(), []))
+            else:
+                self.blocks[-1][1].append(v.clone())
 
         def end(self):
             pass
@@ -1091,9 +1220,28 @@ def test_compaction_under_sampling_and_streamer(gpu_model, stream):
                 assert comp, "no compaction happened"
         assert torch.equal(outs[True], outs[False])
         if stream:
+            # ONE protocol: with or without compaction the streamer gets the reference's decode_mask rows of every block
+            # (model/block_transformer.py:389-398) -- the sequences unfinished when the block started, ascending original order --
+            # and their original row indices; both engines stream the same rows and the same tokens
             widths = [sh[0] for sh in recs[True].shapes]
-            assert widths[0] == B and min(widths) < B // 2 + 1, "the compacted engine streams its live rows only"
-            assert all(sh[0] == B for sh in recs[False].shapes)
+            assert widths[0] == B and min(widths) < B // 2 + 1, "finished sequences are not streamed"
+            assert recs[True].shapes == recs[False].shapes
+            full = outs[True]
+            unfinished = torch.ones(B, dtype=torch.bool)
+            for bi, ((rows_c, toks_c), (rows_m, toks_m)) in enumerate(zip(recs[True].blocks, recs[False].blocks)):
+                assert torch.equal(rows_c, rows_m) and torch.equal(rows_c, unfinished.nonzero().flatten()), f"block {bi}: rows"
+                blk = full[:, P + bi * L:P + (bi + 1) * L]
+                for ti, (a, b) in enumerate(zip(toks_c, toks_m)):
+                    assert torch.equal(a, b), f"block {bi} token {ti}: compacted and masked engines streamed different tokens"
+                # the streamed values are the raw draws; the output holds them up to and including a row's EOS (pad after it)
+                got = torch.stack(toks_c, 1)
+                want = blk[rows_c]
+                seen_eos = torch.zeros(len(rows_c), dtype=torch.bool)
+                for ti in range(got.shape[1]):
+                    keep = ~seen_eos
+                    assert torch.equal(got[keep, ti], want[keep, ti]), f"block {bi} token {ti}: stream != output for attributed rows"
+                    seen_eos |= got[:, ti] == eos
+                unfinished &= ~(blk == eos).any(1)
     finally:
         gcfg.update(do_sample=False, temperature=1.0)
         gcfg.eos_token_id = None

@@ -193,11 +193,23 @@ def _fake_sysfs(root, nodes):
     n_nodes = max(nodes) + 1
     per = max(1, len(allowed) // n_nodes)
     lists = {n: allowed[n * per:(n + 1) * per] or allowed[:1] for n in range(n_nodes)}
+    # card0 is the board's BMC VGA function (ASPEED, vendor 0x1a03): it has a numa_node file too and must NOT be counted as a GPU
+    # (ADVICE r4); the GPUs are card1 ..: the first two identified by PCI vendor 0x1002, the rest by their driver link
+    bmc = root / "class" / "drm" / "card0" / "device"
+    bmc.mkdir(parents=True)
+    (bmc / "numa_node").write_text("0\n")
+    (bmc / "local_cpulist").write_text(",".join(str(c) for c in allowed) + "\n")
+    (bmc / "vendor").write_text("0x1a03\n")
+    (root / "bus" / "pci" / "drivers" / "amdgpu").mkdir(parents=True)
     for i, node in enumerate(nodes):
-        d = root / "class" / "drm" / f"card{i}" / "device"
+        d = root / "class" / "drm" / f"card{i + 1}" / "device"
         d.mkdir(parents=True)
         (d / "numa_node").write_text(f"{node}\n")
         (d / "local_cpulist").write_text(",".join(str(c) for c in lists[node]) + "\n")
+        if i < 2:
+            (d / "vendor").write_text("0x1002\n")
+        else:
+            os.symlink(root / "bus" / "pci" / "drivers" / "amdgpu", d / "driver")
     (root / "class" / "drm" / "renderD128").mkdir()
     return lists
 
@@ -211,6 +223,10 @@ def test_numa_binding_from_sysfs(tmp_path):
     lists = _fake_sysfs(tmp_path, [0, 0, 1, 1] if len(os.sched_getaffinity(0)) >= 4 else [0, 0])
     node, cpus = parallel.gpu_numa_cpus(1, str(tmp_path))
     assert node == 0 and cpus == lists[0]
+    n_gpus = 4 if len(os.sched_getaffinity(0)) >= 4 else 2
+    assert parallel.gpu_numa_cpus(n_gpus, str(tmp_path)) == (None, [])       # the BMC card did not become a phantom GPU
+    if n_gpus == 4:
+        assert parallel.gpu_numa_cpus(3, str(tmp_path))[0] == 1               # identified through its amdgpu driver link
     code = (f"import os, sys; sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r});"
             f"from block_transformer_amd import parallel;"
             f"r = parallel.bind_to_gpu_numa_node(int(sys.argv[1]), 2, {str(tmp_path)!r});"
@@ -224,7 +240,7 @@ def test_numa_binding_from_sysfs(tmp_path):
     if len(lists[0]) >= 2:
         assert got[0] and got[1] and set(got[0]) | set(got[1]) <= set(lists[0]) and not set(got[0]) & set(got[1]), outs
     # no NUMA information -> untouched
-    (tmp_path / "class" / "drm" / "card0" / "device" / "numa_node").write_text("-1\n")
+    (tmp_path / "class" / "drm" / "card1" / "device" / "numa_node").write_text("-1\n")
     assert parallel.bind_to_gpu_numa_node(0, 1, str(tmp_path)) is None
     os.environ["BT_NO_NUMA_BIND"] = "1"
     try:
