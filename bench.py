@@ -552,13 +552,7 @@ def main():
                     help="seconds after process start beyond which no further secondary step is started (the line says how many ran)")
     ap.add_argument("--no-ceilings", action="store_true", help="skip the in-run empirical ceilings (copy kernel, MFMA loop) and the clock / power sampler")
     ap.add_argument("--no-graphs", action="store_true")
-    ap.add_argument("--pipeline", choices=["auto", "on", "off"], default="auto",
-                    help="two half-batch shards on two streams (global-attention / GEMM overlap, measured not to pay: DESIGN.md "
-                         "section 3); auto = off unless BT_PIPELINE=1")
     ap.add_argument("--cpu-sample", default="128,128", help="prefill,decode of the CPU baseline sample")
-    ap.add_argument("--two-branch", choices=["auto", "on", "off"], default="auto",
-                    help="large stacks: mlp.dense_h_to_4h on a second stream beside QKV / attention / dense (parallel residual); "
-                         "auto = the engine's default")
     ap.add_argument("--keep-logits", action="store_true",
                     help="materialise the [B, vocab] logits of every greedy step (A/B: the default feeds the argmax from the logits "
                          "GEMM's epilogue and never writes them, like HF generate with output_scores=False)")
@@ -594,10 +588,7 @@ def main():
     model = build_model(dims, args.dtype, device, args.seed)   # same weights on every rank (replicated)
     log("model built")
     model.use_graphs = not args.no_graphs
-    model.pipeline = {"auto": None, "on": True, "off": False}[args.pipeline]
     model.keep_logits = bool(args.keep_logits)
-    if args.two_branch != "auto":
-        model.two_branch = args.two_branch == "on"
     gen = torch.Generator().manual_seed(args.seed + 1000 * rank)
     input_ids = torch.randint(0, dims.vocab, (B, P), generator=gen).to(device)
 
@@ -652,9 +643,7 @@ def main():
                    "batch_per_gpu": B, "global_batch": B * world, "prefill": P, "decode": D, "block_length": L,
                    "batch_sizing": "fixed (--batch)" if args.batch > 0 else "auto: free HBM / bytes per sequence, cap 4096",
                    "parallelism": f"dp{world} request shards", "hipgraph": model.use_graphs,
-                   "half_batch_pipeline": bool(model._engine is not None and model._engine.pipelined),
-                   "logits_materialised": bool(model.keep_logits),
-                   "two_branch": bool(model._engine is not None and getattr(model._engine, "aux", None) is not None)},
+                   "logits_materialised": bool(model.keep_logits)},
     }
 
     if ceilings is not None:
@@ -696,11 +685,6 @@ def main():
         counts = algorithmic_counts(dims, B, P, D, itemsize)
         # section 8d decode-phase roofline of the TIMED configuration: both lower bounds against the measured decode time
         result["roofline_decode_phase"] = decode_phase_roofline(counts, decode_ms)
-        # kernels in isolation: single-stream engine (the half-batch pipeline overlaps kernels, which inflates per-kernel times)
-        was_pipeline = model.pipeline
-        if model._engine is not None and model._engine.pipelined:
-            model.pipeline = False
-            model.release_buffers()
         model.use_graphs = False
         _lib.prof_enable(True)
         model.generate(input_ids, max_length=max_length)
@@ -708,7 +692,6 @@ def main():
         fam = _lib.prof_collect()
         _lib.prof_enable(False)
         model.use_graphs = not args.no_graphs
-        model.pipeline = was_pipeline
         fam_ms = {k: round(v[0], 3) for k, v in fam.items() if v[1]}
         fam_n = {k: int(v[1]) for k, v in fam.items() if v[1]}
         result["kernel_family_ms"] = fam_ms

@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint64, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_uint32, c_uint64, c_void_p
 
 import torch  # noqa: F401  (must be imported first: libbt_hip.so binds to the HIP runtime torch already loaded)
 
@@ -38,7 +38,7 @@ class bt_decoder_weights(Structure):
 
 class bt_engine_desc(Structure):
     """include/bt_hip.h bt_engine_desc (field order and types must match the header exactly)."""
-    _fields_ = [("dtype", c_int32), ("L", c_int32), ("E", c_int32), ("vocab", c_int32), ("B", c_int64),
+    _fields_ = [("struct_size", c_uint32), ("dtype", c_int32), ("L", c_int32), ("E", c_int32), ("vocab", c_int32), ("B", c_int64),
                 ("bd_dims", bt_decoder_dims), ("bd_w", bt_decoder_weights),
                 ("td_dims", bt_decoder_dims), ("td_w", bt_decoder_weights),
                 ("emb_table", c_void_p), ("emb_width", c_int32), ("do_sample", c_int32),
@@ -58,13 +58,20 @@ class bt_engine_desc(Structure):
                 ("config_pad", c_int64), ("gen_eos", c_int64), ("gen_pad", c_int64),
                 ("row_map", c_void_p), ("aux_stream", c_void_p), ("ev_fork", c_void_p), ("ev_join", c_void_p), ("err_flag", c_void_p)]
 
+    def __init__(self, *args, **kw):
+        super().__init__(ctypes.sizeof(type(self)), *args, **kw)    # struct_size: the library rejects any other value
+
 
 class bt_attn_args(Structure):
-    _fields_ = [("k_cache", c_void_p), ("v_cache", c_void_p), ("layer_stride", c_int64), ("n_max", c_int64),
+    _fields_ = [("struct_size", c_uint32),
+                ("k_cache", c_void_p), ("v_cache", c_void_p), ("layer_stride", c_int64), ("n_max", c_int64),
                 ("pos0_dev", c_void_p), ("pos0_host", c_int32), ("pos_table", c_void_p), ("mask", c_void_p),
                 ("mask_ld", c_int64), ("cos_tab", c_void_p), ("sin_tab", c_void_p), ("mode", c_int32),
                 ("n_split", c_int32), ("split_ws", c_void_p), ("split_ws_bytes", c_int64), ("seq_skip", c_void_p),
                 ("aux_stream", c_void_p), ("ev_fork", c_void_p), ("ev_join", c_void_p)]
+
+    def __init__(self, *args, **kw):
+        super().__init__(ctypes.sizeof(type(self)), *args, **kw)    # struct_size first; positional fields follow as before
 
 
 _SIGS = {
@@ -88,6 +95,9 @@ _SIGS = {
                              c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_void_p]),
     "bt_linear2": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                            c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "bt_stream_k_scratch_bytes": (c_int64, []),
+    "bt_linear2_ws": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
+                              c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "bt_ln_qkv_rope_append": (c_int, [c_int, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p,
                                       c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                       c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -154,6 +164,8 @@ _DEBUG_SIGS = {
     "bt_debug_few_rows_max": (None, [c_int]),
     "bt_debug_no_few_rows_fusion": (None, [c_int]),
     "bt_debug_lin2_large": (None, [c_int]),
+    "bt_debug_lin2_sk": (None, [c_int]),
+    "bt_debug_stream_k": (None, [c_int]),
     "bt_debug_no_two_branch": (None, [c_int]),
     "bt_debug_ln_streaming": (None, [c_int]),
     "bt_debug_tr_probe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -225,6 +225,22 @@ int mid_res_ln(hipStream_t s, int64_t M, int64_t N, int64_t K1, const void* x1, 
                const void* ln1_b, void* ln1_out, const void* ln2_w, const void* ln2_b, void* ln2_out, int64_t ld_ln, float eps,
                void* slabs, int64_t slab_bytes);
 
+// ---- stream-K items GEMM (gemm.hip, round 5): scratch sizing / flag clearing, and the engine-side forms of the entry points that
+// may dispatch to it (`sk_clean`: the flag words of `scratch` are known to be zero -- bt_decoder_forward clears them once per pass)
+int64_t sk_scratch_bytes();
+bool sk_linear2_ok(int64_t M, int64_t N, int64_t K1, int64_t K2, int64_t scratch_bytes);
+int sk_clear_flags(void* scratch, int64_t scratch_bytes, hipStream_t s);
+int linear_ws_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* W, const void* bias,
+                   const void* residual, int64_t ldr, void* out, int64_t ldo, int act, void* scratch, int64_t scratch_bytes,
+                   bool sk_clean, bt_stream stream);
+int qkv_rope_append_impl(int dtype, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim, int32_t rot, const void* x, int64_t ldx,
+                         const void* qkv_w, const void* qkv_b, void* qkv, int64_t ld_qkv, void* k_cache, void* v_cache, int64_t n_max,
+                         const int32_t* pos0_dev, int32_t pos0_host, const int32_t* pos_table, const float* cos_tab,
+                         const float* sin_tab, void* scratch, int64_t scratch_bytes, bool sk_clean, bt_stream stream);
+int linear2_impl(int dtype, int64_t M, int64_t N, int64_t K1, const void* x1, int64_t ldx1, const void* W1, const void* bias1, int64_t K2,
+                 const void* x2, int64_t ldx2, const void* W2, const void* bias2, const void* residual, int64_t ldr, void* out,
+                 int64_t ldo, void* scratch, int64_t scratch_bytes, bool sk_clean, bt_stream stream);
+
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 inline size_t dtype_size(int dtype) { return dtype == BT_BF16 ? 2 : 4; }

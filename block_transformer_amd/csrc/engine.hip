@@ -33,19 +33,25 @@ static bool g_lin2_large = false;
 extern "C" void bt_debug_lin2_large(int on) { g_lin2_large = on != 0; }
 static bool g_no_two_branch = false;   // A/B: ignore bt_attn_args.aux_stream (run the parallel-residual branch on the main stream)
 extern "C" void bt_debug_no_two_branch(int on) { g_no_two_branch = on != 0; }
+// > 256 rows (round 5): attention.dense + dense_4h_to_h as ONE stream-K GEMM over K = I + H (gemm_bf16_mfma256sk_kernel; x read and
+// written once, one launch, 32-MFMA phases instead of the one-tile 256 x 128 kernel's 16): 0 = off (two launches, A/B), 1 = stacks of
+// up to 8192 rows (the decode steps: M = B and, token step 0, M = B * E), 2 = every stack incl. the prefill chunks
+static int g_lin2_sk = 1;
+extern "C" void bt_debug_lin2_sk(int mode) { g_lin2_sk = mode; }
 #else
 static constexpr int g_few_rows_max = 2;
 static constexpr bool g_no_few_rows_fusion = false;
 static constexpr bool g_lin2_large = false;
-static constexpr bool g_no_two_branch = false;
+static constexpr int g_lin2_sk = 1;
 #endif
 
 static int64_t ws_elems(const bt_decoder_dims* d, int64_t M) {
     return M * ((int64_t)d->hidden * 5 + d->inter);
 }
-// split-K scratch for skinny GEMMs (M <= 256 rows): up to 16 fp32 partial slabs of [M, inter]
+// GEMM scratch: split-K slabs for skinny GEMMs (M <= 256 rows: up to 16 fp32 partial slabs of [M, inter]); above that the
+// stream-K kernel's hand-off slabs + flag words (one 256 KiB slab per CU: 64 MiB on MI355X)
 static int64_t splitk_bytes(const bt_decoder_dims* d, int64_t M) {
-    return M <= 256 ? 16 * M * (int64_t)d->inter * 4 : 0;
+    return M <= 256 ? 16 * M * (int64_t)d->inter * 4 : sk_scratch_bytes();
 }
 
 extern "C" int64_t bt_decoder_workspace_bytes(const bt_decoder_dims* dims, int dtype, int64_t M) {
@@ -57,6 +63,9 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
                                   int32_t q_len, void* x, const bt_attn_args* attn, int32_t first_out_row, void* out,
                                   void* ws, int64_t ws_bytes, bt_stream stream) {
     BT_CHECK_ARG(dims && w && w->layers_host && attn && x && out && ws, "bt_decoder_forward: null pointer");
+    BT_CHECK_ARG(attn->struct_size == sizeof(bt_attn_args),
+                 "bt_decoder_forward: bt_attn_args.struct_size %u != %zu -- the caller was built against another bt_hip.h (this is %d)",
+                 attn->struct_size, sizeof(bt_attn_args), BT_VERSION);
     BT_CHECK_ARG(dtype == BT_F32 || dtype == BT_BF16, "bt_decoder_forward: bad dtype %d", dtype);
     BT_CHECK_ARG(B >= 0 && q_len > 0 && first_out_row >= 0 && first_out_row < q_len, "bt_decoder_forward: bad shape");
     BT_CHECK_ARG(dims->hidden == dims->heads * dims->head_dim, "bt_decoder_forward: hidden != heads*head_dim");
@@ -151,6 +160,10 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
                               more ? nx.ln2_b : nullptr, ln2, H, dims->ln_eps, scratch, slab_room));
         }
     }
+    // stream-K hand-off flags of the large-M GEMMs (QKV at M = 4096: 1.5 rounds of tiles; the fused residual projections): cleared
+    // once per pass, the kernels leave them zero -> the layers below pass sk_clean = true (no memset in front of every launch)
+    const bool sk_ws = !mid_rows && !few_rows && dtype == BT_BF16 && M > 256 && scratch && sk_bytes >= sk_scratch_bytes();
+    if (sk_ws) BT_TRY(sk_clear_flags(scratch, sk_bytes, (hipStream_t)stream));
     for (int l = 0; l < dims->layers && !mid_rows; ++l) {
         const bt_layer_weights& lw = w->layers_host[l];
         char* kc = reinterpret_cast<char*>(attn->k_cache) + (int64_t)l * attn->layer_stride * es;
@@ -213,23 +226,54 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
         // stream it is forked off here and joined in front of dense_4h_to_h; it then fills the CUs the QKV projection's last partial
         // round of tiles, the attention kernel and the 256-tile dense projection leave idle (same arithmetic, same order of the
         // residual updates: bit-identical results).  Only for large bf16 stacks (> 256 rows: the GEMMs fill the chip on their own).
-        const bool two_branch = !last && dtype == BT_BF16 && M > 256 && attn->aux_stream && attn->ev_fork && attn->ev_join &&
+        // one stream-K GEMM for both residual-stream projections (K = I + H), when the plan exists for this shape
+        const bool lin2_sk = !last && sk_ws && g_lin2_sk != 0 && (g_lin2_sk >= 2 || M <= 8192) && lw.h_b && lw.dense_b &&
+                             aligned16(lw.h_b) && aligned16(lw.dense_b) && aligned16(lw.h_w) && aligned16(lw.dense_w) && aligned16(x) &&
+                             sk_linear2_ok(M, H, I, H, sk_bytes);
+#ifdef BT_DEBUG_HOOKS   // measured negative in round 4 (-0.2 ... -0.3 % end to end): A/B and bit-identity test only, not in the product library
+        const bool two_branch = !last && !lin2_sk && dtype == BT_BF16 && M > 256 && attn->aux_stream && attn->ev_fork && attn->ev_join &&
                                 !g_lin2_large && !g_no_two_branch;
+#else
+        constexpr bool two_branch = false;
+#endif
         if (two_branch) {
             hipError_t fe = hipEventRecord((hipEvent_t)attn->ev_fork, (hipStream_t)stream);
             if (fe == hipSuccess) fe = hipStreamWaitEvent((hipStream_t)attn->aux_stream, (hipEvent_t)attn->ev_fork, 0);
             if (fe != hipSuccess) return bt::hip_fail(fe, "fork onto the second stream");
-            BT_TRY(bt_linear_ws(dtype, M, I, H, ln2, H, lw.h4_w, lw.h4_b, nullptr, 0, h4, I, BT_ACT_GELU, nullptr, 0, attn->aux_stream));
+            const int arc = bt_linear_ws(dtype, M, I, H, ln2, H, lw.h4_w, lw.h4_b, nullptr, 0, h4, I, BT_ACT_GELU, nullptr, 0, attn->aux_stream);
+            // whatever happened on the second stream, the join event is recorded: an error path below can always re-join it
             fe = hipEventRecord((hipEvent_t)attn->ev_join, (hipStream_t)attn->aux_stream);
-            if (fe != hipSuccess) return bt::hip_fail(fe, "hipEventRecord(join)");
+            if (arc != BT_OK || fe != hipSuccess) {
+                (void)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)attn->ev_join, 0);
+                if (arc != BT_OK) return arc;
+                return bt::hip_fail(fe, "hipEventRecord(join)");
+            }
         }
-        BT_TRY(bt_qkv_rope_append(dtype, B, q_len, dims->heads, dims->head_dim, dims->rot, ln1, H, lw.qkv_w, lw.qkv_b, qkv,
-                                  3 * H, kc, vc, attn->n_max, attn->pos0_dev, attn->pos0_host, attn->pos_table,
-                                  attn->cos_tab, attn->sin_tab, scratch, sk_bytes, stream));
+        // between the fork and the join a failing call must not return with the second stream still forked off the launch stream (an
+        // un-joined capture under hipGraph capture; in eager mode h4 would race the next layer): re-join first.  The aux
+        // stream and its two events belong to ONE engine and one host thread at a time (prefill and decode of an engine share them).
+#define BT_TRY_JOINED(expr)                                                                        \
+    do {                                                                                           \
+        const int rc__ = (expr);                                                                   \
+        if (rc__ != BT_OK) {                                                                       \
+            if (two_branch) (void)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)attn->ev_join, 0); \
+            return rc__;                                                                           \
+        }                                                                                          \
+    } while (0)
+        BT_TRY_JOINED(qkv_rope_append_impl(dtype, B, q_len, dims->heads, dims->head_dim, dims->rot, ln1, H, lw.qkv_w, lw.qkv_b, qkv,
+                                           3 * H, kc, vc, attn->n_max, attn->pos0_dev, attn->pos0_host, attn->pos_table,
+                                           attn->cos_tab, attn->sin_tab, scratch, sk_bytes, sk_ws, stream));
         if (!last) {
-            BT_TRY(attention_impl(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc,
-                                attn->n_max, attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H,
-                                attn->n_split, attn->split_ws, attn->split_ws_bytes, skip, stream));
+            BT_TRY_JOINED(attention_impl(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc,
+                                         attn->n_max, attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H,
+                                         attn->n_split, attn->split_ws, attn->split_ws_bytes, skip, stream));
+            if (lin2_sk) {
+                // h = gelu(LN2 W1^T + b1), then x += h W2^T + b2 + att Wd^T + bd as ONE stream-K GEMM over K = I + H
+                BT_TRY(linear_ws_impl(dtype, M, I, H, ln2, H, lw.h4_w, lw.h4_b, nullptr, 0, h4, I, BT_ACT_GELU, scratch, sk_bytes, true, stream));
+                BT_TRY(linear2_impl(dtype, M, H, I, h4, I, lw.h_w, lw.h_b, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, scratch, sk_bytes,
+                                    true, stream));
+                continue;
+            }
             const bool lin2_rows = g_lin2_large && dtype == BT_BF16 && M > 64 && H % 64 == 0 && I % 64 == 0 && lw.h_b &&
                                    lw.dense_b && aligned16(lw.h_b) && aligned16(lw.dense_b) && aligned16(lw.h_w) &&
                                    aligned16(lw.dense_w) && aligned16(x);
@@ -238,7 +282,8 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
                 BT_TRY(bt_linear_ws(dtype, M, I, H, ln2, H, lw.h4_w, lw.h4_b, nullptr, 0, h4, I, BT_ACT_GELU, scratch, sk_bytes, stream));
                 BT_TRY(bt_linear2(dtype, M, H, I, h4, I, lw.h_w, lw.h_b, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, stream));
             } else {
-                BT_TRY(bt_linear_ws(dtype, M, H, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, BT_ACT_NONE, scratch, sk_bytes, stream));
+                BT_TRY_JOINED(bt_linear_ws(dtype, M, H, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, BT_ACT_NONE, scratch, sk_bytes, stream));
+#undef BT_TRY_JOINED
                 if (two_branch) {   // the up-projection ran on the second stream beside QKV / attention / dense: join
                     hipError_t je = hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)attn->ev_join, 0);
                     if (je != hipSuccess) return bt::hip_fail(je, "hipStreamWaitEvent(join)");
@@ -297,6 +342,9 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
 // token-decoder-only user, e.g. GPTNeoXTokenDecoder.generate, leaves the block-decoder half of the descriptor empty)
 static int check_desc(const bt_engine_desc* e, const char* who, bool token_side, bool block_side) {
     BT_CHECK_ARG(e, "%s: null descriptor", who);
+    BT_CHECK_ARG(e->struct_size == sizeof(bt_engine_desc),
+                 "%s: bt_engine_desc.struct_size %u != %zu -- the caller was built against another bt_hip.h (this is %d)", who,
+                 e->struct_size, sizeof(bt_engine_desc), BT_VERSION);
     BT_CHECK_ARG(e->dtype == BT_F32 || e->dtype == BT_BF16, "%s: bad dtype %d", who, e->dtype);
     BT_CHECK_ARG(e->B >= 0 && e->L > 0 && e->E > 0 && e->vocab > 0, "%s: bad shape", who);
     BT_CHECK_ARG(e->ctx && e->raw, "%s: null ctx / raw buffer", who);
@@ -318,6 +366,7 @@ static int check_desc(const bt_engine_desc* e, const char* who, bool token_side,
 
 static bt_attn_args local_attn(const bt_engine_desc* e, int32_t pos0) {
     bt_attn_args a{};
+    a.struct_size = sizeof(a);
     a.k_cache = e->lk;
     a.v_cache = e->lv;
     a.layer_stride = e->l_layer_stride;
@@ -392,6 +441,7 @@ extern "C" int bt_roll_over_enqueue(const bt_engine_desc* e, bt_stream stream) {
     BT_TRY(bt_embed_rows(e->dtype, B * e->L, e->emb_width, e->raw, 1, e->vocab, e->emb_table, e->x_blk, e->emb_width,
                          e->finished_prev, e->L, stream));
     bt_attn_args a{};
+    a.struct_size = sizeof(a);
     a.k_cache = e->gk;
     a.v_cache = e->gv;
     a.layer_stride = e->g_layer_stride;
@@ -435,6 +485,7 @@ extern "C" int bt_prefill_enqueue(const bt_engine_desc* e, const int64_t* block_
                          e->emb_width, nullptr, 1, stream));
     const int64_t seq_off = b0 * e->bd_dims.heads * e->g_nmax * e->bd_dims.head_dim;   // elements of one layer's slab
     bt_attn_args a{};
+    a.struct_size = sizeof(a);
     a.k_cache = reinterpret_cast<char*>(e->gk) + seq_off * es;
     a.v_cache = reinterpret_cast<char*>(e->gv) + seq_off * es;
     a.layer_stride = e->g_layer_stride;

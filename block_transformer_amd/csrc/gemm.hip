@@ -1863,6 +1863,9 @@ struct Mma16 {
     }
 };
 
+#ifdef BT_DEBUG_HOOKS   // round 5: the 32x32 MFMA policy (measured 5-8 % slower) and the first-generation persistent
+                        // kernel (A/B reference of the second generation; its two-operand-pair form measured 4-7 % slower than two
+                        // launches) live in the debug library only -- the product binary carries what runs
 // 32x32 blocks: lane holds row m = lane & 31 of the block and, per q = 0..3, the 4 consecutive columns 8q + 4(lane >> 5) + r
 constexpr int EPI32_PITCH = 80;                  // 32 columns x 2 B + 16 pad
 constexpr int PP_EPI32_WAVE = 32 * EPI32_PITCH;  // 2.5 KiB per wave
@@ -2243,6 +2246,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp_kernel(const bf16* __
     }
     if (!grp1) cbarrier();
 }
+
+#endif  // BT_DEBUG_HOOKS (Mma32, first-generation persistent kernel)
 
 // ---- persistent kernel, second generation of the K-loop (round 3) --------------------------------------------------------------
 // Same tile walk, LDS ring, fragment mapping, MFMA order, per-wave epilogue and -- phase for phase -- the same vmcnt values as
@@ -2631,6 +2636,411 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         P::template epilogue<MODE, (ABL >> 5) & 3 | ((ABL >> 6) & 12) | ((ABL >> 12) & 16)>(ep, pos0, stage, acc, cm0, cn0 + wcol, wm, lane_e);
+    }
+    if (!grp1) cbarrier();
+}
+
+// ---- persistent kernel, stream-K items (round 5): the decode-shape GEMMs whose 256 x 256 tiles do not fill whole rounds ------------
+// The persistent kernel above gives a workgroup WHOLE tiles.  At M = 4096 that quantises badly exactly where the decode step
+// spends its GEMM time: the QKV projection is 384 tiles = 1.5 rounds (2 tile-times for 1.5 of work), and the two
+// projections onto the residual stream (N = 2048: 128 tiles) cannot use it at all -- they run on the one-tile 256 x 128 kernel
+// (16 MFMAs per phase instead of 32: 0.88 / 1.13 PF) as two launches.  Here the unit of work is an ITEM = (output tile, nk K-tiles
+// of its K range): a tile is C items ("chunks"), the T * C items are dealt out tile-major in equal contiguous runs of q = T * C / G
+// to the G resident workgroups (classic stream-K), and consecutive items of one tile CHAIN (the accumulators carry over: no
+// epilogue, no init between them).  A run that starts or ends inside a tile shares that tile with the neighbouring workgroup:
+//   * the workgroup holding the tile's FIRST chunks ends its chain early -> it PUBLISHES the fp32 accumulators (bias included) to a
+//     slab and raises a flag;  the workgroup holding the LAST chunks starts from zero, CONSUMES the slab (adds it) and runs the
+//     normal fused epilogue (bias / residual / RoPE + append) -- one tile is never shared by more than two workgroups (host check);
+//   * a workgroup walks its chains in REVERSE tile order: its publish chain (the tail of its run) FIRST, its consume chain (the head)
+//     LAST, so in a 1.5-round problem the partials are published one item-time into the launch and consumed at its very end: the
+//     hand-off is off the critical path (the consumer never waits);
+//   * hand-off per WAVE, no workgroup barrier (the two wave groups run half a phase apart; a barrier "for everyone" does not exist
+//     in this kernel): wave w of the consumer owns exactly the accumulator fragments wave w of the producer owns.  Producer wave:
+//     32 write-through (sc1) 16-byte stores per lane = its 128 x 64 fp32 block, s_waitcnt vmcnt(0), lane 0 stores the wave's flag
+//     (relaxed, agent scope).  Consumer wave: lane 0 polls that one word (relaxed, s_sleep, bounded), one agent-scope acquire,
+//     plain loads, add, flag back to zero.  (CDNA guide, Guideline 16 recipe R1.)  Virtual workgroup ids are XCD-contiguous, so a
+//     pair shares an L2 -- a speed bonus only.
+// A second operand pair (bt_linear2: attention.dense + mlp.dense_4h_to_h as ONE GEMM over K = H + I) is just a different base
+// pointer for the items whose chunk lies in the second K range: nothing of it lives in the K-loop (the first generation's two-pair
+// K-loop spilled scalars there and measured 4-7 % slower).
+// The K-loop, ring, waits and tile-boundary protocol are gemm_bf16_mfma256pp2_kernel's, item for tile (every item has nk K-tiles;
+// full tiles only: M % 256 == N % 256 == 0); an item that ends without stores leaves prev_full = false, a publish drains its
+// stores itself.  tests/test_gemm_ring_schedule.py runs the v2 hazard model over such item sequences.
+struct SkArgs {
+    const bf16* A2;      // second operand pair (items whose chunk starts at K-tile >= nk1), or unused when nk1 covers all of K
+    int64_t lda2;
+    const bf16* W2;
+    int64_t ldw2;
+    const bf16* bias2;   // second bias (the accumulators of a tile's first chunk start at bias + bias2)
+    int nk1;             // K-tiles of the first pair (a multiple of nk)
+    int C;               // chunks per output tile
+    int q;               // items per workgroup
+    int nk;              // K-tiles per item (>= 4)
+    float* slabs;        // [G][8 waves][32][64 lanes][4] fp32: slab vw = partial tile of virtual workgroup vw's consume chain
+    uint32_t* flags;     // [G][8] one word per (consumer workgroup, wave), zero at launch and left zero; + [8 G] sticky timeout word
+};
+constexpr int SK_SLAB_FLOATS = 8 * 32 * 64 * 4;          // 256 KiB per workgroup
+constexpr uint32_t SK_SPIN_LIMIT = 1u << 20;              // polls (x ~1 us) before a consumer gives up and flags the launch
+
+// flag words of the hand-off (wave-uniform addresses): relaxed agent-scope accesses = `sc1` loads / stores (CDNA guide, visibility
+// table).  Inline asm with its own zero offset register: the compiler's form kept that zero in a VGPR across the K-loop, spilled it,
+// and reloaded it from scratch (+ vmcnt(0)) on every poll.
+__device__ inline uint32_t sk_flag_load(const uint32_t* p) {      // every lane reads the same word
+    uint32_t v;
+    asm volatile("v_mov_b32 %0, 0\n\tglobal_load_dword %0, %0, %1 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "s"(p) : "memory");
+    return __builtin_amdgcn_readfirstlane(v);
+}
+__device__ inline void sk_flag_store(uint32_t* p, uint32_t value) {   // every lane stores the same value to the same word
+    uint32_t z, d;
+    asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, %3\n\tglobal_store_dword %0, %1, %2 sc1" : "=&v"(z), "=&v"(d) : "s"(p), "s"(value) : "memory");
+}
+
+struct SkWalk {          // wave-uniform: the items of this workgroup's run [lo, lo + q), chains in reverse tile order
+    int tile, c, cs, ce; // current tile, current chunk, first / end chunk of the current chain
+    int m0, n0;
+    __device__ inline void coords(int tiles_m, int tiles_n) {
+        const int group_sz = GROUP_M2 * tiles_n;
+        const int g = tile / group_sz;
+        const int first_m = g * GROUP_M2;
+        const int gm = min(tiles_m - first_m, GROUP_M2);
+        const int in_g = tile - g * group_sz;
+        m0 = (first_m + in_g % gm) * BM2;
+        n0 = (in_g / gm) * BN2;
+    }
+    __device__ inline void start(int lo, int hi, int C, int tiles_m, int tiles_n) {
+        tile = (hi - 1) / C;
+        cs = max(lo - tile * C, 0);
+        ce = hi - tile * C;
+        c = cs;
+        coords(tiles_m, tiles_n);
+    }
+    __device__ inline void next(int lo, int C, int tiles_m, int tiles_n) {   // (the caller counts items: never called past the run)
+        if (++c == ce) {
+            --tile;
+            ce = C;
+            cs = max(lo - tile * C, 0);
+            c = cs;
+            coords(tiles_m, tiles_n);
+        }
+    }
+    __device__ inline bool chain_first() const { return c == cs; }
+    __device__ inline bool chain_last() const { return c == ce - 1; }
+};
+
+template <int MODE>
+__global__ __launch_bounds__(512) void gemm_bf16_mfma256sk_kernel(const bf16* __restrict__ A, int64_t lda,
+                                                                 const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
+                                                                 int tiles_m, int tiles_n, const SkArgs sk) {
+    typedef Mma16 P;
+    __shared__ __attribute__((aligned(16))) char smem[PP_SMEM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int wh = wn >> 1;
+    const int wrow = (wn & 1) * 64;
+    const int wcol = wh * 128 + wrow;
+    const bool grp1 = wave >= 4;
+    char* stage = smem + PP_EPI_OFF + wave * P::PATCH_BYTES;
+    uint32_t voff_a = 0, voff_w = 0, row8_a = 0, row8_w = 0;   // of the load cursor's item (its operand pair's row pitch)
+    const uint32_t ring_lds = lds_addr(smem) + (uint32_t)wave * 2048u;
+
+    const int nk = sk.nk, nt = sk.q, C = sk.C;
+    const int total = 4 * nk * nt;
+    const int G = gridDim.x;
+    const int vw = (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);   // XCD-contiguous virtual id (G % 8 == 0)
+    const int lo = vw * nt;
+
+    // ---- load cursor (wave-uniform) ----
+    SkWalk lw;
+    lw.start(lo, lo + nt, C, tiles_m, tiles_n);
+    int lt = 0, lj = 0, lx = 0;
+    bool lvalid = true, lbias = false;
+    const char *pa0 = nullptr, *pa1 = nullptr, *pw0 = nullptr, *pw1 = nullptr;
+    auto enter_item = [&]() {   // the cursor stands at K-tile 0 of item lw
+        const int kt0 = lw.c * nk;
+        const bool second = kt0 >= sk.nk1;
+        const bf16* Ap = second ? sk.A2 : A;
+        const bf16* Wp = second ? sk.W2 : W;
+        const int64_t la = second ? sk.lda2 : lda, lwd = second ? sk.ldw2 : ldw;
+        const int64_t kb = (int64_t)(second ? kt0 - sk.nk1 : kt0) * (BK * 2);
+        pa0 = reinterpret_cast<const char*>(Ap) + (int64_t)(lw.m0 + wave * 16) * la * 2 + kb;
+        pa1 = pa0 + (int64_t)128 * la * 2;
+        pw0 = reinterpret_cast<const char*>(Wp) + (int64_t)(lw.n0 + wave * 16) * lwd * 2 + kb;
+        pw1 = pw0 + (int64_t)128 * lwd * 2;
+        // lane part of a DMA address, recomputed from the lane id per item (volatile asm: a value the compiler could hoist would sit
+        // in two VGPRs through the K-loop, which has none to spare -- it spilled them to scratch, and a scratch reload is a VMEM op
+        // the compiler fences with vmcnt(0), i.e. a drain of the whole DMA ring)
+        uint32_t ln;
+        asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+        const uint32_t lane_slot = ((ln & 7u) ^ ((ln >> 3) & 7u)) * 16u;
+        const uint32_t lane_row = ln >> 3;
+        voff_a = lane_row * (uint32_t)(la * 2) + lane_slot;
+        voff_w = lane_row * (uint32_t)(lwd * 2) + lane_slot;
+        row8_a = (uint32_t)(8 * la * 2);
+        row8_w = (uint32_t)(8 * lwd * 2);
+        lbias = lw.chain_first() && lw.c == 0 && ep.bias != nullptr;
+    };
+    enter_item();
+    auto issue1 = [&](auto kc, bool check_valid) {
+        if (check_valid && !lvalid) return;
+        constexpr int kind = decltype(kc)::value;
+        const uint32_t ring = ring_lds + (uint32_t)(lx & 1) * (4u * HALF_BYTES);
+        constexpr bool is_a = (kind == 0) || (kind == 3);
+        constexpr int half = (kind >= 2) ? 1 : 0;
+        constexpr int off = ((is_a ? 0 : 2) + half) * HALF_BYTES;
+        const char* base = is_a ? (half ? pa1 : pa0) : (half ? pw1 : pw0);
+        const uint32_t v0 = is_a ? voff_a : voff_w;
+        glds16_sbase_off<off>(base, v0, ring);
+        glds16_sbase_off<off + 1024>(base, v0 + (is_a ? row8_a : row8_w), ring);
+    };
+    auto issue2 = [&](auto k0c, auto k1c, bool check_valid) {
+        issue1(k0c, check_valid);
+        issue1(k1c, check_valid);
+    };
+    // wave 0: the tile's bias row(s) -> LDS row (lj & 1), only for an item that starts its tile (chunk 0): lanes 0..31 fetch
+    // bias[n0 .. n0 + 255], lanes 32..63 the second pair's bias (or the same bytes again)
+    const bf16* bias_hi = sk.bias2 ? sk.bias2 : ep.bias;
+    auto issue_bias = [&]() {
+        if (wave == 0 && lbias && lvalid)
+            glds16_vaddr((lane < 32 ? ep.bias : bias_hi) + lw.n0 + (lane & 31) * 8, lds_addr(smem + PP_BIAS_OFF + (lj & 1) * 1024));
+    };
+    auto advance = [&]() {
+        ++lx;
+        voff_a += 128;
+        voff_w += 128;
+        if (++lt == nk) {
+            lt = 0;
+            ++lj;
+            lvalid = lj < nt;
+            if (lvalid) {
+                lw.next(lo, C, tiles_m, tiles_n);
+                enter_item();
+            }
+        }
+    };
+    auto issue1_fast = [&](auto kc, auto rc) {
+        constexpr int kind = decltype(kc)::value, RING = decltype(rc)::value;
+        constexpr bool is_a = (kind == 0) || (kind == 3);
+        constexpr int half = (kind >= 2) ? 1 : 0;
+        constexpr int off = RING * 4 * HALF_BYTES + ((is_a ? 0 : 2) + half) * HALF_BYTES;
+        const char* base = is_a ? (half ? pa1 : pa0) : (half ? pw1 : pw0);
+        const uint32_t v0 = is_a ? voff_a : voff_w;
+        glds16_sbase_off<off>(base, v0, ring_lds);
+        glds16_sbase_off<off + 1024>(base, v0 + (is_a ? row8_a : row8_w), ring_lds);
+    };
+    auto advance_fast = [&]() {
+        ++lx;
+        ++lt;
+        pa0 += 128;
+        pa1 += 128;
+        pw0 += 128;
+        pw1 += 128;
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+    using IDyn = std::integral_constant<int, -1>;
+    // prologue: K-tile 0 (4 half-tiles) + K-tile 1 (A0, W0) = PD2 loads  (nk >= 4: K-tile 1 belongs to the same item)
+    issue_bias();
+    issue2(I0{}, I1{}, true);
+    issue2(I2{}, I3{}, true);
+    advance();
+    issue2(I0{}, I1{}, true);
+
+    typename P::Acc acc[2 * P::MI][P::NB];
+    bf16x8_t af[P::MI][P::KS];
+    bf16x8_t wf[P::NB][P::KS];
+    int pos0 = 0;
+    if (MODE == PP_QKV) pos0 = __builtin_amdgcn_readfirstlane(ep.q.pos0_dev ? *ep.q.pos0_dev : ep.q.pos0_host);
+
+    if (grp1) {
+        wait_for_phase_pp(0, total, false);
+        cbarrier();
+    }
+    int g = 0;
+    bool prev_full = false;
+    bool pre_issued = false;
+    // ---- compute cursor ----
+    SkWalk cw;
+    cw.start(lo, lo + nt, C, tiles_m, tiles_n);
+    bool c_init = true, c_bias = false;      // of the compute cursor's item: start a chain (accumulators <- bias rows, or zero)
+    auto phase = [&](auto pc, auto pmc, int t, int j, auto stc) {
+        constexpr int p = decltype(pc)::value, PM = decltype(pmc)::value, ST = decltype(stc)::value;
+        static_assert(ST < 0 || PM == 1, "fast K-tiles are steady-state K-tiles");
+        if (!grp1) {
+            if constexpr (PM == 2) {
+                wait_for_phase_pp(g, total, false);
+            } else if constexpr (PM == 0) {
+                if (prev_full) wait_vmcnt_pp<(p ? PP2_WAIT_P1 : PP2_WAIT_P0) + PP_STORES>();
+                else wait_vmcnt<(p ? PP2_WAIT_P1 : PP2_WAIT_P0)>();
+            } else {
+                wait_vmcnt<(p ? PP2_WAIT_P1 : PP2_WAIT_P0)>();
+            }
+        }
+        cbarrier();
+        const char* buf = smem + (ST >= 0 ? ST * 4 * HALF_BYTES : (g & 2) * 2 * HALF_BYTES);
+        if constexpr (p == 0) {
+            if constexpr (PM == 0) {
+                if (t == 0 && c_init)
+                    P::init(acc, c_bias, c_bias && sk.bias2 != nullptr, lds_addr(smem + PP_BIAS_OFF + (j & 1) * 1024), wcol, lane);
+            }
+#pragma unroll
+            for (int ks = 0; ks < P::KS; ++ks) {
+#pragma unroll
+                for (int nb = 0; nb < P::NB; ++nb) wf[nb][ks] = P::read_w(buf + (2 + wh) * HALF_BYTES, wrow, nb, ks, lane);
+#pragma unroll
+                for (int i = 0; i < P::MI; ++i) af[i][ks] = P::read_a(buf, wm, i, ks, lane);
+            }
+            if constexpr (ST >= 0) {     // the cursor stands one K-tile ahead: the other ring stage
+                issue1_fast(I2{}, std::integral_constant<int, 1 - ST>{});
+                issue1_fast(I3{}, std::integral_constant<int, 1 - ST>{});
+                advance_fast();
+            } else if (PM == 0 && t == 0 && pre_issued) {
+                pre_issued = false;          // issued at the item boundary
+            } else {
+                issue2(I2{}, I3{}, PM == 2);
+                advance();
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < P::KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < P::MI; ++i) af[i][ks] = P::read_a(buf + HALF_BYTES, wm, i, ks, lane);
+            if constexpr (ST >= 0) {     // two K-tiles ahead: this K-tile's own stage
+                issue1_fast(I0{}, std::integral_constant<int, ST>{});
+                issue1_fast(I1{}, std::integral_constant<int, ST>{});
+            } else {
+                if (lt == 0) issue_bias();
+                issue2(I0{}, I1{}, PM == 2);
+            }
+        }
+        if (grp1) {   // group 1 waits for the data of phase g + 1 before the barrier that opens it for group 0
+            if constexpr (PM == 2) {
+                wait_for_phase_pp(g + 1, total, false);
+            } else if constexpr (PM == 0) {
+                if (prev_full && !(t == 1 && p == 1)) wait_vmcnt_pp<(p == 0 ? PP2_WAIT_P1 : PP2_WAIT_P0) + PP_STORES>();
+                else wait_vmcnt<(p == 0 ? PP2_WAIT_P1 : PP2_WAIT_P0)>();
+            } else {
+                wait_vmcnt<(p == 0 ? PP2_WAIT_P1 : PP2_WAIT_P0)>();
+            }
+        }
+        cbarrier();
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < P::KS; ++ks)
+#pragma unroll
+            for (int i = 0; i < P::MI; ++i)
+#pragma unroll
+                for (int nb = 0; nb < P::NB; ++nb) acc[p * P::MI + i][nb] = P::mma(wf[nb][ks], af[i][ks], acc[p * P::MI + i][nb]);
+        ++g;
+    };
+    for (int j = 0; j < nt; ++j) {
+        c_init = cw.chain_first();
+        c_bias = c_init && cw.c == 0 && ep.bias != nullptr;
+        const int t_gen = (j == nt - 1) ? nk - 2 : nk;
+        phase(I0{}, I0{}, 0, j, IDyn{});
+        phase(I1{}, I0{}, 0, j, IDyn{});
+        phase(I0{}, I0{}, 1, j, IDyn{});
+        phase(I1{}, I0{}, 1, j, IDyn{});
+        int t = 2;
+        {
+            if ((g & 2) && t <= nk - 3) {
+                phase(I0{}, I1{}, t, j, IDyn{});
+                phase(I1{}, I1{}, t, j, IDyn{});
+                ++t;
+            }
+            for (; t + 1 <= nk - 3; t += 2) {
+                phase(I0{}, I1{}, t, j, I0{});
+                phase(I1{}, I1{}, t, j, I0{});
+                phase(I0{}, I1{}, t + 1, j, I1{});
+                phase(I1{}, I1{}, t + 1, j, I1{});
+            }
+        }
+        for (; t < t_gen; ++t) {
+            phase(I0{}, I1{}, t, j, IDyn{});
+            phase(I1{}, I1{}, t, j, IDyn{});
+        }
+        for (; t < nk; ++t) {
+            phase(I0{}, I2{}, t, j, IDyn{});
+            phase(I1{}, I2{}, t, j, IDyn{});
+        }
+        const bool last = cw.chain_last();
+        const bool publish = last && cw.ce != C;          // the chain ends inside its tile: the neighbour finishes the tile
+        const bool consume = last && !publish && cw.cs != 0;   // the chain began inside its tile: add the neighbour's partial first
+        prev_full = last && !publish;                      // a normal epilogue follows: >= PP_STORES stores per wave
+        if (MODE == PP_ARGMAX && ep.out == nullptr) prev_full = false;
+        if (j + 1 < nt) {
+            // item boundary: W1 / A1 of the next item's K-tile 1 go out ahead of whatever this item stores (see the v2 kernel)
+            cbarrier();
+            issue2(I2{}, I3{}, false);
+            advance();
+            pre_issued = true;
+        } else {
+            prev_full = false;
+        }
+        const int cm0 = cw.m0, cn0 = cw.n0;
+        if (j + 1 < nt) cw.next(lo, C, tiles_m, tiles_n);
+        if (!last) continue;                               // the next item continues this tile in the same accumulators
+        if (publish) {
+            // this wave's 128 x 64 fp32 block -> slab of the consumer (the next virtual workgroup), write-through, then its flag
+            float* slab = sk.slabs + ((int64_t)(vw + 1) * 8 + wave) * (32 * 64 * 4);
+            const __amdgpu_buffer_rsrc_t srs = tile_rsrc(reinterpret_cast<const char*>(slab));
+            const uint32_t svoff = (uint32_t)lane * 16u;
+#pragma unroll
+            for (int i = 0; i < 2 * P::MI; ++i)
+#pragma unroll
+                for (int nb = 0; nb < P::NB; ++nb) {
+                    const f32x4_t v = acc[i][nb];
+                    __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
+                                                                   __float_as_uint(v[3])},
+                                                           srs, svoff, (uint32_t)((i * P::NB + nb) * 1024), 16 /* sc1: write-through */);
+                }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every store of this wave has left the CU (and the loads issued before them)
+            sk_flag_store(sk.flags + (int64_t)(vw + 1) * 8 + wave, 1u);
+            continue;
+        }
+        if (consume) {
+            uint32_t* flag = sk.flags + (int64_t)vw * 8 + wave;
+            uint32_t seen = 0;
+            for (uint32_t spins = 0; spins < SK_SPIN_LIMIT; ++spins) {
+                seen = sk_flag_load(flag);
+                if (seen != 0) break;
+                __builtin_amdgcn_s_sleep(8);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (seen == 0)    // the producer never arrived (cannot happen with G resident workgroups): flag the launch, go on
+                sk_flag_store(sk.flags + (int64_t)G * 8, 1u);
+            const float* slab = sk.slabs + ((int64_t)vw * 8 + wave) * (32 * 64 * 4);
+            const __amdgpu_buffer_rsrc_t srs = tile_rsrc(reinterpret_cast<const char*>(slab));
+            uint32_t svoff = (uint32_t)lane * 16u;
+            // two batches of 16 loads (64 transient registers = the K-loop's dead fragment registers); the scheduling barriers keep
+            // the compiler from hoisting all 32 loads in front of the first add (128 transient registers: it spilled)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                u32x4_t pv[P::MI][P::NB];
+#pragma unroll
+                for (int i = 0; i < P::MI; ++i)
+#pragma unroll
+                    for (int nb = 0; nb < P::NB; ++nb)
+                        pv[i][nb] = __builtin_amdgcn_raw_buffer_load_b128(srs, svoff, (uint32_t)(((h * P::MI + i) * P::NB + nb) * 1024), 0);
+#pragma unroll
+                for (int i = 0; i < P::MI; ++i)
+#pragma unroll
+                    for (int nb = 0; nb < P::NB; ++nb) {
+                        acc[h * P::MI + i][nb][0] += __uint_as_float(pv[i][nb].x);
+                        acc[h * P::MI + i][nb][1] += __uint_as_float(pv[i][nb].y);
+                        acc[h * P::MI + i][nb][2] += __uint_as_float(pv[i][nb].z);
+                        acc[h * P::MI + i][nb][3] += __uint_as_float(pv[i][nb].w);
+                    }
+                // the second batch's address "depends" on a sum of the first: its loads cannot be issued ahead of the first adds
+                asm volatile("" : "+v"(svoff) : "v"(acc[h * P::MI + P::MI - 1][P::NB - 1][3]) : "memory");
+            }
+            sk_flag_store(flag, 0u);   // ready for the next launch
+        }
+        int lane_e = lane;
+        asm volatile("" : "+v"(lane_e));
+        P::template epilogue<MODE>(ep, pos0, stage, acc, cm0, cn0 + wcol, wm, lane_e);
     }
     if (!grp1) cbarrier();
 }
@@ -3840,6 +4250,9 @@ BT_KNOB bool g_few_attn = false;
 BT_KNOB bool g_few_persist = true;   // <= 2 rows: the [QKV | h->4h] launch as ~2 resident workgroups per CU walking the row groups (false: A/B)
 BT_KNOB bool g_few_dual = true;   // <= 4 rows: QKV and h->4h GEMVs of a layer in one launch (false: two launches, A/B)
 BT_KNOB int g_small_stages = 0;   // LDS ring depth of the 128^2 / 128x64 / 64x64 kernels: 0 = per-tile default, 2..4 forced (A/B)
+// stream-K items kernel (gemm_bf16_mfma256sk_kernel, round 5) for full-tile problems whose 256 x 256 tiles leave the persistent
+// kernel's last round under 90 % full, and for bt_linear2 above 256 rows: 1 = on (needs the caller's scratch: slabs + flags), 0 = A/B
+BT_KNOB int g_sk = 1;
 BT_KNOB int g_gemm_variant = 0;   // 0 auto; 1 force 128^2; 2/3 256^2 four-phase ring (plain/staggered); 4-8 timing ablations; 9/10 256^2
 // two-phase ring, one tile per workgroup (staggered/plain); 14 persistent on 32x32x16 MFMA; default: persistent two-phase ring.
 
@@ -3847,13 +4260,63 @@ BT_KNOB int g_gemm_variant = 0;   // 0 auto; 1 force 128^2; 2/3 256^2 four-phase
 
 using namespace bt;
 
+// ---- stream-K items plan (gemm_bf16_mfma256sk_kernel) --------------------------------------------------------------------------
+// T output tiles x C chunks of nk K-tiles, dealt tile-major in runs of q to G workgroups.  Picks the LARGEST nk (fewest item
+// boundaries) for which the items divide evenly, an item never straddles the two operand pairs, and no tile is shared by more than
+// two workgroups (the kernel's hand-off is pairwise).  ok = false: the problem stays on the other kernels.
+struct SkPlan {
+    bool ok;
+    int nk, C, q, G;
+};
+static SkPlan sk_plan(int64_t M, int64_t N, int64_t K1, int64_t K2, int G) {
+    SkPlan p{false, 0, 0, 0, G};
+    if (G < 8 || G % 8 != 0 || M % BM2 != 0 || N % BN2 != 0 || K1 % BK != 0 || K2 % BK != 0 || K1 <= 0) return p;
+    const int64_t T = (M / BM2) * (N / BN2);
+    const int nk1 = (int)(K1 / BK), nkt = (int)((K1 + K2) / BK);
+    if (T < G / 2 || T > (1 << 20)) return p;
+    for (int C = 1; C <= nkt / 4; ++C) {
+        if (nkt % C != 0 || (T * C) % G != 0) continue;
+        const int nk = nkt / C;
+        if (nk < 4 || nk1 % nk != 0) continue;
+        const int64_t q = T * C / G;
+        if (q < 1 || q > (1 << 20)) continue;
+        bool pairwise = true;
+        for (int64_t t = 0; t < T && pairwise; ++t) pairwise = ((t * C + C - 1) / q - (t * C) / q) <= 1;
+        if (!pairwise) continue;
+        p.ok = true;
+        p.nk = nk;
+        p.C = C;
+        p.q = (int)q;
+        return p;
+    }
+    return p;
+}
+static int64_t sk_ws_bytes(int G) { return (int64_t)G * SK_SLAB_FLOATS * 4 + ((int64_t)G * 8 + 8) * 4; }
+namespace bt {
+// scratch layout of the stream-K kernel: [G slabs of 256 KiB][G * 8 + 1 flag words]; bt_decoder_forward sizes its scratch for it
+// (engine.hip) and clears the flag words once per pass with sk_clear_flags(); the kernels leave them zero
+int64_t sk_scratch_bytes() { return sk_ws_bytes(num_cus()); }
+// does bt_linear2 (M rows, N outputs, operand pairs of K1 and K2) run as ONE stream-K GEMM with this much scratch?
+bool sk_linear2_ok(int64_t M, int64_t N, int64_t K1, int64_t K2, int64_t scratch_bytes) {
+    const int G = num_cus();
+    return g_sk != 0 && M > 256 && scratch_bytes >= sk_ws_bytes(G) && sk_plan(M, N, K1, K2, G).ok;
+}
+int sk_clear_flags(void* scratch, int64_t scratch_bytes, hipStream_t s) {
+    const int G = num_cus();
+    if (!scratch || scratch_bytes < sk_ws_bytes(G)) return BT_OK;
+    hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(scratch) + (int64_t)G * SK_SLAB_FLOATS * 4, 0, ((size_t)G * 8 + 8) * 4, s);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(stream-K flags)");
+    return BT_OK;
+}
+}  // namespace bt
+
 // amax (bt_logits_argmax): when the persistent kernel takes the problem, run its PP_ARGMAX epilogue (per-slab argmax partials
 // into amax[M][amax_ld]; the logits tile is stored only if store_out) and report it through *amax_done
 static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* W,
                        const void* bias, const void* residual, int64_t ldr, void* out, int64_t ldo, int act,
                        const QkvEpi* qkv, bool* fused_out, bt_stream stream, void* scratch = nullptr,
                        int64_t scratch_bytes = 0, const Seg2* seg2 = nullptr, uint2* amax = nullptr, int amax_ld = 0,
-                       bool store_out = true, bool* amax_done = nullptr) {
+                       bool store_out = true, bool* amax_done = nullptr, bool sk_clean = false) {
     // seg2 (bt_linear2, > 64 rows): a second (x2, W2, bias2) operand pair accumulated into the same output tiles; only
     // the persistent 256^2 kernel and the non-split small-tile family take it -> BT_ERR_UNSUPPORTED otherwise
     BT_CHECK_ARG(dtype == BT_F32 || dtype == BT_BF16, "bt_linear: bad dtype %d", dtype);
@@ -3899,6 +4362,45 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
             ep.q = *qkv;
             ep.q.enabled = 1;
             if (fused_out) *fused_out = true;
+        }
+        // stream-K items kernel: full 256 x 256 tiles whose count leaves the persistent kernel's last round under 90 % full
+        // (M = 4096 QKV: 384 tiles = 1.5 rounds), and every two-pair problem (bt_linear2 above 256 rows: attention.dense +
+        // dense_4h_to_h as ONE K = H + I GEMM; M = 4096: 128 tiles x 10 chunks over 256 workgroups).  Needs the caller's scratch.
+        if (g_sk && mfma_ok && g_gemm_variant == 0 && scratch && aligned16(scratch) && M > 256 && (ldo % 8 == 0) && aligned16(out) &&
+            (!residual || (ldr % 8 == 0 && aligned16(residual))) && (!bias || aligned16(bias)) && !amax &&
+            (act == BT_ACT_NONE || !residual)) {
+            const int G = num_cus();
+            const int64_t T = (M / BM2) * (N / BN2);
+            // (at least one full round plus a remainder: problems below one round keep the one-tile kernels)
+            const bool ragged = T > G && (T % G) != 0 && (double)T / (double)(ceil_div(T, G) * G) < 0.9;
+            const SkPlan pl = (seg2 || ragged) && scratch_bytes >= sk_ws_bytes(G) ? sk_plan(M, N, K, s2.K, G) : SkPlan{false, 0, 0, 0, G};
+            if (pl.ok) {
+                ProfScope ps(BT_PROF_LINEAR_MFMA, s);
+                SkArgs sk{};
+                sk.A2 = s2.x;
+                sk.lda2 = s2.ldx;
+                sk.W2 = s2.w;
+                sk.ldw2 = s2.ldw;
+                sk.bias2 = s2.bias;
+                sk.nk1 = (int)(K / BK);
+                sk.C = pl.C;
+                sk.q = pl.q;
+                sk.nk = pl.nk;
+                sk.slabs = reinterpret_cast<float*>(scratch);
+                sk.flags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(scratch) + (int64_t)G * SK_SLAB_FLOATS * 4);
+                if (!sk_clean) BT_TRY(bt::sk_clear_flags(scratch, scratch_bytes, s));
+                const int tiles_m = (int)(M / BM2), tiles_n = (int)(N / BN2);
+#define BT_LAUNCH_SK(MODE_)                                                                                                  \
+    hipLaunchKernelGGL((gemm_bf16_mfma256sk_kernel<MODE_>), dim3(G), dim3(512), 0, s, (const bf16*)A, lda, (const bf16*)W, K, ep, \
+                       tiles_m, tiles_n, sk)
+                if (ep.q.enabled) BT_LAUNCH_SK(PP_QKV);
+                else if (act == BT_ACT_GELU) BT_LAUNCH_SK(PP_GELU);
+                else if (residual) BT_LAUNCH_SK(PP_RES);
+                else BT_LAUNCH_SK(PP_PLAIN);
+#undef BT_LAUNCH_SK
+                BT_LAUNCH_CHECK("bt_linear stream-K launch");
+                return BT_OK;
+            }
         }
         const int64_t tiles256 = ceil_div(M, BM2) * ceil_div(N, BN2);
         // big-tile kernel: one 8-wave workgroup per CU -> needs >= ~3/4 of a wave of 256 tiles and little tail quantisation
@@ -4036,9 +4538,13 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
         hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A, lda,      \
                            (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                          \
     } while (0)
+#ifdef BT_DEBUG_HOOKS
 #define BT_LAUNCH_PP2(MODE_)                                                                                          \
     hipLaunchKernelGGL((gemm_bf16_mfma256pp_kernel<MODE_, Mma16, true>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,   \
                        lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n, s2)
+#else   // (unreachable in the product library: linear2_impl never sends a two-pair problem to the 256 x 256 dispatch)
+#define BT_LAUNCH_PP2(MODE_) do { set_error("bt_linear2: two-pair 256 x 256 kernel is a debug-build A/B kernel"); return BT_ERR_UNSUPPORTED; } while (0)
+#endif
                         // (the engine never combines these: QKV has no activation / residual, GELU has no residual)
                         if (seg2 && residual) BT_LAUNCH_PP2(PP_RES);
                         else if (seg2) BT_LAUNCH_PP2(PP_PLAIN);
@@ -4255,12 +4761,31 @@ extern "C" int bt_linear_ws(int dtype, int64_t M, int64_t N, int64_t K, const vo
     return linear_impl(dtype, M, N, K, A, lda, W, bias, residual, ldr, out, ldo, act, nullptr, nullptr, stream, scratch,
                        scratch_bytes);
 }
+namespace bt {
+// engine-side forms (engine.hip): the same calls with `sk_clean` = the stream-K flag words of `scratch` are known to be zero
+// (bt_decoder_forward clears them once per pass; the kernels leave them zero) -> no memset in front of every launch
+int linear_ws_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* W, const void* bias,
+                   const void* residual, int64_t ldr, void* out, int64_t ldo, int act, void* scratch, int64_t scratch_bytes,
+                   bool sk_clean, bt_stream stream) {
+    return linear_impl(dtype, M, N, K, A, lda, W, bias, residual, ldr, out, ldo, act, nullptr, nullptr, stream, scratch, scratch_bytes,
+                       nullptr, nullptr, 0, true, nullptr, sk_clean);
+}
+}  // namespace bt
 
 extern "C" int bt_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim, int32_t rot,
                                   const void* x, int64_t ldx, const void* qkv_w, const void* qkv_b, void* qkv,
                                   int64_t ld_qkv, void* k_cache, void* v_cache, int64_t n_max, const int32_t* pos0_dev,
                                   int32_t pos0_host, const int32_t* pos_table, const float* cos_tab, const float* sin_tab,
                                   void* scratch, int64_t scratch_bytes, bt_stream stream) {
+    return bt::qkv_rope_append_impl(dtype, B, q_len, heads, head_dim, rot, x, ldx, qkv_w, qkv_b, qkv, ld_qkv, k_cache, v_cache, n_max,
+                                    pos0_dev, pos0_host, pos_table, cos_tab, sin_tab, scratch, scratch_bytes, false, stream);
+}
+
+int bt::qkv_rope_append_impl(int dtype, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim, int32_t rot, const void* x,
+                             int64_t ldx, const void* qkv_w, const void* qkv_b, void* qkv, int64_t ld_qkv, void* k_cache,
+                             void* v_cache, int64_t n_max, const int32_t* pos0_dev, int32_t pos0_host, const int32_t* pos_table,
+                             const float* cos_tab, const float* sin_tab, void* scratch, int64_t scratch_bytes, bool sk_clean,
+                             bt_stream stream) {
     BT_CHECK_ARG(B >= 0 && q_len > 0 && heads > 0 && head_dim > 0, "bt_qkv_rope_append: bad shape");
     BT_CHECK_ARG(x && qkv_w && qkv && k_cache && v_cache && cos_tab && sin_tab, "bt_qkv_rope_append: null pointer");
     BT_CHECK_ARG(pos0_dev || (pos0_host >= 0 && pos0_host + q_len <= n_max), "bt_qkv_rope_append: cache overflow");
@@ -4285,7 +4810,8 @@ extern "C" int bt_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_t h
     // skinny problems stream W faster with split-K (an unfused RoPE pass over a few rows costs nothing)
     const bool skinny = scratch != nullptr && ceil_div(M, 64) * ceil_div(3 * H, 64) < 256;
     BT_TRY(linear_impl(dtype, M, 3 * H, H, x, ldx, qkv_w, qkv_b, nullptr, 0, qkv, ld_qkv, BT_ACT_NONE,
-                       (fusable && !skinny) ? &q : nullptr, &fused, stream, scratch, scratch_bytes));
+                       (fusable && !skinny) ? &q : nullptr, &fused, stream, scratch, scratch_bytes, nullptr, nullptr, 0, true, nullptr,
+                       sk_clean));
     if (!fused)
         BT_TRY(bt_rope_kv_append(dtype, B, q_len, heads, head_dim, rot, qkv, ld_qkv, k_cache, v_cache, n_max, pos0_dev,
                                  pos0_host, pos_table, cos_tab, sin_tab, stream));
@@ -4426,10 +4952,45 @@ extern "C" int bt_ln_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_
 extern "C" int bt_linear2(int dtype, int64_t M, int64_t N, int64_t K1, const void* x1, int64_t ldx1, const void* W1,
                           const void* bias1, int64_t K2, const void* x2, int64_t ldx2, const void* W2, const void* bias2,
                           const void* residual, int64_t ldr, void* out, int64_t ldo, bt_stream stream) {
+    return bt::linear2_impl(dtype, M, N, K1, x1, ldx1, W1, bias1, K2, x2, ldx2, W2, bias2, residual, ldr, out, ldo, nullptr, 0, false,
+                            stream);
+}
+
+extern "C" int bt_linear2_ws(int dtype, int64_t M, int64_t N, int64_t K1, const void* x1, int64_t ldx1, const void* W1,
+                             const void* bias1, int64_t K2, const void* x2, int64_t ldx2, const void* W2, const void* bias2,
+                             const void* residual, int64_t ldr, void* out, int64_t ldo, void* scratch, int64_t scratch_bytes,
+                             bt_stream stream) {
+    return bt::linear2_impl(dtype, M, N, K1, x1, ldx1, W1, bias1, K2, x2, ldx2, W2, bias2, residual, ldr, out, ldo, scratch,
+                            scratch_bytes, false, stream);
+}
+
+extern "C" int64_t bt_stream_k_scratch_bytes(void) { return bt::sk_scratch_bytes(); }
+
+int bt::linear2_impl(int dtype, int64_t M, int64_t N, int64_t K1, const void* x1, int64_t ldx1, const void* W1, const void* bias1,
+                     int64_t K2, const void* x2, int64_t ldx2, const void* W2, const void* bias2, const void* residual, int64_t ldr,
+                     void* out, int64_t ldo, void* scratch, int64_t scratch_bytes, bool sk_clean, bt_stream stream) {
     BT_CHECK_ARG(x1 && W1 && x2 && W2 && out, "bt_linear2: null pointer");
     if (dtype == BT_BF16 && M > 64) {
-        // large stacks: one MFMA GEMM over K = K1 + K2 (persistent 256^2 kernel or the small-tile family), both biases and
-        // the residual in its epilogue -- the residual stream is read and written once instead of twice
+        // large stacks: one MFMA GEMM over K = K1 + K2, both biases and the residual in its epilogue -- the residual stream is read
+        // and written once instead of twice.  Product library: the stream-K items kernel when the caller's scratch and the shape
+        // allow it (sk_linear2_ok), the small-tile family with its second operand pair below 192 tiles of 256 x 256, and otherwise
+        // simply the two projections one after the other (same sums, one more bf16 rounding of the residual stream).  The debug
+        // build keeps the first-generation two-pair persistent kernel for the A/B that retired it (profiles/r2_probe_lin2.jsonl).
+#ifndef BT_DEBUG_HOOKS
+        const bool sk_takes = scratch && sk_linear2_ok(M, N, K1, K2, scratch_bytes) && aligned16(scratch);
+        const int64_t tiles256 = ceil_div(M, BM2) * ceil_div(N, BN2);
+        if (!sk_takes && tiles256 >= 192) {
+            const bool seg_ok = bias1 && bias2 && aligned16(bias1) && aligned16(bias2) && K1 % BK == 0 && K2 > 0 && K2 % BK == 0 &&
+                                ldx1 % 8 == 0 && ldx2 % 8 == 0 && aligned16(x1) && aligned16(x2) && aligned16(W1) && aligned16(W2) &&
+                                (N % 8 == 0) && (ldo % 8 == 0) && aligned16(out) && (!residual || (ldr % 8 == 0 && aligned16(residual)));
+            if (!seg_ok) {
+                set_error("bt_linear2: > 64 rows need bf16, both biases, K1 %% 64 == K2 %% 64 == 0, N %% 8 == 0 and 16-byte aligned operands");
+                return BT_ERR_UNSUPPORTED;
+            }
+            BT_TRY(linear_impl(dtype, M, N, K2, x2, ldx2, W2, bias2, residual, ldr, out, ldo, BT_ACT_NONE, nullptr, nullptr, stream));
+            return linear_impl(dtype, M, N, K1, x1, ldx1, W1, bias1, out, ldo, out, ldo, BT_ACT_NONE, nullptr, nullptr, stream);
+        }
+#endif
         Seg2 seg;
         seg.x = (const bf16*)x2;
         seg.w = (const bf16*)W2;
@@ -4438,7 +4999,7 @@ extern "C" int bt_linear2(int dtype, int64_t M, int64_t N, int64_t K1, const voi
         seg.ldw = K2;
         seg.K = (int)K2;
         return linear_impl(dtype, M, N, K1, x1, ldx1, W1, bias1, residual, ldr, out, ldo, BT_ACT_NONE, nullptr, nullptr, stream,
-                           nullptr, 0, &seg);
+                           scratch, scratch_bytes, &seg, nullptr, 0, true, nullptr, sk_clean);
     }
     const bool ok = dtype == BT_BF16 && M >= 1 && M <= 4 && N > 0 && K1 % GV_KC == 0 && K2 % 512 == 0 && K1 > 0 && K2 > 0 &&
                     ldx1 % 8 == 0 && ldx2 % 8 == 0 && aligned16(x1) && aligned16(x2) && aligned16(W1) && aligned16(W2) &&
@@ -4914,6 +5475,7 @@ int mid_res_ln(hipStream_t s, int64_t M, int64_t N, int64_t K1, const void* x1, 
 // test / A-B hooks (libbt_hip_dbg.so only): force the generic kernel for bf16, pick a kernel variant, cap the persistent grid
 extern "C" void bt_debug_force_generic_gemm(int on) { g_force_generic = on != 0; }
 extern "C" void bt_debug_gemm_variant(int v) { g_gemm_variant = v; }
+extern "C" void bt_debug_stream_k(int on) { g_sk = on; }
 extern "C" void bt_debug_gemm_max_wg(int n) { g_max_wg = n; }
 extern "C" void bt_debug_skinny_rows(int n) { g_skinny_rows = n; }
 extern "C" void bt_debug_small_stages(int n) { g_small_stages = n; }

@@ -494,6 +494,9 @@ int bt::guard_ncur(int32_t* n_cur, int64_t n_max, int32_t* err_flag, bt_stream s
 extern "C" int bt_compact_enqueue(const bt_engine_desc* src, const bt_engine_desc* dst, const int64_t* live_rows, int64_t n_live,
                                   bt_stream stream) {
     BT_CHECK_ARG(src && dst && live_rows, "bt_compact_enqueue: null pointer");
+    BT_CHECK_ARG(src->struct_size == sizeof(bt_engine_desc) && dst->struct_size == sizeof(bt_engine_desc),
+                 "bt_compact_enqueue: bt_engine_desc.struct_size %u / %u != %zu -- the caller was built against another bt_hip.h", src->struct_size,
+                 dst->struct_size, sizeof(bt_engine_desc));
     BT_CHECK_ARG(n_live >= 0 && n_live <= dst->B && dst->B <= src->B && n_live < (1ll << 31), "bt_compact_enqueue: bad row counts "
                  "(n_live %lld, dst B %lld, src B %lld)", (long long)n_live, (long long)dst->B, (long long)src->B);
     BT_CHECK_ARG(src->gk && src->gv && src->gk == dst->gk && src->gv == dst->gv && src->g_layer_stride == dst->g_layer_stride &&

@@ -14,7 +14,7 @@ from typing import Optional
 import torch
 from torch import nn
 
-from ..engine import DEFAULT_ROPE_POLICY, DecodeEngine, PipelinedEngine
+from ..engine import DEFAULT_ROPE_POLICY, DecodeEngine
 
 
 class _Timers:
@@ -75,7 +75,7 @@ class BlockTransformer(nn.Module):
         self.decoding_strategy = decoding_strategy
         self.config = self.token_decoder.config  # for Evaluation (reference :48)
         self.use_graphs = True
-        self.pipeline = None          # None = off unless BT_PIPELINE=1 (see _want_pipeline)
+        self.engine_factory = None    # experiments only (tools/experiments): an engine class used instead of DecodeEngine
         self.collect_timers = False  # bench.py: record phase events without the benchmark printout
         # greedy generate() keeps only token ids, like HF generate with output_scores=False: the logits GEMM reduces each row to
         # its argmax in its epilogue (bt_logits_argmax) and the [B, vocab] matrix is never written.  True = also materialise the
@@ -133,27 +133,18 @@ class BlockTransformer(nn.Module):
         return block_embeds.view((batch_size, n_blocks) + block_embeds.shape[-2:])
 
     # ---- engine management ---------------------------------------------------------------------------------------------------
-    def _want_pipeline(self, batch: int) -> bool:
-        """Two half-batch shards on two streams (engine.PipelinedEngine): opt-in (``self.pipeline = True`` or BT_PIPELINE=1).
-        Measured on MI355X (profiles/r2_overlap_probe.jsonl): without a bounded-footprint attention kernel
-        nothing overlaps, with one the two phases hide <= 30 % of the shorter one because the GEMM's own operand traffic
-        already takes half of the fabric bandwidth the global attention needs -- not enough to pay for the smaller GEMMs."""
-        import os
-        want = self.pipeline if self.pipeline is not None else os.environ.get("BT_PIPELINE") == "1"
-        return bool(want) and batch >= 2
-
     def _get_engine(self, batch: int, max_blocks: int, streaming: bool = False):
         e = self._engine
         rt = self.block_decoder._rt
         policy = getattr(self.token_decoder, "rope_policy", DEFAULT_ROPE_POLICY)
         # single stream when a streamer needs per-token host callbacks, and when EOS handling is on: HF stops a block early
         # once EVERY row of the batch has produced EOS (Q6), a whole-batch condition two independent shards cannot evaluate
-        pipelined = self._want_pipeline(batch) and not streaming
+        # (``engine_factory``: experiments plug their own engine class in -- tools/experiments/pipelined_engine.py; None = the product)
+        factory = self.engine_factory if (self.engine_factory is not None and not streaming and batch >= 2) else DecodeEngine
         if (e is None or e.B != batch or e.NB < max_blocks or e.dtype != rt.dtype or e.device != rt.device
-                or e.tok.policy != policy or e.pipelined != pipelined):
+                or e.tok.policy != policy or type(e) is not factory):
             self._engine = e = None  # free the old buffers before allocating the new ones
-            cls = PipelinedEngine if pipelined else DecodeEngine
-            e = self._engine = cls(self, batch, max_blocks, rope_policy=policy)
+            e = self._engine = factory(self, batch, max_blocks, rope_policy=policy)
         return e
 
     def release_buffers(self):
@@ -233,7 +224,7 @@ class BlockTransformer(nn.Module):
             bd = [timers.ms("prefill_start", "decode_start")] + timers.iter_ms("block_decoder")
             td = timers.iter_ms("token_decoder")
             print(" Generation time (ms) ".center(100, "-"))
-            if engine.pipelined:
+            if getattr(engine, "pipelined", False):
                 print("(two half-batch shards on two streams: per-iteration times are shard 0's and overlap shard 1's work)")
             print("Total time: ", timers.ms("prefill_start", "decode_end"))
             print("Block decoder times: ", bd)

@@ -49,6 +49,37 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return out
 
 
+def stream_k_scratch(device) -> torch.Tensor:
+    """Scratch for the stream-K GEMM path of bt_linear_ws / bt_qkv_rope_append / bt_linear2_ws (hand-off slabs + flag words; the
+    entry points clear the flag words themselves)."""
+    return torch.empty(int(lib().bt_stream_k_scratch_bytes()), dtype=torch.uint8, device=device)
+
+
+def linear2(x1: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, x2: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor,
+            residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, scratch: Optional[torch.Tensor] = None):
+    """out = x1 @ w1.T + b1 + x2 @ w2.T + b2 + residual in one call (attention.dense + mlp.dense_4h_to_h of a parallel-residual
+    layer); with ``scratch`` (stream_k_scratch) stacks above 256 rows run as ONE stream-K GEMM over K1 + K2."""
+    a1, ld1 = _rows(x1)
+    a2, ld2 = _rows(x2)
+    M, K1 = a1.shape
+    K2 = a2.shape[1]
+    N = w1.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=x1.dtype, device=x1.device)
+    o2, ldo = _rows(out)
+    ldr = 0
+    if residual is not None:
+        _, ldr = _rows(residual)
+    if scratch is None:
+        check(lib().bt_linear2(dtype_code(x1.dtype), M, N, K1, ptr(a1), ld1, ptr(w1), ptr(b1), K2, ptr(a2), ld2, ptr(w2), ptr(b2),
+                               ptr(residual), ldr, ptr(o2), ldo, current_stream()), "bt_linear2")
+    else:
+        check(lib().bt_linear2_ws(dtype_code(x1.dtype), M, N, K1, ptr(a1), ld1, ptr(w1), ptr(b1), K2, ptr(a2), ld2, ptr(w2), ptr(b2),
+                                  ptr(residual), ldr, ptr(o2), ldo, ptr(scratch), scratch.numel() * scratch.element_size(),
+                                  current_stream()), "bt_linear2_ws")
+    return out
+
+
 def layernorm(x, w1, b1, eps: float, w2=None, b2=None):
     """LN(x)*w1+b1 (and LN(x)*w2+b2 when w2 is given) in one pass."""
     x2, ldx = _rows(x)

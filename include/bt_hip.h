@@ -38,7 +38,9 @@
 extern "C" {
 #endif
 
-#define BT_VERSION 210 /* 0.2.1: bt_engine_desc.row_map / err_flag, bt_compact_enqueue */
+#define BT_VERSION 300 /* 0.3.0: bt_attn_args / bt_engine_desc start with struct_size (NOT binary compatible with 0.2.x: a binder
+                          * compiled against an older header is rejected by the size check instead of having fields read past the
+                          * end of its struct); stream-K GEMM path (bt_linear2_ws, bt_stream_k_scratch_bytes); bt_ceiling_* */
 
 typedef void* bt_stream; /* hipStream_t */
 
@@ -159,6 +161,16 @@ int bt_ln_linear(int dtype, int64_t M, int64_t N, int64_t K, const void* x, int6
 int bt_linear2(int dtype, int64_t M, int64_t N, int64_t K1, const void* x1, int64_t ldx1, const void* W1, const void* bias1,
                int64_t K2, const void* x2, int64_t ldx2, const void* W2, const void* bias2, const void* residual,
                int64_t ldr, void* out, int64_t ldo, bt_stream stream);
+/* bt_linear2 with caller-provided scratch: above 256 rows, with >= bt_stream_k_scratch_bytes() bytes (16-byte aligned) and full
+ * 256 x 256 output tiles, the two projections run as ONE stream-K MFMA GEMM over K1 + K2 (items of a tile's K range dealt out to
+ * all CUs; a tile shared by two workgroups is handed over through fp32 slabs + flag words inside `scratch`: no second launch, x read
+ * and written once).  Any other case behaves like bt_linear2.  bt_linear_ws / bt_qkv_rope_append take the same route with that much
+ * scratch when their 256 x 256 tiles do not fill whole rounds of CUs (M = 4096 QKV: 384 tiles).  Results are not bit-identical to
+ * the two-launch form (one bf16 rounding of the sum instead of two, fp32 summation split at the hand-off). */
+int64_t bt_stream_k_scratch_bytes(void);
+int bt_linear2_ws(int dtype, int64_t M, int64_t N, int64_t K1, const void* x1, int64_t ldx1, const void* W1, const void* bias1,
+                  int64_t K2, const void* x2, int64_t ldx2, const void* W2, const void* bias2, const void* residual,
+                  int64_t ldr, void* out, int64_t ldo, void* scratch, int64_t scratch_bytes, bt_stream stream);
 int bt_ln_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim, int32_t rot, const void* x,
                           int64_t ldx, const void* ln_w, const void* ln_b, float eps, const void* qkv_w, const void* qkv_b,
                           void* qkv, int64_t ld_qkv, void* k_cache, void* v_cache, int64_t n_max, const int32_t* pos0_dev,
@@ -207,6 +219,8 @@ int bt_topk_sample(int dtype, int64_t M, int64_t V, const void* logits, int64_t 
 
 /* ---- composite: one GPT-NeoX stack over M = B*q_len rows (what GPTNeoXModel.forward does for inputs_embeds) ---- */
 typedef struct bt_attn_args {
+    uint32_t struct_size;    /* = sizeof(bt_attn_args) of the header the caller was compiled against; every entry point rejects
+                                a value that is not its own (BT_ERR_ARG): structs grew between versions */
     void* k_cache;           /* [layers][B_alloc][heads][n_max][d]; points at this call's first sequence */
     void* v_cache;
     int64_t layer_stride;    /* elements between consecutive layers (= B_alloc*heads*n_max*d) */
@@ -225,7 +239,8 @@ typedef struct bt_attn_args {
     const int32_t* seq_skip; /* optional [B]: != 0 marks a finished sequence whose decode-step attention (mode 0, q_len = 1) is
                                 skipped (zeros are written; its tokens are forced to pad anyway) -- the reference compacts such
                                 rows away, model/block_transformer.py:381-398 */
-    /* ---- since 0.2.1: optional second stream for the parallel-residual branch (all three or none) ----
+    /* ---- optional second stream for the parallel-residual branch (all three or none); honoured by the DEBUG build only since
+     * 0.3.0 (measured -0.2 ... -0.3 % end to end: the product library runs one stream whatever these hold) ----
      * GPT-NeoX's parallel residual makes mlp.dense_h_to_4h independent of the attention (both read LayerNorms of the same layer
      * input; HF GPTNeoXLayer, use_parallel_residual).  With these set, stacks of > 256 bf16 rows enqueue that GEMM on `aux_stream`
      * (forked from and joined back into `stream` with the two events, capture-safe: hipEventRecord / hipStreamWaitEvent only), so it
@@ -262,6 +277,7 @@ int bt_bump(int32_t* counter, int32_t delta, bt_stream stream);
  * replays lives in device memory (n_cur, finished[], mask, sample_step).  No entry point allocates, synchronises or
  * reads device memory on the host.  All activation buffers are dtype `dtype`, row-major, contiguous. */
 typedef struct bt_engine_desc {
+    uint32_t struct_size;    /* = sizeof(bt_engine_desc), checked like bt_attn_args.struct_size */
     int32_t dtype;           /* bt_dtype of weights, activations and KV caches */
     int32_t L;               /* block_length */
     int32_t E;               /* token_decoder.n_expanded_emb (prefix rows per block) */

@@ -4,11 +4,18 @@ COMPACT_U: all loads of a batch first (slots live[i .. i+U)), then its stores (s
 load ever reads a slot an earlier store of the same walk has overwritten, whatever the ascending live list, so no temporary is
 needed.  Checked here exhaustively for small sizes and on random lists; the GPU test (test_compact_enqueue_c_abi) checks the kernel."""
 import itertools
+import os
+import re
 
 import numpy as np
 import pytest
 
-COMPACT_U = 8   # csrc/misc.hip
+# DOCUMENTATION / PROOF test (ADVICE r4): it checks the ARGUMENT the kernel rests on, on a numpy restatement; it never runs product
+# code and is not coverage of the HIP path (tests/test_kernels_gpu.py::test_compact_enqueue_c_abi and the compaction tests of
+# tests/test_model_gpu.py are).  The batch size is parsed from the kernel source so that the restatement follows a COMPACT_U change.
+_SRC = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "block_transformer_amd", "csrc", "misc.hip")).read()
+COMPACT_U = int(re.search(r"constexpr int COMPACT_U = (\d+);", _SRC).group(1))
+assert "for (; i < n_live; i += COMPACT_U)" in _SRC   # loads of a batch first, then its stores: the schedule restated below
 
 
 def walk(slots: np.ndarray, live, u: int = COMPACT_U):

@@ -4,7 +4,28 @@ row_ror:4 does not deliver lane ^ 4 -- it delivers lane (i -+ 4) mod 16 -- so bi
 the first stage lanes j and j ^ 8 hold the same value, hence the rotated partner holds the value lane ^ 4 holds, and fp32 addition
 commutes.  Restated here in numpy fp32, stage by stage, for both rotation directions; the GPU tests (kernel vs fp64, fused vs unfused
 bit-identity) run the real instruction sequence."""
+import os
+import re
+
 import numpy as np
+
+# DOCUMENTATION / PROOF test (ADVICE r4): the argument for bit-identity, on a numpy restatement -- not coverage of the HIP path (the
+# GPU kernel tests are).  The DPP control words are parsed from bt_common.h so that a changed control code breaks this test instead
+# of silently leaving the restatement behind: 0x128 = row_ror:8, 0x124 = row_ror:4, 0x4e = quad_perm [2,3,0,1], 0xb1 = quad_perm [1,0,3,2].
+_HDR = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "block_transformer_amd", "csrc", "bt_common.h")).read()
+_BODY = _HDR[_HDR.index("__device__ inline float row16_sum_dpp(float v)"):]
+_BODY = _BODY[:_BODY.index("return v;")]
+DPP_CTRL = [int(x, 16) for x in re.findall(r"__builtin_bit_cast\(int, v\), (0x[0-9a-f]+), 0xf, 0xf, false", _BODY)]
+assert DPP_CTRL == [0x128, 0x124, 0x4E, 0xB1], DPP_CTRL
+
+
+def _quad_perm(ctrl):
+    """quad_perm control word -> source lane (within its quad) of each of the four lanes"""
+    return [(ctrl >> (2 * i)) & 3 for i in range(4)]
+
+
+assert _quad_perm(DPP_CTRL[2]) == [2, 3, 0, 1] and _quad_perm(DPP_CTRL[3]) == [1, 0, 3, 2]
+assert [c - 0x120 for c in DPP_CTRL[:2]] == [8, 4]      # row_ror:N is encoded as 0x120 + N
 
 
 def xor_butterfly(v):

@@ -245,7 +245,7 @@ def test_pp2_constant_waits_equal_the_generic_function(nk, nt):
                 g += 1
 
 
-def _pp2_stream(grp, wave0, nk, nt, full, stores, pd, has_bias, bad=None, dmac=False):
+def _pp2_stream(grp, wave0, nk, nt, full, stores, pd, has_bias, bad=None, dmac=False, drain=()):
     """Program-order event list of one wave of gemm_bf16_mfma256pp2_kernel: constant waits in K-tiles >= 2, store-count waits in
     K-tiles 0 / 1 behind a full tile, W1 / A1 of the next tile's K-tile 1 issued at the tile boundary behind one extra barrier and
     AHEAD of the tile's stores; generic waits in the last two K-tiles of the last tile.  `bad` injects a deliberate error."""
@@ -331,9 +331,48 @@ def _pp2_stream(grp, wave0, nk, nt, full, stores, pd, has_bias, bad=None, dmac=F
             prev_full = False
         for _ in range(stores[j]):
             ev.append(("vm", ("st", j)))
+        if j in drain:                            # stream-K publish: s_waitcnt vmcnt(0) behind the slab stores, then the flag
+            ev.append(("wait", 0))
     if grp == 0:
         ev.append(("bar",))
     return ev
+
+
+SK_PUBLISH_STORES = 32                            # a wave's 128 x 64 fp32 block = 32 x 16 bytes per lane
+
+
+@pytest.mark.parametrize("nk", [4, 5, 8, 16, 32])
+def test_stream_k_item_sequences_schedule(nk):
+    """gemm_bf16_mfma256sk_kernel (round 5) runs the v2 K-loop over ITEMS (nk K-tiles of one output tile) instead of whole tiles;
+    per item the only thing that differs from a tile of the v2 kernel is what happens at its end:
+      chained item   -- the next item continues in the same accumulators: no stores, prev_full = false;
+      publish item   -- 32 write-through stores per wave (its fp32 block), then s_waitcnt vmcnt(0): prev_full = false;
+      epilogue item  -- the normal fused epilogue: >= PP_STORES stores, prev_full = true  (a consume + epilogue item is always the
+                        workgroup's last item: nothing follows it).
+    RAW / WAR of every run shape the host plan produces, on the v2 program-order model: the M = 4096 QKV workgroups (publish,
+    chain, epilogue | chain, epilogue, consume-epilogue), the fused residual projections (five chained items then publish /
+    consume), long runs with several chained tiles."""
+    import functools
+    P, E, C = "publish", "epilogue", "chain"
+
+    def run(kinds):
+        nt = len(kinds)
+        full = [k == E for k in kinds]
+        stores = [PP_STORES if k == E else (SK_PUBLISH_STORES if k == P else 0) for k in kinds]
+        drain = {j for j, k in enumerate(kinds) if k == P}
+        pp_model(nk, nt, full, stores, stream=functools.partial(_pp2_stream, drain=drain))
+        pp_model(nk, nt, full, stores, has_bias=False, stream=functools.partial(_pp2_stream, drain=drain))
+
+    run([P, C, E])                     # QKV at M = 4096, even workgroup: half a tile published, then a whole tile in two chunks
+    run([C, E, C])                     # odd workgroup up to its consume chain ...
+    run([C, E, E])                     # ... whose last item ends with consume + epilogue (stores; nothing follows)
+    run([C, C, C, C, P])               # fused residual projections at M = 4096: producer
+    run([C, C, C, C, E])               # consumer
+    run([C, C, C, C, E] * 4)           # a prefill chunk: four chained tiles of five chunks per workgroup
+    run([P] + [C, C, C, E] * 2)        # B = 6144 QKV: publish first, then whole tiles of four chunks
+    run([C] * 9 + [P] + [C] * 4 + [E])  # 20-chunk tiles in runs of 15: ten chunks published, five consumed
+    run([P])
+    run([E])
 
 
 @pytest.mark.parametrize("nk", [4, 5, 8, 32])

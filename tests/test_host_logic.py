@@ -56,7 +56,7 @@ def test_overrides():
 def test_library_exports_every_declared_symbol():
     """The C-ABI library loads and exports exactly what include/bt_hip.h declares (no compute without a GPU)."""
     lib = _lib.lib()
-    assert lib.bt_version() == 210
+    assert lib.bt_version() == 300
     header = open(os.path.join(ROOT, "include", "bt_hip.h")).read()
     declared = set(re.findall(r"^\s*(?:int|int32_t|int64_t|const char\*)\s+(bt_\w+)\(", header, flags=re.M))
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
@@ -82,6 +82,21 @@ def test_library_exports_every_declared_symbol():
     assert rc == -1 and b"row counts" in lib.bt_last_error()
     rc = lib.bt_compact_enqueue(ctypes.byref(src), ctypes.byref(dst), 0x10, 2, None)
     assert rc == -1 and b"null state buffer" in lib.bt_last_error()
+    # struct_size guard: a descriptor / attention-args struct of another header version is refused, not read past its end
+    bad = _lib.bt_engine_desc()
+    bad.struct_size = ctypes.sizeof(_lib.bt_engine_desc) - 8
+    rc = lib.bt_block_step_enqueue(ctypes.byref(bad), 4, 1, None)
+    assert rc == -1 and b"struct_size" in lib.bt_last_error()
+    rc = lib.bt_compact_enqueue(ctypes.byref(bad), ctypes.byref(dst), 0x10, 2, None)
+    assert rc == -1 and b"struct_size" in lib.bt_last_error()
+    args = _lib.bt_attn_args()
+    assert args.struct_size == ctypes.sizeof(_lib.bt_attn_args) and _lib.bt_engine_desc().struct_size == ctypes.sizeof(_lib.bt_engine_desc)
+    args.struct_size = 0
+    dims, w = _lib.bt_decoder_dims(64, 2, 32, 8, 256, 1, 1e-5), _lib.bt_decoder_weights()
+    lw = _lib.bt_layer_weights()
+    w.layers_host = ctypes.pointer(lw)
+    rc = lib.bt_decoder_forward(1, ctypes.byref(dims), ctypes.byref(w), 1, 1, 0x1000, ctypes.byref(args), 0, 0x1000, 0x1000, 1 << 20, None)
+    assert rc == -1 and b"struct_size" in lib.bt_last_error()
     # split-N rule shared by the library and the engine's workspace sizing
     assert lib.bt_attention_split_count(128, 544, 1) == 1 and lib.bt_attention_split_count(128, 544, 4) == 4
     assert lib.bt_attention_split_count(128, 40000, 1) == 3   # 40000 keys do not fit one 64 KiB score row
@@ -101,7 +116,7 @@ def test_product_library_has_no_debug_hooks():
         assert name in dbg, name
     prev = _lib.use_debug_library(True)
     try:
-        assert _lib.lib().bt_version() == 210 and hasattr(_lib.lib(), "bt_debug_gemm_variant")
+        assert _lib.lib().bt_version() == 300 and hasattr(_lib.lib(), "bt_debug_gemm_variant")
     finally:
         _lib.use_debug_library(prev)
     assert not hasattr(_lib.lib(), "bt_debug_gemm_variant_missing")

@@ -624,7 +624,7 @@ def test_qkv_rope_append_product_library_benchmark_shapes(B, q, pos0, use_dev_po
     run_qkv_fused(B, q, pos0, 16, 128, use_dev_pos, use_table, True, 0, 0, product=True)
 
 
-def run_qkv_fused(B, q, pos0, heads, d, use_dev_pos, use_table, fused, kernel, max_wg, product=False):
+def run_qkv_fused(B, q, pos0, heads, d, use_dev_pos, use_table, fused, kernel, max_wg, product=False, scratch=None, ret=False):
     rot = 32
     H = heads * d
     n_max = pos0 + q + 2
@@ -645,7 +645,8 @@ def run_qkv_fused(B, q, pos0, heads, d, use_dev_pos, use_table, fused, kernel, m
     try:
         check(lib().bt_qkv_rope_append(_lib.BT_BF16, B, q, heads, d, rot, ptr(xd), H, ptr(wd), ptr(bd), ptr(qkv), 3 * H,
                                        ptr(kc), ptr(vc), n_max, ptr(pos_dev), 0 if use_dev_pos else pos0, ptr(table),
-                                       ptr(tab[0]), ptr(tab[1]), None, 0, current_stream()))
+                                       ptr(tab[0]), ptr(tab[1]), ptr(scratch), 0 if scratch is None else scratch.numel(),
+                                       current_stream()))
         torch.cuda.synchronize()
     finally:
         if not product:
@@ -667,6 +668,133 @@ def run_qkv_fused(B, q, pos0, heads, d, use_dev_pos, use_table, fused, kernel, m
     assert float(kc.cpu()[:, :, :pos0].abs().sum()) == 0 and float(kc.cpu()[:, :, pos0 + q:].abs().sum()) == 0
     if fused:   # the k / v columns of the qkv buffer are not written in fused mode (bandwidth saved)
         assert torch.isnan(qkv.view(B * q, heads, 3, d)[:, :, 1:].float()).all()
+    if ret:
+        return qkv, kc, vc
+
+
+# ---- stream-K items GEMM (gemm_bf16_mfma256sk_kernel, round 5) -------------------------------------------------------------------
+def _poison_scratch(scratch):
+    """garbage in the slabs AND in the flag words: the stand-alone entry points must clear the flags themselves"""
+    scratch.view(torch.int32).fill_(0x7fc00001)
+    return scratch
+
+
+@pytest.mark.parametrize("M,N,K1,K2", [
+    (4096, 2048, 8192, 2048),      # the decode step (B = 4096): 128 tiles x 10 chunks of 16 K-tiles, every tile shared by a pair
+    (8192, 2048, 8192, 2048),      # token step 0 (B * E rows): 256 tiles x 5 chunks, one chained tile per workgroup, no hand-off
+    (4096, 2048, 2048, 512),       # 10 chunks of 4 K-tiles (the shortest item the K-loop takes), the pair boundary inside a run
+    (2048, 4096, 1024, 1024),      # 2 chunks: a pair splits a tile exactly at the boundary of the two operand pairs
+    (32768, 2048, 8192, 2048),     # a prefill chunk: 1024 tiles x 5 chunks = 20 items per workgroup, four chained tiles
+    (6144, 2048, 8192, 2048),      # 192 tiles x 20 chunks of 8: runs of 15 cut tiles at changing positions
+])
+def test_stream_k_linear2_vs_fp64(M, N, K1, K2):
+    """bt_linear2_ws above 256 rows: attention.dense + mlp.dense_4h_to_h as ONE stream-K GEMM over K1 + K2 (items of a tile's K range
+    dealt to all CUs; tiles shared by two workgroups handed over through fp32 slabs + per-wave flags) == fp64 elementwise, == the
+    two separate launches within bf16 rounding, in place on a strided residual stream, with poisoned scratch, repeatably (the
+    kernels leave the flag words zero: the second call runs on them without a clear only if they do)."""
+    x1 = rnd(M, K1, seed=1).bfloat16().to(DEV)
+    x2 = rnd(M, K2 + 8, seed=2).bfloat16().to(DEV)[:, :K2]
+    w1 = rnd(N, K1, seed=3, scale=K1 ** -0.5).bfloat16().to(DEV)
+    w2 = rnd(N, K2, seed=4, scale=K2 ** -0.5).bfloat16().to(DEV)
+    b1, b2 = rnd(N, seed=5).bfloat16().to(DEV), rnd(N, seed=6).bfloat16().to(DEV)
+    hid0 = rnd(M, N + 16, seed=7).bfloat16().to(DEV)
+    ref = (hid0[:, :N].double() + x1.double() @ w1.double().T + b1.double() + x2.double() @ w2.double().T + b2.double()).cpu()
+    two = ops.linear(x2.contiguous(), w2, b2, ops.linear(x1, w1, b1, hid0[:, :N].contiguous())).double().cpu()
+    scratch = _poison_scratch(ops.stream_k_scratch(DEV))
+    outs = []
+    for rep in range(3):
+        hid = hid0.clone()
+        view = hid[:, :N]
+        ops.linear2(x1, w1, b1, x2, w2, b2, residual=view, out=view, scratch=scratch)
+        torch.cuda.synchronize()
+        outs.append(view.clone())
+        assert torch.equal(hid[:, N:], hid0[:, N:])
+    got = outs[0].double().cpu()
+    assert rel_err(got, ref) <= 8e-3, rel_err(got, ref)
+    err = (got - ref).abs()
+    assert float((err - 1e-2 * ref.abs() - 2e-2).max()) <= 0, float(err.max())   # elementwise: no tile / chunk dropped or doubled
+    assert rel_err(got, two) <= 1.2e-2
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "the hand-off is not deterministic"
+    G = torch.cuda.get_device_properties(0).multi_processor_count
+    tail = scratch.view(torch.int32)[G * 65536:G * 65536 + G * 8 + 1]
+    assert int(tail.abs().max()) == 0, "flag words not left at zero (or the timeout word is set)"
+
+
+@pytest.mark.parametrize("B,q,pos0", [(4096, 1, 6), (6144, 1, 3), (1536, 2, 0)])
+def test_stream_k_qkv_vs_fp64_and_chained_tiles_bit_identical(B, q, pos0, dbg_lib):
+    """bt_qkv_rope_append with stream-K scratch at row counts whose 256 x 256 tiles leave the persistent kernel's last round under
+    90 % full (B = 4096: 384 tiles = 1.5 rounds): q / k(rotated) / v against fp64 like every fused-QKV test; and against the
+    persistent kernel (stream-K switched off in the debug build): tile 0 is a CHAINED tile (its two K halves run back to back in one
+    workgroup, same K order, same accumulators) -> bit-identical; the problem as a whole is not (tiles split between two
+    workgroups sum their halves in a different order), which also shows the stream-K kernel really ran."""
+    scratch = _poison_scratch(ops.stream_k_scratch(DEV))
+    lib().bt_debug_stream_k(1)
+    try:
+        q1, k1, v1 = run_qkv_fused(B, q, pos0, 16, 128, False, True, True, 0, 0, scratch=scratch, ret=True)
+        q1b, k1b, v1b = run_qkv_fused(B, q, pos0, 16, 128, False, True, True, 0, 0, scratch=scratch, ret=True)
+        lib().bt_debug_stream_k(0)
+        q0, k0, v0 = run_qkv_fused(B, q, pos0, 16, 128, False, True, True, 0, 0, scratch=scratch, ret=True)
+    finally:
+        lib().bt_debug_stream_k(1)
+    H = 16 * 128
+    a, b = q1.view(B * q, 16, 3, 128)[:, :, 0], q0.view(B * q, 16, 3, 128)[:, :, 0]
+    assert torch.equal(q1.view(B * q, 16, 3, 128)[:, :, 0], q1b.view(B * q, 16, 3, 128)[:, :, 0]) and torch.equal(k1, k1b) and torch.equal(v1, v1b)
+    assert torch.equal(a[:256, 0], b[:256, 0]), "tile 0 (rows 0..255, q of head 0) is a chained tile: same sums as the persistent kernel"
+    assert not (torch.equal(a, b) and torch.equal(k1, k0) and torch.equal(v1, v0)), "stream-K did not run (or no tile was split)"
+    assert (a.float() - b.float()).abs().max().item() <= 6.5e-2 * max(1.0, a.float().abs().max().item())
+
+
+@pytest.mark.parametrize("variant", ["plain", "bias", "bias_gelu", "bias_res"])
+@pytest.mark.parametrize("M,N,K", [(4096, 6144, 2048), (2304, 8192, 2048)])
+def test_stream_k_linear_epilogues_vs_fp64(M, N, K, variant):
+    """bt_linear_ws with stream-K scratch on ragged tile counts (384 = 1.5 rounds; 60 x ... ) for every epilogue the kernel is instantiated with."""
+    x = rnd(M, K, seed=11).bfloat16().to(DEV)
+    w = rnd(N, K, seed=12, scale=K ** -0.5).bfloat16().to(DEV)
+    b = rnd(N, seed=13).bfloat16().to(DEV) if variant != "plain" else None
+    r = rnd(M, N, seed=14).bfloat16().to(DEV) if variant == "bias_res" else None
+    ref = x.double() @ w.double().T
+    if b is not None:
+        ref = ref + b.double()
+    if variant == "bias_gelu":
+        ref = torch.nn.functional.gelu(ref)
+    if r is not None:
+        ref = ref + r.double()
+    scratch = _poison_scratch(ops.stream_k_scratch(DEV))
+    got = ops.linear(x, w, b, r, act="gelu" if variant == "bias_gelu" else "none", scratch=scratch).double()
+    torch.cuda.synchronize()
+    err = (got - ref).abs()
+    assert rel_err(got.cpu(), ref.cpu()) <= 8e-3
+    assert float((err - 1e-2 * ref.abs() - 2e-2).max()) <= 0, float(err.max())
+
+
+def test_stream_k_hand_off_under_uneven_load():
+    """The hand-off under uneven load (CDNA guide: idle chips and uniform load hide visibility bugs): the decode-shape stream-K GEMM
+    replayed 40 times back to back while a second stream keeps half of the chip busy with copies -- every replay bit-identical to the
+    first (fixed summation order: a stale or torn slab would show), flag words zero afterwards."""
+    M, N, K1, K2 = 4096, 2048, 8192, 2048
+    x1 = rnd(M, K1, seed=1).bfloat16().to(DEV)
+    x2 = rnd(M, K2, seed=2).bfloat16().to(DEV)
+    w1 = rnd(N, K1, seed=3, scale=K1 ** -0.5).bfloat16().to(DEV)
+    w2 = rnd(N, K2, seed=4, scale=K2 ** -0.5).bfloat16().to(DEV)
+    b1, b2 = rnd(N, seed=5).bfloat16().to(DEV), rnd(N, seed=6).bfloat16().to(DEV)
+    res = rnd(M, N, seed=7).bfloat16().to(DEV)
+    scratch = _poison_scratch(ops.stream_k_scratch(DEV))
+    first = ops.linear2(x1, w1, b1, x2, w2, b2, residual=res, scratch=scratch).clone()
+    side = torch.cuda.Stream()
+    big = torch.empty(1 << 28, dtype=torch.uint8, device=DEV)
+    outs = []
+    for i in range(40):
+        if i % 3 == 0:
+            with torch.cuda.stream(side):
+                big[: 1 << 27].copy_(big[1 << 27:])
+        outs.append(ops.linear2(x1, w1, b1, x2, w2, b2, residual=res, scratch=scratch))
+        if i % 5 == 4:      # an unrelated kernel between two replays, reading one of the operands warm into the caches
+            _ = x1[:256].float().sum()
+    torch.cuda.synchronize()
+    for i, o in enumerate(outs):
+        assert torch.equal(o, first), f"replay {i} differs"
+    G = torch.cuda.get_device_properties(0).multi_processor_count
+    assert int(scratch.view(torch.int32)[G * 65536:G * 65536 + G * 8 + 1].abs().max()) == 0
 
 
 # ---- bt_attention -------------------------------------------------------------------------------------------------------------

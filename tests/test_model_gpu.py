@@ -14,6 +14,7 @@ from conftest import GOLDEN_CONFIGS, t  # noqa: E402
 from block_transformer_amd.config import named_dims  # noqa: E402
 from block_transformer_amd.model.utils import load_block_transformer_from_dims  # noqa: E402
 from oracle.cpu_ref import oracle_from_dims  # noqa: E402
+from tools.experiments.pipelined_engine import PipelinedEngine  # noqa: E402  (measured-negative experiment kept for its tests / A-B)
 from oracle.cpu_ref import random_state_dict as _random_state_dict  # noqa: E402
 
 _SD_CACHE = {}
@@ -718,7 +719,6 @@ def test_full_depth_1p2b_bf16_first_block_logits_vs_oracle(B):
     max: ctx 0.041 / 0.061, logits 0.048 / 0.057 at max|value| 3.4-4.2); the greedy token must agree wherever the oracle's
     top-1 margin exceeds twice that budget."""
     model, dims, o = _full_1p2b()
-    model.pipeline = False
     model.use_graphs = True
     P = 2048
     prompt = torch.randint(0, dims.vocab, (B, P), generator=torch.Generator().manual_seed(B))
@@ -759,7 +759,6 @@ def test_full_depth_1p2b_bf16_benchmark_batch_decode_dispatch_vs_oracle():
       (3) max_length = P + L + 1: context + logits of the SECOND block (block-decoder decode step: q = 1, M = 4096 against
           the global KV written by the prefill + roll-over embedding), oracle prefilled on prompt + the GPU's own first block."""
     model, dims, o = _full_1p2b()
-    model.pipeline = False
     model.use_graphs = True
     B, P, L = 4096, 64, dims.L
     prompt = torch.randint(0, dims.vocab, (B, P), generator=torch.Generator().manual_seed(4096))
@@ -818,7 +817,6 @@ def test_full_depth_1p2b_bf16_steady_state_decode_vs_oracle(B):
     the fused QKV + RoPE + append epilogue).  Context of block 2 and its first logits for 2 rows against the fp32 oracle prefilled on
     prompt + the GPU's first block (same budget as the B = 4096 checkpoints: 2.2 % of max + 0.01), tokens margin-aware."""
     model, dims, o = _full_1p2b()
-    model.pipeline = False
     model.use_graphs = True
     P, L = 2048, dims.L
     prompt = torch.randint(0, dims.vocab, (B, P), generator=torch.Generator().manual_seed(1000 + B))
@@ -930,7 +928,6 @@ def test_full_depth_b8_1p2b_bf16_first_block_and_steady_state_vs_oracle(B):
           context + first logits of block 2."""
     model, dims, o = _full_b8()
     assert dims.L == 8
-    model.pipeline = False
     model.use_graphs = True
     P, L = 2048, dims.L
     prompt = torch.randint(0, dims.vocab, (B, P), generator=torch.Generator().manual_seed(8000 + B))
@@ -973,7 +970,6 @@ def test_full_size_1p2b_p2048_d2048_per_gpu_properties():
     512 -> 1023 keys and the split-N factor re-chosen for n_max = 1024.  Size-independent properties: prompt preserved, ids in
     range, deterministic replay, graphs on == graphs off bit for bit."""
     model, dims, _ = _full_1p2b()
-    model.pipeline = None
     model.use_graphs = True
     B, P, D = 8, 2048, 2048
     prompt = torch.randint(0, dims.vocab, (B, P), generator=torch.Generator().manual_seed(33)).to(DEV)
@@ -1382,7 +1378,6 @@ def test_full_size_1p2b_long_decode_properties():
     prompt preserved, ids in range, replay is deterministic (second run identical: all per-run state is reset), and the
     captured graphs launch exactly the eager sequence (graphs on == graphs off, bit for bit)."""
     model, dims, _ = _full_1p2b()
-    model.pipeline = None
     model.use_graphs = True
     B, P, D = 8, 128, 2048
     prompt = torch.randint(0, dims.vocab, (B, P), generator=torch.Generator().manual_seed(11)).to(DEV)
@@ -1404,17 +1399,17 @@ def test_full_size_1p2b_long_decode_properties():
 @pytest.mark.parametrize("B", [2, 5, 64])
 @pytest.mark.parametrize("sync", ["0", "1"])
 def test_half_batch_pipeline_equals_single_engine(gpu_model, B, sync, monkeypatch):
-    """engine.PipelinedEngine (two half-batch shards on two streams, one token block apart) == the single-stream engine,
+    """tools/experiments PipelinedEngine (two half-batch shards on two streams, one token block apart) == the single-stream engine,
     bit for bit in fp32 (sequences are independent), incl. odd batches, EOS handling and P % L != 0."""
     monkeypatch.setenv("BT_PIPELINE_SYNC", sync)
     model, dims, sd, fx = gpu_model("micro")
     prompt = torch.randint(1, dims.vocab, (B, 10), generator=torch.Generator().manual_seed(B)).to(DEV)
     try:
-        model.pipeline = False
+        model.engine_factory = None
         model.release_buffers()
         one = model.generate(prompt, max_length=39).cpu()
-        assert not model._engine.pipelined
-        model.pipeline = True
+        assert type(model._engine).__name__ == "DecodeEngine"
+        model.engine_factory = PipelinedEngine
         two = model.generate(prompt, max_length=39).cpu()
         assert model._engine.pipelined and len(model._engine.shards) == 2
         assert torch.equal(one, two)
@@ -1428,8 +1423,8 @@ def test_half_batch_pipeline_equals_single_engine(gpu_model, B, sync, monkeypatc
             # generate() falls back to the single-stream engine, so the result cannot depend on the sharding
             gcfg.eos_token_id, gcfg.pad_token_id = eos, 1
             two_e = model.generate(prompt, max_length=39).cpu()
-            assert not model._engine.pipelined
-            model.pipeline = False
+            assert type(model._engine).__name__ == "DecodeEngine"
+            model.engine_factory = None
             one_e = model.generate(prompt, max_length=39).cpu()
             assert torch.equal(one_e, two_e)
             o = oracle_from_dims(dims, sd, gen_eos_token_id=eos, gen_pad_token_id=1)
@@ -1437,7 +1432,7 @@ def test_half_batch_pipeline_equals_single_engine(gpu_model, B, sync, monkeypatc
         finally:
             gcfg.eos_token_id, gcfg.pad_token_id = old
     finally:
-        model.pipeline = None
+        model.engine_factory = None
         model.release_buffers()
 
 
@@ -1455,9 +1450,9 @@ def test_half_batch_pipeline_bf16_full_width_layers():
     model = model.bfloat16().to(DEV)
     model.token_decoder.generation_config.eos_token_id = None
     prompt = torch.randint(0, dims.vocab, (512, 64), generator=torch.Generator().manual_seed(1)).to(DEV)
-    model.pipeline = False
+    model.engine_factory = None
     one = model.generate(prompt, max_length=96).cpu()
-    model.pipeline = True
+    model.engine_factory = PipelinedEngine
     two = model.generate(prompt, max_length=96).cpu()
     assert model._engine.pipelined
     assert torch.equal(two[:, :64], prompt.cpu())
@@ -1926,8 +1921,9 @@ def test_unwritten_cache_rows_never_enter_the_attention(B):
 
 
 @pytest.mark.parametrize("B", [300])
-def test_two_branch_parallel_residual_is_bit_identical(B):
-    """Round 4: with a second stream (bt_attn_args.aux_stream; model.two_branch = True) stacks of > 256 bf16 rows run
+def test_two_branch_parallel_residual_is_bit_identical(B, dbg_lib):
+    """(Debug build only since round 5: measured -0.2 ... -0.3 % end to end, the product library ignores the second stream.)
+    Round 4: with a second stream (bt_attn_args.aux_stream; model.two_branch = True) stacks of > 256 bf16 rows run
     mlp.dense_h_to_4h beside QKV -> attention -> attention.dense (GPT-NeoX parallel residual: it only reads LN2 of the layer input)
     and join in front of dense_4h_to_h.  Same kernels, same arithmetic, same order of the residual updates: tokens and the last
     context embedding are bit-identical to the one-stream schedule, captured as a forked hipGraph and launched eagerly."""

@@ -96,6 +96,64 @@ def probe_lin2(M, N, K1, K2, iters):
     return out
 
 
+def probe_sk(M, iters, reps=3):
+    """Round 5: the decode step's GEMMs at M rows, stream-K items kernel (bt_debug_stream_k 1) vs the round-4 dispatch (0), interleaved
+    on one box, best of `reps`: the fused QKV + RoPE + append projection (N = 3H), and the two residual-stream projections -- ONE
+    stream-K GEMM over K = I + H (bt_linear2_ws) vs attention.dense + dense_4h_to_h as two launches (256 x 128 one-tile kernel at
+    M = 4096).  1.2B geometry (H = 2048, I = 8192, 16 heads x 128)."""
+    H, I, heads, d = 2048, 8192, 16, 128
+    B = M
+    x = torch.randn(M, H, device=DEV).bfloat16()
+    wq = (torch.randn(3 * H, H, device=DEV) * H ** -0.5).bfloat16()
+    bq = torch.randn(3 * H, device=DEV).bfloat16()
+    qkv = torch.empty(M, 3 * H, device=DEV, dtype=torch.bfloat16)
+    n_max = 8
+    kc = torch.zeros(B, heads, n_max, d, dtype=torch.bfloat16, device=DEV)
+    vc = torch.zeros_like(kc)
+    tab = ops.rope_tables(64, 32, 10000.0, DEV)
+    att = torch.randn(M, H, device=DEV).bfloat16()
+    h4 = torch.randn(M, I, device=DEV).bfloat16()
+    wd = (torch.randn(H, H, device=DEV) * H ** -0.5).bfloat16()
+    w2 = (torch.randn(H, I, device=DEV) * I ** -0.5).bfloat16()
+    bd, b2 = torch.randn(H, device=DEV).bfloat16(), torch.randn(H, device=DEV).bfloat16()
+    xres = torch.randn(M, H, device=DEV).bfloat16()
+    scratch = ops.stream_k_scratch(DEV)
+    st = current_stream()
+
+    def qkv_call():
+        check(lib().bt_qkv_rope_append(_lib.BT_BF16, B, 1, heads, d, 32, ptr(x), H, ptr(wq), ptr(bq), ptr(qkv), 3 * H, ptr(kc), ptr(vc),
+                                       n_max, None, 3, None, ptr(tab[0]), ptr(tab[1]), ptr(scratch), scratch.numel(), st))
+
+    def lin2_one():
+        ops.linear2(h4, w2, b2, att, wd, bd, residual=xres, out=xres, scratch=scratch)
+
+    def lin2_two():
+        ops.linear(att, wd, bd, xres, out=xres)
+        ops.linear(h4, w2, b2, xres, out=xres)
+
+    best = {}
+    for _ in range(reps):
+        for sk in (1, 0):
+            hooks.bt_debug_stream_k(sk)
+            for name, fn in (("qkv", qkv_call), ("res_one_launch", lin2_one), ("res_two_launches", lin2_two)):
+                if name == "res_one_launch" and sk == 0:
+                    continue          # without stream-K bt_linear2_ws is the two launches again
+                ms = timed(fn, iters)
+                key = (name, sk)
+                best[key] = min(best.get(key, 1e9), ms)
+    hooks.bt_debug_stream_k(1)
+    fl_qkv = 2.0 * M * 3 * H * H
+    fl_res = 2.0 * M * H * (H + I)
+    rec = {"op": "stream_k_decode_shapes", "M": M,
+           "qkv_us": {"stream_k": round(best[("qkv", 1)] * 1e3, 2), "round4": round(best[("qkv", 0)] * 1e3, 2)},
+           "qkv_TFLOPs": {"stream_k": round(fl_qkv / best[("qkv", 1)] / 1e9, 1), "round4": round(fl_qkv / best[("qkv", 0)] / 1e9, 1)},
+           "res_us": {"stream_k_one_launch": round(best[("res_one_launch", 1)] * 1e3, 2),
+                      "two_launches": round(min(best[("res_two_launches", 0)], best[("res_two_launches", 1)]) * 1e3, 2)},
+           "res_TFLOPs": {"stream_k_one_launch": round(fl_res / best[("res_one_launch", 1)] / 1e9, 1),
+                          "two_launches": round(fl_res / min(best[("res_two_launches", 0)], best[("res_two_launches", 1)]) / 1e9, 1)}}
+    return rec
+
+
 def probe_attn(B, n, iters, heads=16, d=128, n_split=1, dtype=torch.bfloat16):
     H = heads * d
     n_max = n + 1
@@ -164,7 +222,7 @@ def probe_copy(nbytes, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=["gemm", "attn", "flash", "suite", "copy", "ab", "abl", "skinny", "decode", "vendor", "pitch",
-                                     "local", "lin2", "ln", "ppabl", "ppstore", "ppv2", "ppepi", "ppab", "t21", "ppqkv"])
+                                     "local", "lin2", "ln", "ppabl", "ppstore", "ppv2", "ppepi", "ppab", "t21", "ppqkv", "sk"])
     ap.add_argument("--m", type=int, default=32768)
     ap.add_argument("--n", type=int, default=6144)
     ap.add_argument("--k", type=int, default=2048)
@@ -181,6 +239,9 @@ def main():
     hooks.bt_debug_gemm_variant(args.variant)
     if args.what == "gemm":
         res.append(probe_gemm(args.m, args.n, args.k, args.iters, act=args.act, res=args.res))
+    elif args.what == "sk":      # round 5: stream-K items kernel vs the round-4 dispatch on the decode step's GEMM shapes
+        for M in ((args.m,) if args.m != 32768 else (4096, 8192, 2048, 6144)):
+            res.append(probe_sk(M, args.iters))
     elif args.what == "lin2":    # the residual-stream projections of block_main_b4_1.2b at decode / prefill stack heights
         for M in (4096, 8192, 16384, 32768):
             res.append(probe_lin2(M, 2048, 8192, 2048, args.iters))
