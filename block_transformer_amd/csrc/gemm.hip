@@ -2687,12 +2687,17 @@ constexpr uint32_t SK_SPIN_LIMIT = 1u << 20;              // polls (x ~1 us) bef
 // and reloaded it from scratch (+ vmcnt(0)) on every poll.
 __device__ inline uint32_t sk_flag_load(const uint32_t* p) {      // every lane reads the same word
     uint32_t v;
-    asm volatile("v_mov_b32 %0, 0\n\tglobal_load_dword %0, %0, %1 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "s"(p) : "memory");
+    // s_nop 4 first: the pointer may sit in SGPRs the compiler has just written with v_readlane / v_readfirstlane (a spill reload),
+    // and a VALU-written SGPR needs 5 wait states before a VMEM instruction reads it as its base -- hipcc pads that hazard for its
+    // own instructions, never inside an asm string (CDNA guide 5.7 item 2).  Without it the load went to (stale high half : low
+    // half) -- a memory access fault on every launch with a hand-off (profiles/r5_sk_bisect.md).
+    asm volatile("s_nop 4\n\tv_mov_b32 %0, 0\n\tglobal_load_dword %0, %0, %1 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "s"(p) : "memory");
     return __builtin_amdgcn_readfirstlane(v);
 }
 __device__ inline void sk_flag_store(uint32_t* p, uint32_t value) {   // every lane stores the same value to the same word
     uint32_t z, d;
-    asm volatile("v_mov_b32 %0, 0\n\tv_mov_b32 %1, %3\n\tglobal_store_dword %0, %1, %2 sc1" : "=&v"(z), "=&v"(d) : "s"(p), "s"(value) : "memory");
+    asm volatile("s_nop 4\n\tv_mov_b32 %0, 0\n\tv_mov_b32 %1, %3\n\tglobal_store_dword %0, %1, %2 sc1\n\ts_nop 1"
+                 : "=&v"(z), "=&v"(d) : "s"(p), "s"(value) : "memory");
 }
 
 struct SkWalk {          // wave-uniform: the items of this workgroup's run [lo, lo + q), chains in reverse tile order
