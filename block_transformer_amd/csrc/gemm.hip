@@ -4376,8 +4376,13 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
             (act == BT_ACT_NONE || !residual)) {
             const int G = num_cus();
             const int64_t T = (M / BM2) * (N / BN2);
-            // (at least one full round plus a remainder: problems below one round keep the one-tile kernels)
-            const bool ragged = T > G && (T % G) != 0 && (double)T / (double)(ceil_div(T, G) * G) < 0.9;
+            // (at least one full round plus a remainder: problems below one round keep the one-tile kernels).  g_sk == 1: only where
+            // the persistent kernel's own dispatch rule would refuse the shape (last round under 96 tiles: those ran on the 128 x 128
+            // kernel -- M = 6144 QKV 181 -> 159 us, profiles/r5_decode_shapes_sk.jsonl); where it takes the shape (M = 4096 QKV: 384
+            // tiles, last round half full) its half-empty last round runs faster than a full one and the hand-off costs what the
+            // better balance saves (103 vs 101 us, same file) -> g_sk >= 2 (A/B) includes those
+            const bool pp_takes = T >= 192 && (T % 256 == 0 || T >= 1024 || (T % 256) >= 96);
+            const bool ragged = T > G && (T % G) != 0 && (double)T / (double)(ceil_div(T, G) * G) < 0.9 && (g_sk >= 2 || !pp_takes);
             const SkPlan pl = (seg2 || ragged) && scratch_bytes >= sk_ws_bytes(G) ? sk_plan(M, N, K, s2.K, G) : SkPlan{false, 0, 0, 0, G};
             if (pl.ok) {
                 ProfScope ps(BT_PROF_LINEAR_MFMA, s);

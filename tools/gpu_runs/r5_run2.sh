@@ -17,14 +17,17 @@ echo "kernel tests rc=$?"; tail -4 $O/r5_run2_kernel_tests.log
 timeout 1500 python -m pytest tests/test_model_gpu.py -x -q -s -m gpu -k "full_depth or two_branch or half_batch or streamer or large_stack or real_dims or full_size" > $O/r5_run2_model_tests.log 2>&1
 RC2=$?
 echo "model tests rc=$RC2"; grep -E "^\[|passed|failed|Error" $O/r5_run2_model_tests.log | tail -30
+for cfg in "0 0" "1 1" "2 1" "1 2"; do
+  set -- $cfg
+  timeout 300 python tools/bench_knobs.py stream_k=$1 lin2_sk=$2 -- --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary --no-parity --no-ceilings > $O/r5_ab_sk$1$2_p2048.json 2> $O/r5_ab_sk$1$2_p2048.log
+done
 for cfg in "0 0" "1 1"; do
   set -- $cfg
-  timeout 300 python tools/bench_knobs.py stream_k=$1 lin2_sk=$2 -- --steps 4 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary --no-parity --no-ceilings > $O/r5_ab_sk$1_p2048.json 2> $O/r5_ab_sk$1_p2048.log
-  timeout 400 python tools/bench_knobs.py stream_k=$1 lin2_sk=$2 -- --prefill 128 --decode 2048 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary --no-parity --no-ceilings > $O/r5_ab_sk$1_p128.json 2> $O/r5_ab_sk$1_p128.log
+  timeout 400 python tools/bench_knobs.py stream_k=$1 lin2_sk=$2 -- --prefill 128 --decode 2048 --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-secondary --no-parity --no-ceilings > $O/r5_ab_sk$1$2_p128.json 2> $O/r5_ab_sk$1$2_p128.log
 done
 python - <<'PY'
 import json
-for name in ("r5_ab_sk0_p2048", "r5_ab_sk1_p2048", "r5_ab_sk0_p128", "r5_ab_sk1_p128"):
+for name in ("r5_ab_sk00_p2048", "r5_ab_sk11_p2048", "r5_ab_sk21_p2048", "r5_ab_sk12_p2048", "r5_ab_sk00_p128", "r5_ab_sk11_p128"):
     try:
         d = json.load(open(f"gpurun_out/{name}.json"))
         print(name, round(d["value"]), "tok/s", round(d["ms_per_step"], 1), "ms", "decode_ms", round(d.get("decode_ms", 0), 1), "prefill_ms", round(d.get("prefill_ms", 0), 1))
