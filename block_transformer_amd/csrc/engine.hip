@@ -35,14 +35,15 @@ static bool g_no_two_branch = false;   // A/B: ignore bt_attn_args.aux_stream (r
 extern "C" void bt_debug_no_two_branch(int on) { g_no_two_branch = on != 0; }
 // > 256 rows (round 5): attention.dense + dense_4h_to_h as ONE stream-K GEMM over K = I + H (gemm_bf16_mfma256sk_kernel; x read and
 // written once, one launch, 32-MFMA phases instead of the one-tile 256 x 128 kernel's 16): 0 = off (two launches, A/B), 1 = stacks of
-// up to 8192 rows (the decode steps: M = B and, token step 0, M = B * E), 2 = every stack incl. the prefill chunks
-static int g_lin2_sk = 1;
+// up to 8192 rows (the decode steps: M = B and, token step 0, M = B * E), 2 = every stack incl. the prefill chunks (default: same
+// box, one setting per process, profiles/r5_ab_sk*_p2048.json: 126.2k -> 127.5k tok/s with 1, 128.5k with 2)
+static int g_lin2_sk = 2;
 extern "C" void bt_debug_lin2_sk(int mode) { g_lin2_sk = mode; }
 #else
 static constexpr int g_few_rows_max = 2;
 static constexpr bool g_no_few_rows_fusion = false;
 static constexpr bool g_lin2_large = false;
-static constexpr int g_lin2_sk = 1;
+static constexpr int g_lin2_sk = 2;
 #endif
 
 static int64_t ws_elems(const bt_decoder_dims* d, int64_t M) {

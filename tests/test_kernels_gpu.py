@@ -362,9 +362,11 @@ def test_linear2_two_projections_one_launch(M, N, K1, K2):
     (16384, 1024, 256, 128), (8192, 2048, 128, 128),                               # short K: ring wraps across tiles / pairs
 ])
 def test_linear2_large_stack_one_gemm(M, N, K1, K2):
-    """bt_linear2 with > 64 rows: ONE MFMA GEMM over K1 + K2 with both biases and the residual in its epilogue (what
-    bt_decoder_forward runs for attention.dense + mlp.dense_4h_to_h on prefill / large-batch stacks) == fp64 and == the
-    two separate bt_linear calls; in place on a strided residual stream, strided second operand."""
+    """bt_linear2 with > 64 rows and NO scratch: below 192 tiles of 256 x 256 ONE small-tile MFMA GEMM over K1 + K2 with both biases
+    and the residual in its epilogue; above that (round 5: the two-pair 256 x 256 kernel left the product library) the two
+    projections one after the other -- == fp64 and == the two separate bt_linear calls; in place on a strided residual stream,
+    strided second operand.  (With scratch the same call is ONE stream-K GEMM: test_stream_k_linear2_vs_fp64.)  The elementwise
+    bound allows for the bf16 rounding of the intermediate residual stream the two-launch form has."""
     x1 = rnd(M, K1, seed=1).bfloat16().to(DEV)
     x2 = rnd(M, K2 + 8, seed=2).bfloat16().to(DEV)[:, :K2]
     w1 = rnd(N, K1, seed=3, scale=K1 ** -0.5).bfloat16().to(DEV)
@@ -372,7 +374,8 @@ def test_linear2_large_stack_one_gemm(M, N, K1, K2):
     b1, b2 = rnd(N, seed=5).bfloat16().to(DEV), rnd(N, seed=6).bfloat16().to(DEV)
     hid = rnd(M, N + 16, seed=7).bfloat16().to(DEV)
     view = hid[:, :N]
-    ref = (view.double() + x1.double() @ w1.double().T + b1.double() + x2.double() @ w2.double().T + b2.double()).cpu()
+    view_in = view.double().clone()
+    ref = (view_in + x1.double() @ w1.double().T + b1.double() + x2.double() @ w2.double().T + b2.double()).cpu()
     two = ops.linear(x2.contiguous(), w2, b2, ops.linear(x1, w1, b1, view.contiguous())).double().cpu()
     pad = hid[:, N:].clone()
     check(lib().bt_linear2(_lib.BT_BF16, M, N, K1, ptr(x1), K1, ptr(w1), ptr(b1), K2, ptr(x2), x2.stride(0), ptr(w2), ptr(b2),
@@ -381,7 +384,8 @@ def test_linear2_large_stack_one_gemm(M, N, K1, K2):
     got = view.double().cpu()
     assert rel_err(got, ref) <= 8e-3, rel_err(got, ref)
     err = (got - ref).abs()
-    assert float((err - 1e-2 * ref.abs() - 2e-2).max()) <= 0, float(err.max())   # elementwise: no tile / K-tile dropped
+    inter = (view_in + x2.double() @ w2.double().T + b2.double()).abs().cpu()     # what a two-launch form rounds to bf16 in between
+    assert float((err - 1e-2 * ref.abs() - 2e-2 - 2.0 ** -8 * inter).max()) <= 0, float(err.max())   # elementwise: no tile / K-tile dropped
     assert rel_err(got, two) <= 1.2e-2
     assert torch.equal(hid[:, N:], pad)
 

@@ -240,8 +240,8 @@ def main():
     if args.what == "gemm":
         res.append(probe_gemm(args.m, args.n, args.k, args.iters, act=args.act, res=args.res))
     elif args.what == "sk":      # round 5: stream-K items kernel vs the round-4 dispatch on the decode step's GEMM shapes
-        for M in ((args.m,) if args.m != 32768 else (4096, 8192, 2048, 6144)):
-            res.append(probe_sk(M, args.iters))
+        for M in ((args.m,) if args.m != 32768 else (4096, 8192, 2048, 6144, 32768)):
+            res.append(probe_sk(M, args.iters if M < 32768 else 10))
     elif args.what == "lin2":    # the residual-stream projections of block_main_b4_1.2b at decode / prefill stack heights
         for M in (4096, 8192, 16384, 32768):
             res.append(probe_lin2(M, 2048, 8192, 2048, args.iters))
