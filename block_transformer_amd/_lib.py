@@ -29,7 +29,8 @@ class bt_decoder_dims(Structure):
 
 class bt_layer_weights(Structure):
     _fields_ = [(n, c_void_p) for n in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "qkv_w", "qkv_b", "dense_w", "dense_b",
-                                        "h4_w", "h4_b", "h_w", "h_b")]
+                                        "h4_w", "h4_b", "h_w", "h_b",
+                                        "qkv_wf", "qkv_s", "qkv_c", "h4_wf", "h4_s", "h4_c")]   # folded LayerNorm (optional)
 
 
 class bt_decoder_weights(Structure):
@@ -98,6 +99,10 @@ _SIGS = {
     "bt_stream_k_scratch_bytes": (c_int64, []),
     "bt_linear2_ws": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                               c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
+    "bt_rowstats": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
+    "bt_lnfold_shape_ok": (c_int32, [c_int64, c_int64, c_int64]),
+    "bt_linear_lnfold": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                 c_int64, c_int, c_void_p]),
     "bt_ln_qkv_rope_append": (c_int, [c_int, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p,
                                       c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                       c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -165,6 +170,7 @@ _DEBUG_SIGS = {
     "bt_debug_no_few_rows_fusion": (None, [c_int]),
     "bt_debug_lin2_large": (None, [c_int]),
     "bt_debug_lin2_sk": (None, [c_int]),
+    "bt_debug_ln_fold": (None, [c_int]),
     "bt_debug_stream_k": (None, [c_int]),
     "bt_debug_no_two_branch": (None, [c_int]),
     "bt_debug_ln_streaming": (None, [c_int]),

@@ -100,6 +100,12 @@ struct EpiArgs {
     QkvEpi q;
     uint2* amax;      // PP_ARGMAX: per (row, 64-column slab) {bits of the largest bf16-rounded value, its column}; [M][amax_ld]
     int amax_ld;
+    // LayerNorm folded into the GEMM (round 5; persistent kernel, EABL bit 32): the GEMM runs on the RAW rows x with the weight
+    // W' = W diag(gamma), and the epilogue turns  acc = W' x  into  W (gamma (x - mu) rstd + beta) + b  =  rstd (acc - mu s) + c
+    // with  s[n] = sum_k W'[n, k]  and  c[n] = (W beta)[n] + b[n]:
+    const float2* ln_stats;   // [M] (mu, rstd) of the rows (bt_rowstats), or NULL
+    const float* ln_s;        // [N]
+    const float* ln_c;        // [N]
 };
 
 __device__ inline void epi_store4(const EpiArgs& e, int m, int n, float (&v)[4], bool vec_ok) {
@@ -1546,6 +1552,37 @@ __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x
                                    int lane) {
     const int M = e.M, N = e.N;
     constexpr bool qkv = MODE == PP_QKV;
+    if constexpr ((EABL & 32) != 0) {
+        // folded LayerNorm (EpiArgs.ln_*): acc <- rstd[m] * (acc - mu[m] * s[n]) + c[n].  The lane holds output rows m = 16-row fragment
+        // ai, row (lane & 15), and for every 16-column fragment jf the 4 columns (lane >> 4) * 4 + r.  All 24 loads first (8 row
+        // statistics, 2 x 4 column vectors), then 2 FMAs per value:  acc * a + (b * s + c)  with  a = rstd,  b = -rstd * mu.
+        float2 st[8];
+        float4 sv[4], cv[4];
+#pragma unroll
+        for (int ai = 0; ai < 8; ++ai) {
+            int m = cm0 + (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16 + (lane & 15);
+            m = m < M ? m : M - 1;
+            st[ai] = e.ln_stats[m];
+        }
+#pragma unroll
+        for (int jf = 0; jf < 4; ++jf) {
+            int n = n_wave + jf * 16 + (lane >> 4) * 4;
+            n = n <= N - 4 ? n : N - 4;
+            sv[jf] = *reinterpret_cast<const float4*>(e.ln_s + n);
+            cv[jf] = *reinterpret_cast<const float4*>(e.ln_c + n);
+        }
+#pragma unroll
+        for (int ai = 0; ai < 8; ++ai) {
+            const float a = st[ai].y, b = -st[ai].y * st[ai].x;
+#pragma unroll
+            for (int jf = 0; jf < 4; ++jf) {
+                const float sj[4] = {sv[jf].x, sv[jf].y, sv[jf].z, sv[jf].w};
+                const float cj[4] = {cv[jf].x, cv[jf].y, cv[jf].z, cv[jf].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[ai][jf][r] = fmaf(acc[ai][jf][r], a, fmaf(b, sj[r], cj[r]));
+            }
+        }
+    }
     // ---- sweep A ----  (two batches of 4 fragments: 32 transient registers, two exposed load latencies)
     if (qkv) {
         const int D = e.q.head_dim;
@@ -2284,7 +2321,7 @@ __device__ inline void glds16_sbase_off(const char* base_uniform, uint32_t voff,
 // (Measured and rejected, round 3, profiles/r3_ppab_dmac.jsonl: issuing the second half-tile of each phase in the middle of the
 //  phase's MFMA cluster -- shorter load segment, two DMA issues among the MFMAs -- is 3-8 % SLOWER on every shape: the MFMA
 //  cluster, not the load segment, is the critical resource of a phase.)
-template <int MODE, int ABL = 0>
+template <int MODE, int ABL = 0, bool LNF = false>
 __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* __restrict__ A, int64_t lda,
                                                                   const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
                                                                   int K, int tiles_m, int tiles_n) {
@@ -2635,7 +2672,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
         }
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
-        P::template epilogue<MODE, (ABL >> 5) & 3 | ((ABL >> 6) & 12) | ((ABL >> 12) & 16)>(ep, pos0, stage, acc, cm0, cn0 + wcol, wm, lane_e);
+        P::template epilogue<MODE, (ABL >> 5) & 3 | ((ABL >> 6) & 12) | ((ABL >> 12) & 16) | (LNF ? 32 : 0)>(ep, pos0, stage, acc, cm0, cn0 + wcol, wm, lane_e);
     }
     if (!grp1) cbarrier();
 }
@@ -4265,6 +4302,20 @@ BT_KNOB int g_gemm_variant = 0;   // 0 auto; 1 force 128^2; 2/3 256^2 four-phase
 
 using namespace bt;
 
+// LayerNorm folded into a GEMM (EpiArgs.ln_*): the caller passes the raw rows as A, the folded weight W diag(gamma) as W, no bias
+struct LnFold {
+    const float2* stats;   // [M] (mu, rstd): bt_rowstats
+    const float* s;        // [N] row sums of the folded weight
+    const float* c;        // [N] W beta + b
+};
+// the persistent 256 x 256 kernel's own dispatch rule (the only kernel with the folded-LayerNorm epilogue)
+static bool pp2_takes(int64_t M, int64_t N, int64_t K) {
+    const int64_t tiles256 = ceil_div(M, BM2) * ceil_div(N, BN2);
+    return (K % BK == 0) && K / BK >= 4 && (N % 8 == 0) &&
+           tiles256 >= 192 && (tiles256 % 256 == 0 || tiles256 >= 1024 || (tiles256 % 256) >= 96) &&
+           4 * M * N >= 3 * tiles256 * (int64_t)(BM2 * BN2);
+}
+
 // ---- stream-K items plan (gemm_bf16_mfma256sk_kernel) --------------------------------------------------------------------------
 // T output tiles x C chunks of nk K-tiles, dealt tile-major in runs of q to G workgroups.  Picks the LARGEST nk (fewest item
 // boundaries) for which the items divide evenly, an item never straddles the two operand pairs, and no tile is shared by more than
@@ -4321,7 +4372,7 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                        const void* bias, const void* residual, int64_t ldr, void* out, int64_t ldo, int act,
                        const QkvEpi* qkv, bool* fused_out, bt_stream stream, void* scratch = nullptr,
                        int64_t scratch_bytes = 0, const Seg2* seg2 = nullptr, uint2* amax = nullptr, int amax_ld = 0,
-                       bool store_out = true, bool* amax_done = nullptr, bool sk_clean = false) {
+                       bool store_out = true, bool* amax_done = nullptr, bool sk_clean = false, const LnFold* lnf = nullptr) {
     // seg2 (bt_linear2, > 64 rows): a second (x2, W2, bias2) operand pair accumulated into the same output tiles; only
     // the persistent 256^2 kernel and the non-split small-tile family take it -> BT_ERR_UNSUPPORTED otherwise
     BT_CHECK_ARG(dtype == BT_F32 || dtype == BT_BF16, "bt_linear: bad dtype %d", dtype);
@@ -4371,7 +4422,21 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
         // stream-K items kernel: full 256 x 256 tiles whose count leaves the persistent kernel's last round under 90 % full
         // (M = 4096 QKV: 384 tiles = 1.5 rounds), and every two-pair problem (bt_linear2 above 256 rows: attention.dense +
         // dense_4h_to_h as ONE K = H + I GEMM; M = 4096: 128 tiles x 10 chunks over 256 workgroups).  Needs the caller's scratch.
-        if (g_sk && mfma_ok && g_gemm_variant == 0 && scratch && aligned16(scratch) && M > 256 && (ldo % 8 == 0) && aligned16(out) &&
+        if (lnf) {
+            // folded LayerNorm: only the persistent kernel has that epilogue -- refuse anything it would not take, before any launch
+            const bool ok = mfma_ok && !seg2 && !residual && !bias && !amax && g_gemm_variant == 0 && pp2_takes(M, N, K) && (ldo % 8 == 0) &&
+                            aligned16(out) && lnf->stats && lnf->s && lnf->c && aligned16(lnf->s) && aligned16(lnf->c) &&
+                            (reinterpret_cast<uintptr_t>(lnf->stats) & 7u) == 0 && N % 4 == 0 && (!qkv || ep.q.enabled);
+            if (!ok) {
+                set_error("bt_linear (folded LayerNorm): bf16, no bias / residual, and a shape the persistent 256 x 256 kernel takes "
+                          "(>= 192 tiles, last round >= 96 tiles) are required");
+                return BT_ERR_UNSUPPORTED;
+            }
+            ep.ln_stats = lnf->stats;
+            ep.ln_s = lnf->s;
+            ep.ln_c = lnf->c;
+        }
+        if (!lnf && g_sk && mfma_ok && g_gemm_variant == 0 && scratch && aligned16(scratch) && M > 256 && (ldo % 8 == 0) && aligned16(out) &&
             (!residual || (ldr % 8 == 0 && aligned16(residual))) && (!bias || aligned16(bias)) && !amax &&
             (act == BT_ACT_NONE || !residual)) {
             const int G = num_cus();
@@ -4556,7 +4621,13 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
 #define BT_LAUNCH_PP2(MODE_) do { set_error("bt_linear2: two-pair 256 x 256 kernel is a debug-build A/B kernel"); return BT_ERR_UNSUPPORTED; } while (0)
 #endif
                         // (the engine never combines these: QKV has no activation / residual, GELU has no residual)
-                        if (seg2 && residual) BT_LAUNCH_PP2(PP_RES);
+#define BT_LAUNCH_PP_LNF(MODE_)                                                                                       \
+    hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 0, true>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A, lda, \
+                       (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n)
+                        if (lnf && ep.q.enabled) BT_LAUNCH_PP_LNF(PP_QKV);
+                        else if (lnf && act == BT_ACT_GELU) BT_LAUNCH_PP_LNF(PP_GELU);
+                        else if (lnf) BT_LAUNCH_PP_LNF(PP_PLAIN);
+                        else if (seg2 && residual) BT_LAUNCH_PP2(PP_RES);
                         else if (seg2) BT_LAUNCH_PP2(PP_PLAIN);
                         else if (ep.q.enabled) BT_LAUNCH_PP(PP_QKV);
                         else if (act == BT_ACT_GELU && !residual) BT_LAUNCH_PP(PP_GELU);
@@ -4580,6 +4651,7 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
 #undef BT_PP2_ABL_AB
 #undef BT_PP_ABL_AB
 #undef BT_LAUNCH_PP2
+#undef BT_LAUNCH_PP_LNF
 #undef BT_PP_MMA32_AB
                     } else {
                         BT_LAUNCH_256((gemm_bf16_mfma256p2_kernel<true>));
@@ -4788,14 +4860,32 @@ extern "C" int bt_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_t h
                                   int32_t pos0_host, const int32_t* pos_table, const float* cos_tab, const float* sin_tab,
                                   void* scratch, int64_t scratch_bytes, bt_stream stream) {
     return bt::qkv_rope_append_impl(dtype, B, q_len, heads, head_dim, rot, x, ldx, qkv_w, qkv_b, qkv, ld_qkv, k_cache, v_cache, n_max,
-                                    pos0_dev, pos0_host, pos_table, cos_tab, sin_tab, scratch, scratch_bytes, false, stream);
+                                    pos0_dev, pos0_host, pos_table, cos_tab, sin_tab, scratch, scratch_bytes, false, stream, nullptr,
+                                    nullptr, nullptr);
+}
+
+// ---- LayerNorm folded into the consuming GEMM (round 5) ---------------------------------------------------------------------------
+// out = act( LayerNorm(x; gamma, beta) . W^T + b )  computed as  act( rstd (x . W'^T - mu s) + c )  on the RAW rows x:
+//   W' = W diag(gamma) (bf16, [N, K]),  s[n] = sum_k W'[n, k],  c[n] = (W beta)[n] + b[n]  (fp32, built once per weight by the caller:
+//   block_transformer_amd/runtime.py),  stats[m] = (mu, rstd) of row m (bt_rowstats).  The stand-alone LayerNorm launch of a large
+//   stack read M H and wrote 2 M H elements; bt_rowstats reads M H and writes 8 M bytes.  Only where the persistent 256 x 256
+//   kernel takes the shape (bt_lnfold_shape_ok); BT_ERR_UNSUPPORTED otherwise, nothing launched.
+extern "C" int32_t bt_lnfold_shape_ok(int64_t M, int64_t N, int64_t K) { return (M > 256 && pp2_takes(M, N, K) && g_gemm_variant == 0) ? 1 : 0; }
+
+extern "C" int bt_linear_lnfold(int dtype, int64_t M, int64_t N, int64_t K, const void* x, int64_t ldx, const void* stats,
+                                const void* w_folded, const float* s_vec, const float* c_vec, void* out, int64_t ldo, int act,
+                                bt_stream stream) {
+    BT_CHECK_ARG(stats && s_vec && c_vec, "bt_linear_lnfold: null pointer");
+    LnFold lnf{reinterpret_cast<const float2*>(stats), s_vec, c_vec};
+    return linear_impl(dtype, M, N, K, x, ldx, w_folded, nullptr, nullptr, 0, out, ldo, act, nullptr, nullptr, stream, nullptr, 0, nullptr,
+                       nullptr, 0, true, nullptr, false, &lnf);
 }
 
 int bt::qkv_rope_append_impl(int dtype, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim, int32_t rot, const void* x,
                              int64_t ldx, const void* qkv_w, const void* qkv_b, void* qkv, int64_t ld_qkv, void* k_cache,
                              void* v_cache, int64_t n_max, const int32_t* pos0_dev, int32_t pos0_host, const int32_t* pos_table,
                              const float* cos_tab, const float* sin_tab, void* scratch, int64_t scratch_bytes, bool sk_clean,
-                             bt_stream stream) {
+                             bt_stream stream, const void* ln_stats, const float* ln_s, const float* ln_c) {
     BT_CHECK_ARG(B >= 0 && q_len > 0 && heads > 0 && head_dim > 0, "bt_qkv_rope_append: bad shape");
     BT_CHECK_ARG(x && qkv_w && qkv && k_cache && v_cache && cos_tab && sin_tab, "bt_qkv_rope_append: null pointer");
     BT_CHECK_ARG(pos0_dev || (pos0_host >= 0 && pos0_host + q_len <= n_max), "bt_qkv_rope_append: cache overflow");
@@ -4819,9 +4909,14 @@ int bt::qkv_rope_append_impl(int dtype, int64_t B, int32_t q_len, int32_t heads,
     bool fused = false;
     // skinny problems stream W faster with split-K (an unfused RoPE pass over a few rows costs nothing)
     const bool skinny = scratch != nullptr && ceil_div(M, 64) * ceil_div(3 * H, 64) < 256;
+    LnFold lnf{reinterpret_cast<const float2*>(ln_stats), ln_s, ln_c};
+    if (ln_stats && !(fusable && !skinny)) {
+        set_error("bt_qkv_rope_append (folded LayerNorm): needs the fused RoPE + append epilogue (bf16, rot == 32, head_dim %% 32 == 0)");
+        return BT_ERR_UNSUPPORTED;
+    }
     BT_TRY(linear_impl(dtype, M, 3 * H, H, x, ldx, qkv_w, qkv_b, nullptr, 0, qkv, ld_qkv, BT_ACT_NONE,
                        (fusable && !skinny) ? &q : nullptr, &fused, stream, scratch, scratch_bytes, nullptr, nullptr, 0, true, nullptr,
-                       sk_clean));
+                       sk_clean, ln_stats ? &lnf : nullptr));
     if (!fused)
         BT_TRY(bt_rope_kv_append(dtype, B, q_len, heads, head_dim, rot, qkv, ld_qkv, k_cache, v_cache, n_max, pos0_dev,
                                  pos0_host, pos_table, cos_tab, sin_tab, stream));

@@ -139,6 +139,65 @@ __global__ __launch_bounds__(256) void layernorm_reg_kernel(const T* __restrict_
     }
 }
 
+// Row statistics only (round 5: LayerNorm folded into the consuming GEMMs, gemm.hip EpiArgs.ln_*): stats[row] = (mean, rstd) with
+// exactly layernorm_reg_kernel's arithmetic (same per-lane summation order, two-pass variance) -- reads M*H elements, writes 8 M
+// bytes instead of 2 M H elements.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void rowstats_reg_kernel(const T* __restrict__ x, int64_t ldx, float2* __restrict__ stats, int64_t M,
+                                                          int H, float eps) {
+    constexpr int V = Elem<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const T* xr = x + row * ldx;
+    float v[NV][V];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = (i * 64 + lane) * V;
+        if (c < H) load_vec<T>(xr + c, v[i]);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if ((i * 64 + lane) * V < H) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) sum += v[i][j];
+        }
+    const float mean = wave_sum(sum) / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if ((i * 64 + lane) * V < H) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                const float d = v[i][j] - mean;
+                sq = fmaf(d, d, sq);
+            }
+        }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)H + eps);
+    if (lane == 0) stats[row] = float2{mean, rstd};
+}
+
+int rowstats_impl(int dtype, int64_t M, int64_t H, const void* x, int64_t ldx, float eps, void* stats, bt_stream stream) {
+    BT_CHECK_ARG(dtype == BT_BF16, "bt_rowstats: bf16 only");
+    BT_CHECK_ARG(M >= 0 && H > 0 && H % 8 == 0 && H <= 8 * 64 * 8 && ldx >= H && ldx % 8 == 0 && x && stats && aligned16(x) &&
+                     (reinterpret_cast<uintptr_t>(stats) & 7u) == 0,
+                 "bt_rowstats: rows of <= 4096 bf16 elements in 16-byte units, 8-byte aligned stats");
+    if (M == 0) return BT_OK;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(BT_PROF_LAYERNORM, s);
+    const unsigned grid = (unsigned)ceil_div(M, 4);
+    const int nv = (int)ceil_div(H, (int64_t)64 * 8);
+#define BT_RS(NV_) hipLaunchKernelGGL((rowstats_reg_kernel<bf16, NV_>), dim3(grid), dim3(256), 0, s, (const bf16*)x, ldx, (float2*)stats, M, (int)H, eps)
+    if (nv <= 1) BT_RS(1);
+    else if (nv <= 2) BT_RS(2);
+    else if (nv <= 4) BT_RS(4);
+    else BT_RS(8);
+#undef BT_RS
+    BT_LAUNCH_CHECK("bt_rowstats launch");
+    return BT_OK;
+}
+
 #ifdef BT_DEBUG_HOOKS
 static bool g_ln_streaming = false;   // A/B (debug library only): force the three-pass streaming kernel
 #else
@@ -190,6 +249,10 @@ extern "C" int bt_layernorm(int dtype, int64_t M, int64_t H, const void* x, int6
     if (dtype == BT_BF16)
         return launch_ln<bf16>(M, H, x, ldx, w1, b1, out1, ldo1, w2, b2, out2, ldo2, eps, (hipStream_t)stream);
     return launch_ln<float>(M, H, x, ldx, w1, b1, out1, ldo1, w2, b2, out2, ldo2, eps, (hipStream_t)stream);
+}
+
+extern "C" int bt_rowstats(int dtype, int64_t M, int64_t H, const void* x, int64_t ldx, float eps, void* stats, bt_stream stream) {
+    return bt::rowstats_impl(dtype, M, H, x, ldx, eps, stats, stream);
 }
 
 #ifdef BT_DEBUG_HOOKS

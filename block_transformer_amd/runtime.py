@@ -82,6 +82,14 @@ class Workspace:
 _shared_ws = Workspace()
 
 
+def _version(p: torch.Tensor) -> int:
+    """In-place modification counter of a parameter (inference tensors do not keep one: 0)."""
+    try:
+        return int(p._version)
+    except RuntimeError:
+        return 0
+
+
 class DecoderRuntime:
     """ctypes view of one GPT-NeoX stack's parameters (HF layout, used in place — no repack, no copy)."""
 
@@ -96,6 +104,8 @@ class DecoderRuntime:
         self._layers = None
         self._weights = None
         self._tables = {}
+        self._folded = None      # per layer (qkv_wf, qkv_s, qkv_c, h4_wf, h4_s, h4_c): LayerNorm folded into its consumers (bf16 only)
+        self.fold_layernorm = True
 
     def _params(self) -> List[torch.Tensor]:
         out = []
@@ -114,12 +124,34 @@ class DecoderRuntime:
         hipGraphs on it, so re-materialised parameters (``.to()``, ``load_state_dict(assign=True)``) are never replayed
         through stale pointers."""
         params = self._params()
-        return tuple(p.data_ptr() for p in params) + (params[0].dtype,)
+        fold = self.fold_layernorm and params[0].dtype == torch.bfloat16 and params[0].is_cuda
+        return tuple(p.data_ptr() for p in params) + (params[0].dtype, fold) + (tuple(_version(p) for p in params) if fold else ())
+
+    def _fold(self, params):
+        """LayerNorm folded into the two projections that consume it (bt_layer_weights.*_wf / *_s / *_c, include/bt_hip.h): for a
+        bf16 stack, per layer  W' = W diag(gamma) (bf16),  s = row sums of W' (of the ROUNDED values: what the GEMM multiplies),
+        c = W beta + b  (fp32).  One-time weight preparation with torch ops -- not on the hot path; the HF-layout parameters stay
+        untouched (the fold costs 7 H^2 extra bf16 elements per layer: 1.4 GB for both 1.2B stacks).  HF GPTNeoXLayer:
+        input_layernorm -> attention.query_key_value, post_attention_layernorm -> mlp.dense_h_to_4h."""
+        out = []
+        with torch.no_grad():
+            for i in range(len(self.module.layers)):
+                ln1w, ln1b, ln2w, ln2b, qw, qb, _, _, hw, hb, _, _ = params[12 * i:12 * i + 12]
+                rec = []
+                for w, b, g, beta in ((qw, qb, ln1w, ln1b), (hw, hb, ln2w, ln2b)):
+                    wf = (w.float() * g.float()[None, :]).to(w.dtype).contiguous()
+                    svec = wf.float().sum(dim=1).contiguous()
+                    cvec = (w.float() @ beta.float() + b.float()).contiguous()
+                    rec += [wf, svec, cvec]
+                out.append(rec)
+        return out
 
     def weights(self) -> bt_decoder_weights:
-        """(Re)build the pointer table when parameters moved (``.to(device)``, dtype cast, checkpoint load)."""
+        """(Re)build the pointer table when parameters moved (``.to(device)``, dtype cast, checkpoint load) -- and, because the folded
+        LayerNorm weights are COPIES, also when a parameter was modified in place (its version counter moved)."""
         params = self._params()
-        key = tuple(p.data_ptr() for p in params) + (params[0].dtype,)
+        fold = self.fold_layernorm and params[0].dtype == torch.bfloat16 and params[0].is_cuda
+        key = tuple(p.data_ptr() for p in params) + (params[0].dtype, fold) + (tuple(_version(p) for p in params) if fold else ())
         if key != self._key:
             dt = params[0].dtype
             for p in params:
@@ -129,8 +161,10 @@ class DecoderRuntime:
                     raise _lib.BtError("all decoder parameters must share one dtype and be contiguous")
             n = len(self.module.layers)
             arr = (bt_layer_weights * n)()
+            self._folded = self._fold(params) if fold else None
             for i in range(n):
-                arr[i] = bt_layer_weights(*[p.data_ptr() for p in params[12 * i:12 * i + 12]])
+                extra = [t.data_ptr() for t in self._folded[i]] if fold else []
+                arr[i] = bt_layer_weights(*([p.data_ptr() for p in params[12 * i:12 * i + 12]] + extra))
             self._layers = arr
             self._weights = bt_decoder_weights(ctypes.cast(arr, ctypes.POINTER(bt_layer_weights)),
                                                params[-2].data_ptr(), params[-1].data_ptr())

@@ -813,6 +813,81 @@ def test_stream_k_hand_off_under_uneven_load():
     assert int(scratch.view(torch.int32)[G * 65536:G * 65536 + G * 8 + 1].abs().max()) == 0
 
 
+# ---- LayerNorm folded into the consuming GEMM (round 5) --------------------------------------------------------------------------
+def _fold(w, b, gamma, beta):
+    """what block_transformer_amd/runtime.py builds per projection"""
+    wf = (w.float() * gamma.float()[None, :]).bfloat16().contiguous()
+    return wf, wf.float().sum(1).contiguous(), (w.float() @ beta.float() + (0 if b is None else b.float())).contiguous()
+
+
+@pytest.mark.parametrize("M,H", [(7, 256), (33, 2048), (4099, 2048), (5, 4096), (300, 1024)])
+def test_rowstats_equals_layernorm_statistics(M, H):
+    """bt_rowstats: (mean, rstd) per row == fp64 LayerNorm statistics, rows strided."""
+    x = (rnd(M, H + 8, seed=3) * 3 + rnd(M, 1, seed=4)).bfloat16().to(DEV)[:, :H]
+    stats = torch.full((M, 2), float("nan"), dtype=torch.float32, device=DEV)
+    check(lib().bt_rowstats(_lib.BT_BF16, M, H, ptr(x), x.stride(0), 1e-5, ptr(stats), current_stream()))
+    torch.cuda.synchronize()
+    xd = x.double()
+    mu = xd.mean(1)
+    rstd = 1.0 / torch.sqrt(((xd - mu[:, None]) ** 2).mean(1) + 1e-5)
+    assert (stats[:, 0].double() - mu).abs().max().item() <= 1e-5 * (1 + mu.abs().max().item())
+    assert ((stats[:, 1].double() - rstd).abs() / rstd).max().item() <= 1e-5
+
+
+@pytest.mark.parametrize("act", ["none", "gelu"])
+@pytest.mark.parametrize("M,N,K", [(4096, 8192, 2048), (4096, 6144, 2048), (8192, 8192, 2048), (512, 24576, 256), (2304, 6144, 2048)])
+def test_linear_lnfold_vs_fp64_layernorm_then_linear(M, N, K, act):
+    """bt_linear_lnfold: act(LayerNorm(x) W^T + b) through the folded form -- raw rows x folded weight W diag(gamma), epilogue
+    rstd (acc - mean s) + c -- against fp64 LayerNorm + linear, and against the two-launch form it replaces (bt_layernorm, then
+    bt_linear on the normalised bf16 rows): same error level (the fold skips the bf16 rounding of the normalised rows and rounds
+    W gamma instead).  Rows with a large common offset and one massive feature (what real residual streams look like)."""
+    assert lib().bt_lnfold_shape_ok(M, N, K) == 1
+    x = (rnd(M, K, seed=1) * 2.5 + 0.7 * rnd(M, 1, seed=2)).float()
+    x[:, 5] += 30.0
+    x = x.bfloat16().to(DEV)
+    w = rnd(N, K, seed=3, scale=K ** -0.5).bfloat16().to(DEV)
+    b = rnd(N, seed=4, scale=0.1).bfloat16().to(DEV)
+    gamma = (1 + 0.1 * rnd(K, seed=5)).bfloat16().to(DEV)
+    beta = (0.1 * rnd(K, seed=6)).bfloat16().to(DEV)
+    wf, s, c = _fold(w, b, gamma, beta)
+    stats = torch.empty(M, 2, dtype=torch.float32, device=DEV)
+    out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
+    a = _lib.BT_ACT_GELU if act == "gelu" else _lib.BT_ACT_NONE
+    check(lib().bt_rowstats(_lib.BT_BF16, M, K, ptr(x), K, 1e-5, ptr(stats), current_stream()))
+    check(lib().bt_linear_lnfold(_lib.BT_BF16, M, N, K, ptr(x), K, ptr(stats), ptr(wf), ptr(s), ptr(c), ptr(out), N, a, current_stream()))
+    ln = ops.layernorm(x, gamma, beta, 1e-5)
+    two = ops.linear(ln, w, b, act=act)
+    torch.cuda.synchronize()
+    xd = x.double()
+    mu = xd.mean(1, keepdim=True)
+    n = (xd - mu) / torch.sqrt(((xd - mu) ** 2).mean(1, keepdim=True) + 1e-5)
+    ref = (n * gamma.double() + beta.double()) @ w.double().T + b.double()
+    if act == "gelu":
+        ref = torch.nn.functional.gelu(ref)
+    e_fold = (out.double() - ref).abs()
+    e_two = (two.double() - ref).abs()
+    scale = ref.abs().max().item()
+    print(f"[lnfold M={M} N={N} K={K} {act}] max err fold {e_fold.max().item():.4f} vs two launches {e_two.max().item():.4f} (max|ref| {scale:.2f}); "
+          f"rms {e_fold.pow(2).mean().sqrt().item():.5f} vs {e_two.pow(2).mean().sqrt().item():.5f}")
+    assert not torch.isnan(out.float()).any()
+    assert e_fold.max().item() <= 1.2e-2 * scale + 1e-2
+    assert e_fold.pow(2).mean().sqrt().item() <= 1.5 * e_two.pow(2).mean().sqrt().item() + 1e-4
+    assert float((e_fold - 1e-2 * ref.abs() - 3e-2).max()) <= 0      # elementwise
+
+
+def test_linear_lnfold_refuses_shapes_the_persistent_kernel_does_not_take():
+    M, N, K = 300, 520, 256
+    assert lib().bt_lnfold_shape_ok(M, N, K) == 0
+    x = rnd(M, K, seed=1).bfloat16().to(DEV)
+    w = rnd(N, K, seed=2).bfloat16().to(DEV)
+    v = torch.zeros(max(N, 2 * M), dtype=torch.float32, device=DEV)
+    out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
+    rc = lib().bt_linear_lnfold(_lib.BT_BF16, M, N, K, ptr(x), K, ptr(v), ptr(w), ptr(v), ptr(v), ptr(out), N, 0, current_stream())
+    assert rc == -2 and b"folded LayerNorm" in lib().bt_last_error()
+    torch.cuda.synchronize()
+    assert float(out.float().abs().max()) == 0.0
+
+
 # ---- bt_attention -------------------------------------------------------------------------------------------------------------
 def attn_ref(qkv, kc, vc, B, q, heads, d, pos0, mask):
     """fp64 reference: query t sees keys j <= pos0+t with mask[b, j]; fully-masked rows -> 0."""

@@ -1956,6 +1956,57 @@ def test_two_branch_parallel_residual_is_bit_identical(B, dbg_lib):
     torch.cuda.empty_cache()
 
 
+def test_layernorm_folded_into_the_gemms_matches_the_layernorm_launch(dbg_lib):
+    """Round 5: above 256 rows the dual LayerNorm launch of a layer is replaced by bt_rowstats + the folded form inside the QKV and
+    h->4h GEMMs (bt_layer_weights.*_wf; raw residual stream x folded weight, epilogue rstd (acc - mean s) + c).  2-layer 1.2B-shaped
+    bf16 model with non-trivial LayerNorm weights / biases, B = 4096 (prefill chunks of 32768 rows, token step 0 at 8192 rows, the
+    other steps and the block-decoder step at 4096 rows all take the folded path): context embedding of the second block and every
+    token of two blocks against the fp32 oracle on the same bf16 weights, folded and unfolded (debug knob), and the two against each
+    other within the same budget."""
+    import dataclasses
+    base = named_dims("block_main_b4_1.2b")
+    dims = dataclasses.replace(base, name="b4_1.2b_2layer", bd=dataclasses.replace(base.bd, layers=2),
+                               td=dataclasses.replace(base.td, layers=2))
+    sd = random_state_dict(dims, seed=13, include_unused_embed_in=False, bias_std=0.05)     # LayerNorm gamma = 1 + N(0, .05), beta = N(0, .05)
+    model = load_block_transformer_from_dims(dims, "fp32", keep_unused_embed_in=False)
+    model.load_state_dict(sd, strict=True)
+    model = model.bfloat16().to(DEV)
+    model.token_decoder.generation_config.eos_token_id = None
+    model.keep_logits = True
+    o = oracle_from_dims(dims, {k: v.bfloat16().float() for k, v in sd.items()})
+    B, P, L = 4096, 32, dims.L
+    prompt = torch.randint(0, dims.vocab, (B, P), generator=torch.Generator().manual_seed(5))
+    rows = [0, 1999, B - 1]
+    res = {}
+    try:
+        for fold in (1, 0):
+            lib_ = dbg_lib
+            lib_.bt_debug_ln_fold(fold)
+            model._engine = None
+            out = model.generate(prompt.to(DEV), max_length=P + L + 1).cpu()
+            eng = model._engine
+            res[fold] = (out, eng.ctx.float().cpu()[rows], eng.tok.logits.float().cpu()[rows])
+    finally:
+        dbg_lib.bt_debug_ln_fold(1)
+        model._engine = None
+    assert model.block_decoder._rt._folded is not None and len(model.block_decoder._rt._folded) == 2
+    ref_ctx2, ref_lg2 = None, None
+    for fold, (out, ctx2, lg2) in res.items():
+        ref_ctx2, ref_lg2 = _oracle_first_token(o, out[rows, :P + L])
+        e_ctx, e_lg = (ctx2 - ref_ctx2).abs().max().item(), (lg2 - ref_lg2).abs().max().item()
+        b_ctx, b_lg = 3e-2 * ref_ctx2.abs().max().item() + 1e-2, 3e-2 * ref_lg2.abs().max().item() + 1e-2
+        print(f"[ln fold={fold}] block-2 ctx err {e_ctx:.4f} / {b_ctx:.4f}, logit err {e_lg:.4f} / {b_lg:.4f}")
+        assert e_ctx <= b_ctx and e_lg <= b_lg
+        _, ref_blk1 = oracle_block_logits(o, prompt[rows], out[rows, P:P + L])
+        assert_tokens_within_noise(ref_blk1, out[rows, P:P + L], 3e-2, 1e-2, f"ln fold={fold} first block")
+        assert torch.equal(out[:, :P], prompt)
+    d_ctx = (res[1][1] - res[0][1]).abs().max().item()
+    assert d_ctx <= 3e-2 * res[0][1].abs().max().item() + 1e-2, d_ctx
+    assert (res[1][0][:, P] == res[0][0][:, P]).float().mean().item() >= 0.97     # first tokens: bf16 near-ties only
+    del model
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("B", [1, 2])
 def test_few_rows_persistent_gemv_is_bit_identical(B, dbg_lib):
     """Round 4: <= 2 rows: the [QKV | h->4h] launch as ~2 resident workgroups per CU that stage and LayerNorm x once and walk their
