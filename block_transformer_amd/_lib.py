@@ -99,10 +99,6 @@ _SIGS = {
     "bt_stream_k_scratch_bytes": (c_int64, []),
     "bt_linear2_ws": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                               c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
-    "bt_rowstats": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
-    "bt_lnfold_shape_ok": (c_int32, [c_int64, c_int64, c_int64]),
-    "bt_linear_lnfold": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                 c_int64, c_int, c_void_p]),
     "bt_ln_qkv_rope_append": (c_int, [c_int, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p,
                                       c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64,
                                       c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
@@ -171,6 +167,10 @@ _DEBUG_SIGS = {
     "bt_debug_lin2_large": (None, [c_int]),
     "bt_debug_lin2_sk": (None, [c_int]),
     "bt_debug_ln_fold": (None, [c_int]),
+    "bt_debug_rowstats": (c_int, [c_int, c_int64, c_int64, c_void_p, c_int64, c_float, c_void_p, c_void_p]),
+    "bt_debug_lnfold_shape_ok": (c_int32, [c_int64, c_int64, c_int64]),
+    "bt_debug_linear_lnfold": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_int64, c_int, c_void_p]),
     "bt_debug_stream_k": (None, [c_int]),
     "bt_debug_no_two_branch": (None, [c_int]),
     "bt_debug_ln_streaming": (None, [c_int]),

@@ -238,7 +238,10 @@ int qkv_rope_append_impl(int dtype, int64_t B, int32_t q_len, int32_t heads, int
                          const int32_t* pos0_dev, int32_t pos0_host, const int32_t* pos_table, const float* cos_tab,
                          const float* sin_tab, void* scratch, int64_t scratch_bytes, bool sk_clean, bt_stream stream,
                          const void* ln_stats = nullptr, const float* ln_s = nullptr, const float* ln_c = nullptr);   // folded LayerNorm: x = raw rows, qkv_w = folded weight
+#ifdef BT_DEBUG_HOOKS   // folded-LayerNorm experiment (debug library only)
 int rowstats_impl(int dtype, int64_t M, int64_t H, const void* x, int64_t ldx, float eps, void* stats, bt_stream stream);
+bool lnfold_shape_ok(int64_t M, int64_t N, int64_t K);
+#endif
 int linear2_impl(int dtype, int64_t M, int64_t N, int64_t K1, const void* x1, int64_t ldx1, const void* W1, const void* bias1, int64_t K2,
                  const void* x2, int64_t ldx2, const void* W2, const void* bias2, const void* residual, int64_t ldr, void* out,
                  int64_t ldo, void* scratch, int64_t scratch_bytes, bool sk_clean, bt_stream stream);

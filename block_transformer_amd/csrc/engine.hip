@@ -39,16 +39,20 @@ extern "C" void bt_debug_no_two_branch(int on) { g_no_two_branch = on != 0; }
 // box, one setting per process, profiles/r5_ab_sk*_p2048.json: 126.2k -> 127.5k tok/s with 1, 128.5k with 2)
 static int g_lin2_sk = 2;
 extern "C" void bt_debug_lin2_sk(int mode) { g_lin2_sk = mode; }
-// > 256 rows (round 5): LayerNorm folded into the QKV and h->4h GEMMs when the layer carries folded weights (bt_layer_weights.*_wf):
-// bt_rowstats (reads M*H) instead of the dual LayerNorm launch (reads M*H, writes 2*M*H).  false = A/B against the LayerNorm launch
+// > 256 rows (round 5 experiment, debug build only): LayerNorm folded into the QKV and h->4h GEMMs when the layer carries folded weights
+// (bt_layer_weights.*_wf): row statistics (reads M*H) instead of the dual LayerNorm launch (reads M*H, writes 2*M*H).  Measured
+// (profiles/r5_ab_ln_fused.jsonl): LayerNorm family 95 -> 41 ms per generate, GEMM family +58 ms (the correction at the head of every
+// tile's epilogue) -- no net gain, so the product library does not carry it
 static bool g_ln_fold = true;
 extern "C" void bt_debug_ln_fold(int on) { g_ln_fold = on != 0; }
+extern "C" int bt_debug_linear_lnfold(int dtype, int64_t M, int64_t N, int64_t K, const void* x, int64_t ldx, const void* stats,
+                                      const void* w_folded, const float* s_vec, const float* c_vec, void* out, int64_t ldo, int act,
+                                      bt_stream stream);
 #else
 static constexpr int g_few_rows_max = 2;
 static constexpr bool g_no_few_rows_fusion = false;
 static constexpr bool g_lin2_large = false;
 static constexpr int g_lin2_sk = 2;
-static constexpr bool g_ln_fold = true;
 #endif
 
 static int64_t ws_elems(const bt_decoder_dims* d, int64_t M) {
@@ -221,10 +225,11 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
         const bool lin2_sk = !last && sk_ws && g_lin2_sk != 0 && (g_lin2_sk >= 2 || M <= 8192) && lw.h_b && lw.dense_b &&
                              aligned16(lw.h_b) && aligned16(lw.dense_b) && aligned16(lw.h_w) && aligned16(lw.dense_w) && aligned16(x) &&
                              sk_linear2_ok(M, H, I, H, sk_bytes);
+#ifdef BT_DEBUG_HOOKS
         // LayerNorm folded into its two consumers: both read the layer INPUT x, so this needs the launch order of the lin2_sk path
         // (h->4h before anything updates x in place) and shapes the persistent kernel takes; the statistics go where LN2 would
         const bool ln_fold = lin2_sk && g_ln_fold && lw.qkv_wf && lw.qkv_s && lw.qkv_c && lw.h4_wf && lw.h4_s && lw.h4_c &&
-                             dims->rot == 32 && dims->head_dim % 32 == 0 && bt_lnfold_shape_ok(M, 3 * H, H) && bt_lnfold_shape_ok(M, I, H);
+                             dims->rot == 32 && dims->head_dim % 32 == 0 && lnfold_shape_ok(M, 3 * H, H) && lnfold_shape_ok(M, I, H);
         if (ln_fold) {
             BT_TRY(rowstats_impl(dtype, M, H, x, H, dims->ln_eps, ln2, stream));
             BT_TRY(qkv_rope_append_impl(dtype, B, q_len, dims->heads, dims->head_dim, dims->rot, x, H, lw.qkv_wf, nullptr, qkv, 3 * H, kc, vc,
@@ -233,11 +238,12 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
             BT_TRY(attention_impl(dtype, attn->mode, B, q_len, dims->heads, dims->head_dim, qkv, 3 * H, kc, vc, attn->n_max,
                                   attn->pos0_dev, attn->pos0_host, attn->mask, attn->mask_ld, att, H, attn->n_split, attn->split_ws,
                                   attn->split_ws_bytes, skip, stream));
-            BT_TRY(bt_linear_lnfold(dtype, M, I, H, x, H, ln2, lw.h4_wf, lw.h4_s, lw.h4_c, h4, I, BT_ACT_GELU, stream));
+            BT_TRY(bt_debug_linear_lnfold(dtype, M, I, H, x, H, ln2, lw.h4_wf, lw.h4_s, lw.h4_c, h4, I, BT_ACT_GELU, stream));
             BT_TRY(linear2_impl(dtype, M, H, I, h4, I, lw.h_w, lw.h_b, H, att, H, lw.dense_w, lw.dense_b, x, H, x, H, scratch, sk_bytes,
                                 true, stream));
             continue;
         }
+#endif  // BT_DEBUG_HOOKS (folded LayerNorm)
         if (!last) {
             BT_TRY(bt_layernorm(dtype, M, H, x, H, lw.ln1_w, lw.ln1_b, ln1, H, lw.ln2_w, lw.ln2_b, ln2, H, dims->ln_eps,
                                 stream));

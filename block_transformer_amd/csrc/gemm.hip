@@ -4422,6 +4422,12 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
         // stream-K items kernel: full 256 x 256 tiles whose count leaves the persistent kernel's last round under 90 % full
         // (M = 4096 QKV: 384 tiles = 1.5 rounds), and every two-pair problem (bt_linear2 above 256 rows: attention.dense +
         // dense_4h_to_h as ONE K = H + I GEMM; M = 4096: 128 tiles x 10 chunks over 256 workgroups).  Needs the caller's scratch.
+#ifndef BT_DEBUG_HOOKS
+        if (lnf) {   // (measured: no net gain, profiles/r5_ab_ln_fused.jsonl -> the folded-LayerNorm epilogue is a debug-build experiment)
+            set_error("bt_linear (folded LayerNorm): only in the debug build of the library");
+            return BT_ERR_UNSUPPORTED;
+        }
+#endif
         if (lnf) {
             // folded LayerNorm: only the persistent kernel has that epilogue -- refuse anything it would not take, before any launch
             const bool ok = mfma_ok && !seg2 && !residual && !bias && !amax && g_gemm_variant == 0 && pp2_takes(M, N, K) && (ldo % 8 == 0) &&
@@ -4621,9 +4627,13 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
 #define BT_LAUNCH_PP2(MODE_) do { set_error("bt_linear2: two-pair 256 x 256 kernel is a debug-build A/B kernel"); return BT_ERR_UNSUPPORTED; } while (0)
 #endif
                         // (the engine never combines these: QKV has no activation / residual, GELU has no residual)
+#ifdef BT_DEBUG_HOOKS
 #define BT_LAUNCH_PP_LNF(MODE_)                                                                                       \
     hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 0, true>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A, lda, \
                        (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n)
+#else
+#define BT_LAUNCH_PP_LNF(MODE_) do { } while (0)   /* unreachable: lnf is refused above in the product build */
+#endif
                         if (lnf && ep.q.enabled) BT_LAUNCH_PP_LNF(PP_QKV);
                         else if (lnf && act == BT_ACT_GELU) BT_LAUNCH_PP_LNF(PP_GELU);
                         else if (lnf) BT_LAUNCH_PP_LNF(PP_PLAIN);
@@ -4870,16 +4880,25 @@ extern "C" int bt_qkv_rope_append(int dtype, int64_t B, int32_t q_len, int32_t h
 //   block_transformer_amd/runtime.py),  stats[m] = (mu, rstd) of row m (bt_rowstats).  The stand-alone LayerNorm launch of a large
 //   stack read M H and wrote 2 M H elements; bt_rowstats reads M H and writes 8 M bytes.  Only where the persistent 256 x 256
 //   kernel takes the shape (bt_lnfold_shape_ok); BT_ERR_UNSUPPORTED otherwise, nothing launched.
-extern "C" int32_t bt_lnfold_shape_ok(int64_t M, int64_t N, int64_t K) { return (M > 256 && pp2_takes(M, N, K) && g_gemm_variant == 0) ? 1 : 0; }
+// Built and measured in round 5 (profiles/r5_ab_ln_fused.jsonl, one setting per process): the LayerNorm family of a generate goes
+// 95 -> 41 ms, the GEMM family 2851 -> 2908 ms (24 dependent loads + 256 FMAs per lane at the head of every tile's epilogue, with the
+// next tile's operand stream waiting behind them) -- 125.7k tok/s either way.  So the mechanism lives in the DEBUG library only
+// (bt_debug_* entry points, the engine's bt_debug_ln_fold knob); the product keeps the dual LayerNorm launch.
+#ifdef BT_DEBUG_HOOKS
+namespace bt {
+bool lnfold_shape_ok(int64_t M, int64_t N, int64_t K) { return M > 256 && pp2_takes(M, N, K) && g_gemm_variant == 0; }
+}
+extern "C" int32_t bt_debug_lnfold_shape_ok(int64_t M, int64_t N, int64_t K) { return bt::lnfold_shape_ok(M, N, K) ? 1 : 0; }
 
-extern "C" int bt_linear_lnfold(int dtype, int64_t M, int64_t N, int64_t K, const void* x, int64_t ldx, const void* stats,
+extern "C" int bt_debug_linear_lnfold(int dtype, int64_t M, int64_t N, int64_t K, const void* x, int64_t ldx, const void* stats,
                                 const void* w_folded, const float* s_vec, const float* c_vec, void* out, int64_t ldo, int act,
                                 bt_stream stream) {
-    BT_CHECK_ARG(stats && s_vec && c_vec, "bt_linear_lnfold: null pointer");
+    BT_CHECK_ARG(stats && s_vec && c_vec, "bt_debug_linear_lnfold: null pointer");
     LnFold lnf{reinterpret_cast<const float2*>(stats), s_vec, c_vec};
     return linear_impl(dtype, M, N, K, x, ldx, w_folded, nullptr, nullptr, 0, out, ldo, act, nullptr, nullptr, stream, nullptr, 0, nullptr,
                        nullptr, 0, true, nullptr, false, &lnf);
 }
+#endif  // BT_DEBUG_HOOKS (folded LayerNorm entry points)
 
 int bt::qkv_rope_append_impl(int dtype, int64_t B, int32_t q_len, int32_t heads, int32_t head_dim, int32_t rot, const void* x,
                              int64_t ldx, const void* qkv_w, const void* qkv_b, void* qkv, int64_t ld_qkv, void* k_cache,

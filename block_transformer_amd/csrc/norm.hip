@@ -139,6 +139,7 @@ __global__ __launch_bounds__(256) void layernorm_reg_kernel(const T* __restrict_
     }
 }
 
+#ifdef BT_DEBUG_HOOKS   // the folded-LayerNorm experiment (gemm.hip, profiles/r5_ab_ln_fused.jsonl): debug library only
 // Row statistics only (round 5: LayerNorm folded into the consuming GEMMs, gemm.hip EpiArgs.ln_*): stats[row] = (mean, rstd) with
 // exactly layernorm_reg_kernel's arithmetic (same per-lane summation order, two-pass variance) -- reads M*H elements, writes 8 M
 // bytes instead of 2 M H elements.
@@ -179,10 +180,10 @@ __global__ __launch_bounds__(256) void rowstats_reg_kernel(const T* __restrict__
 }
 
 int rowstats_impl(int dtype, int64_t M, int64_t H, const void* x, int64_t ldx, float eps, void* stats, bt_stream stream) {
-    BT_CHECK_ARG(dtype == BT_BF16, "bt_rowstats: bf16 only");
+    BT_CHECK_ARG(dtype == BT_BF16, "bt_debug_rowstats: bf16 only");
     BT_CHECK_ARG(M >= 0 && H > 0 && H % 8 == 0 && H <= 8 * 64 * 8 && ldx >= H && ldx % 8 == 0 && x && stats && aligned16(x) &&
                      (reinterpret_cast<uintptr_t>(stats) & 7u) == 0,
-                 "bt_rowstats: rows of <= 4096 bf16 elements in 16-byte units, 8-byte aligned stats");
+                 "bt_debug_rowstats: rows of <= 4096 bf16 elements in 16-byte units, 8-byte aligned stats");
     if (M == 0) return BT_OK;
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(BT_PROF_LAYERNORM, s);
@@ -194,9 +195,11 @@ int rowstats_impl(int dtype, int64_t M, int64_t H, const void* x, int64_t ldx, f
     else if (nv <= 4) BT_RS(4);
     else BT_RS(8);
 #undef BT_RS
-    BT_LAUNCH_CHECK("bt_rowstats launch");
+    BT_LAUNCH_CHECK("bt_debug_rowstats launch");
     return BT_OK;
 }
+
+#endif  // BT_DEBUG_HOOKS (rowstats)
 
 #ifdef BT_DEBUG_HOOKS
 static bool g_ln_streaming = false;   // A/B (debug library only): force the three-pass streaming kernel
@@ -251,10 +254,9 @@ extern "C" int bt_layernorm(int dtype, int64_t M, int64_t H, const void* x, int6
     return launch_ln<float>(M, H, x, ldx, w1, b1, out1, ldo1, w2, b2, out2, ldo2, eps, (hipStream_t)stream);
 }
 
-extern "C" int bt_rowstats(int dtype, int64_t M, int64_t H, const void* x, int64_t ldx, float eps, void* stats, bt_stream stream) {
+#ifdef BT_DEBUG_HOOKS
+extern "C" int bt_debug_rowstats(int dtype, int64_t M, int64_t H, const void* x, int64_t ldx, float eps, void* stats, bt_stream stream) {
     return bt::rowstats_impl(dtype, M, H, x, ldx, eps, stats, stream);
 }
-
-#ifdef BT_DEBUG_HOOKS
 extern "C" void bt_debug_ln_streaming(int on) { bt::g_ln_streaming = on != 0; }
 #endif

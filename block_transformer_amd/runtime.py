@@ -104,8 +104,11 @@ class DecoderRuntime:
         self._layers = None
         self._weights = None
         self._tables = {}
-        self._folded = None      # per layer (qkv_wf, qkv_s, qkv_c, h4_wf, h4_s, h4_c): LayerNorm folded into its consumers (bf16 only)
-        self.fold_layernorm = True
+        # per layer (qkv_wf, qkv_s, qkv_c, h4_wf, h4_s, h4_c): LayerNorm folded into its consumers -- a round-5 experiment that measured
+        # no net gain (profiles/r5_ab_ln_fused.jsonl): built only on request AND with the debug library active (tests, A/B); the
+        # product library ignores the fields
+        self._folded = None
+        self.fold_layernorm = False
 
     def _params(self) -> List[torch.Tensor]:
         out = []
@@ -124,7 +127,7 @@ class DecoderRuntime:
         hipGraphs on it, so re-materialised parameters (``.to()``, ``load_state_dict(assign=True)``) are never replayed
         through stale pointers."""
         params = self._params()
-        fold = self.fold_layernorm and params[0].dtype == torch.bfloat16 and params[0].is_cuda
+        fold = self.fold_layernorm and _lib._debug_active and params[0].dtype == torch.bfloat16 and params[0].is_cuda
         return tuple(p.data_ptr() for p in params) + (params[0].dtype, fold) + (tuple(_version(p) for p in params) if fold else ())
 
     def _fold(self, params):
@@ -150,7 +153,7 @@ class DecoderRuntime:
         """(Re)build the pointer table when parameters moved (``.to(device)``, dtype cast, checkpoint load) -- and, because the folded
         LayerNorm weights are COPIES, also when a parameter was modified in place (its version counter moved)."""
         params = self._params()
-        fold = self.fold_layernorm and params[0].dtype == torch.bfloat16 and params[0].is_cuda
+        fold = self.fold_layernorm and _lib._debug_active and params[0].dtype == torch.bfloat16 and params[0].is_cuda
         key = tuple(p.data_ptr() for p in params) + (params[0].dtype, fold) + (tuple(_version(p) for p in params) if fold else ())
         if key != self._key:
             dt = params[0].dtype

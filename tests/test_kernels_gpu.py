@@ -813,7 +813,7 @@ def test_stream_k_hand_off_under_uneven_load():
     assert int(scratch.view(torch.int32)[G * 65536:G * 65536 + G * 8 + 1].abs().max()) == 0
 
 
-# ---- LayerNorm folded into the consuming GEMM (round 5) --------------------------------------------------------------------------
+# ---- LayerNorm folded into the consuming GEMM (round 5 experiment: debug library only, profiles/r5_ab_ln_fused.jsonl) ----------------
 def _fold(w, b, gamma, beta):
     """what block_transformer_amd/runtime.py builds per projection"""
     wf = (w.float() * gamma.float()[None, :]).bfloat16().contiguous()
@@ -821,11 +821,11 @@ def _fold(w, b, gamma, beta):
 
 
 @pytest.mark.parametrize("M,H", [(7, 256), (33, 2048), (4099, 2048), (5, 4096), (300, 1024)])
-def test_rowstats_equals_layernorm_statistics(M, H):
-    """bt_rowstats: (mean, rstd) per row == fp64 LayerNorm statistics, rows strided."""
+def test_rowstats_equals_layernorm_statistics(M, H, dbg_lib):
+    """bt_debug_rowstats: (mean, rstd) per row == fp64 LayerNorm statistics, rows strided."""
     x = (rnd(M, H + 8, seed=3) * 3 + rnd(M, 1, seed=4)).bfloat16().to(DEV)[:, :H]
     stats = torch.full((M, 2), float("nan"), dtype=torch.float32, device=DEV)
-    check(lib().bt_rowstats(_lib.BT_BF16, M, H, ptr(x), x.stride(0), 1e-5, ptr(stats), current_stream()))
+    check(lib().bt_debug_rowstats(_lib.BT_BF16, M, H, ptr(x), x.stride(0), 1e-5, ptr(stats), current_stream()))
     torch.cuda.synchronize()
     xd = x.double()
     mu = xd.mean(1)
@@ -836,12 +836,12 @@ def test_rowstats_equals_layernorm_statistics(M, H):
 
 @pytest.mark.parametrize("act", ["none", "gelu"])
 @pytest.mark.parametrize("M,N,K", [(4096, 8192, 2048), (4096, 6144, 2048), (8192, 8192, 2048), (512, 24576, 256), (2304, 6144, 2048)])
-def test_linear_lnfold_vs_fp64_layernorm_then_linear(M, N, K, act):
-    """bt_linear_lnfold: act(LayerNorm(x) W^T + b) through the folded form -- raw rows x folded weight W diag(gamma), epilogue
+def test_linear_lnfold_vs_fp64_layernorm_then_linear(M, N, K, act, dbg_lib):
+    """bt_debug_linear_lnfold: act(LayerNorm(x) W^T + b) through the folded form -- raw rows x folded weight W diag(gamma), epilogue
     rstd (acc - mean s) + c -- against fp64 LayerNorm + linear, and against the two-launch form it replaces (bt_layernorm, then
     bt_linear on the normalised bf16 rows): same error level (the fold skips the bf16 rounding of the normalised rows and rounds
     W gamma instead).  Rows with a large common offset and one massive feature (what real residual streams look like)."""
-    assert lib().bt_lnfold_shape_ok(M, N, K) == 1
+    assert lib().bt_debug_lnfold_shape_ok(M, N, K) == 1
     x = (rnd(M, K, seed=1) * 2.5 + 0.7 * rnd(M, 1, seed=2)).float()
     x[:, 5] += 30.0
     x = x.bfloat16().to(DEV)
@@ -853,8 +853,8 @@ def test_linear_lnfold_vs_fp64_layernorm_then_linear(M, N, K, act):
     stats = torch.empty(M, 2, dtype=torch.float32, device=DEV)
     out = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device=DEV)
     a = _lib.BT_ACT_GELU if act == "gelu" else _lib.BT_ACT_NONE
-    check(lib().bt_rowstats(_lib.BT_BF16, M, K, ptr(x), K, 1e-5, ptr(stats), current_stream()))
-    check(lib().bt_linear_lnfold(_lib.BT_BF16, M, N, K, ptr(x), K, ptr(stats), ptr(wf), ptr(s), ptr(c), ptr(out), N, a, current_stream()))
+    check(lib().bt_debug_rowstats(_lib.BT_BF16, M, K, ptr(x), K, 1e-5, ptr(stats), current_stream()))
+    check(lib().bt_debug_linear_lnfold(_lib.BT_BF16, M, N, K, ptr(x), K, ptr(stats), ptr(wf), ptr(s), ptr(c), ptr(out), N, a, current_stream()))
     ln = ops.layernorm(x, gamma, beta, 1e-5)
     two = ops.linear(ln, w, b, act=act)
     torch.cuda.synchronize()
@@ -875,14 +875,14 @@ def test_linear_lnfold_vs_fp64_layernorm_then_linear(M, N, K, act):
     assert float((e_fold - 1e-2 * ref.abs() - 3e-2).max()) <= 0      # elementwise
 
 
-def test_linear_lnfold_refuses_shapes_the_persistent_kernel_does_not_take():
+def test_linear_lnfold_refuses_shapes_the_persistent_kernel_does_not_take(dbg_lib):
     M, N, K = 300, 520, 256
-    assert lib().bt_lnfold_shape_ok(M, N, K) == 0
+    assert lib().bt_debug_lnfold_shape_ok(M, N, K) == 0
     x = rnd(M, K, seed=1).bfloat16().to(DEV)
     w = rnd(N, K, seed=2).bfloat16().to(DEV)
     v = torch.zeros(max(N, 2 * M), dtype=torch.float32, device=DEV)
     out = torch.zeros(M, N, dtype=torch.bfloat16, device=DEV)
-    rc = lib().bt_linear_lnfold(_lib.BT_BF16, M, N, K, ptr(x), K, ptr(v), ptr(w), ptr(v), ptr(v), ptr(out), N, 0, current_stream())
+    rc = lib().bt_debug_linear_lnfold(_lib.BT_BF16, M, N, K, ptr(x), K, ptr(v), ptr(w), ptr(v), ptr(v), ptr(out), N, 0, current_stream())
     assert rc == -2 and b"folded LayerNorm" in lib().bt_last_error()
     torch.cuda.synchronize()
     assert float(out.float().abs().max()) == 0.0

@@ -1957,8 +1957,9 @@ def test_two_branch_parallel_residual_is_bit_identical(B, dbg_lib):
 
 
 def test_layernorm_folded_into_the_gemms_matches_the_layernorm_launch(dbg_lib):
-    """Round 5: above 256 rows the dual LayerNorm launch of a layer is replaced by bt_rowstats + the folded form inside the QKV and
-    h->4h GEMMs (bt_layer_weights.*_wf; raw residual stream x folded weight, epilogue rstd (acc - mean s) + c).  2-layer 1.2B-shaped
+    """Round 5 EXPERIMENT (debug library only: measured no net gain, profiles/r5_ab_ln_fused.jsonl): above 256 rows the dual LayerNorm
+    launch of a layer is replaced by row statistics + the folded form inside the QKV and h->4h GEMMs (bt_layer_weights.*_wf; raw
+    residual stream x folded weight, epilogue rstd (acc - mean s) + c; DecoderRuntime.fold_layernorm = True).  2-layer 1.2B-shaped
     bf16 model with non-trivial LayerNorm weights / biases, B = 4096 (prefill chunks of 32768 rows, token step 0 at 8192 rows, the
     other steps and the block-decoder step at 4096 rows all take the folded path): context embedding of the second block and every
     token of two blocks against the fp32 oracle on the same bf16 weights, folded and unfolded (debug knob), and the two against each
@@ -1978,6 +1979,8 @@ def test_layernorm_folded_into_the_gemms_matches_the_layernorm_launch(dbg_lib):
     prompt = torch.randint(0, dims.vocab, (B, P), generator=torch.Generator().manual_seed(5))
     rows = [0, 1999, B - 1]
     res = {}
+    for rt in (model.block_decoder._rt, model.token_decoder._rt):
+        rt.fold_layernorm = True
     try:
         for fold in (1, 0):
             lib_ = dbg_lib
