@@ -3289,6 +3289,175 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_kernel(const bf16* 
     }
 }
 
+// ---- 256 x 128 tiles cut along K into fp32 slabs: the mid-batch projections at 129 .. 256 rows (round 5) ----------------------------
+// At 129 .. 256 rows the 64 x 64 slab kernel above moves 16 KiB of operands from L2 per 0.5 MFLOP (32 flop per L2 -> LDS byte): its QKV
+// and h -> 4h launches sit on the L2 roof (22 us each at 256 rows = 0.29 PF, profiles/r4_bench_b256_kernel_stats.md), not on HBM.  This
+// kernel is the one-tile 256 x 128 kernel's K-loop (85 flop per byte, two staggered wave groups, half-tiles issued five ahead) with
+//   * the whole stack as ONE row tile: rows >= M are clamped in the LDS-DMA addresses (their products are never stored);
+//   * a K range per workgroup instead of the whole K: workgroup = (column tile, slice), slice s of a pair with nk K-tiles and S slices
+//     takes K-tiles [s nk / S, (s + 1) nk / S) -- slices need not be equal, which lets 16 column tiles x 16 slices cover the residual
+//     projections' 32 + 128 K-tiles with 256 workgroups; slices >= s1 belong to the optional second operand pair;
+//   * up to two problems per launch (the QKV projection and the MLP up-projection of a parallel-residual layer), each with its own
+//     operands, N and slab region;
+//   * the epilogue = plain 16-byte stores of the fp32 fragments into slab[slice][M][N] -- the format the mid-batch reduce kernels read.
+// Requires N % 128 == 0, K % 64 == 0, >= 4 K-tiles per slice (checked by the host).
+struct TallSide {
+    const bf16* A;
+    const bf16* W;
+    const bf16* A2;
+    const bf16* W2;
+    int64_t lda, ldw, lda2, ldw2;
+    float* partial;
+    int N, nk1, nk2, s1, s2;
+};
+struct TallArgs {
+    TallSide g[2];
+};
+
+__global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const TallArgs a, int M, int wg_side1) {
+    __shared__ __attribute__((aligned(16))) char smem[T21_SMEM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const bool grp1 = wave >= 4;
+    // side, column tile and slice: workgroup-uniform index into the kernel-argument array (scalar loads at a computed offset)
+    const int side = (int)blockIdx.x >= wg_side1 ? 1 : 0;
+    const TallSide& g = a.g[side];
+    const int id = (int)blockIdx.x - side * wg_side1;
+    const int S = g.s1 + g.s2;
+    const int slice = id % S, tn = id / S;   // consecutive ids (= XCDs) take different slices: an XCD's L2 holds S / 8 of the A columns
+    const bool second = slice >= g.s1;
+    const int sidx = second ? slice - g.s1 : slice, scnt = second ? g.s2 : g.s1, nk_all = second ? g.nk2 : g.nk1;
+    const int kb = (int)((int64_t)sidx * nk_all / scnt), ke = (int)((int64_t)(sidx + 1) * nk_all / scnt);
+    const int nk = ke - kb;
+    const bf16* A = second ? g.A2 : g.A;
+    const bf16* W = second ? g.W2 : g.W;
+    const int64_t lda = second ? g.lda2 : g.lda, ldw = second ? g.ldw2 : g.ldw;
+    const int N = g.N, n0 = tn * 128;
+
+    const uint32_t lane_slot = (uint32_t)(((lane & 7) ^ ((lane >> 3) & 7)) * 16);
+    // A rows of this lane's four DMA instructions per K-tile (half 0 / 1, rows +0 / +8), clamped to the stack
+    const int r0 = wave * 16 + (lane >> 3);
+    uint32_t va00 = (uint32_t)min(r0, M - 1) * (uint32_t)(lda * 2) + lane_slot;
+    uint32_t va01 = (uint32_t)min(r0 + 8, M - 1) * (uint32_t)(lda * 2) + lane_slot;
+    uint32_t va10 = (uint32_t)min(r0 + 128, M - 1) * (uint32_t)(lda * 2) + lane_slot;
+    uint32_t va11 = (uint32_t)min(r0 + 136, M - 1) * (uint32_t)(lda * 2) + lane_slot;
+    uint32_t voff_w = (uint32_t)(lane >> 3) * (uint32_t)(ldw * 2) + lane_slot;
+    const uint32_t row8_w = (uint32_t)(8 * ldw * 2);
+    const char* pa = reinterpret_cast<const char*>(A) + (int64_t)kb * (BK * 2);
+    const char* pw = reinterpret_cast<const char*>(W) + ((int64_t)(n0 + wave * 16) * ldw + (int64_t)kb * BK) * 2;
+    const uint32_t ring_lds = lds_addr(smem) + (uint32_t)wave * 2048u;
+    int lt = 0;
+    auto issue_a = [&](auto hc) {
+        constexpr int half = decltype(hc)::value;
+        const uint32_t ring = ring_lds + (uint32_t)(lt & 1) * (uint32_t)T21_STAGE;
+        glds16_sbase_off<half * HALF_BYTES>(pa, half ? va10 : va00, ring);
+        glds16_sbase_off<half * HALF_BYTES + 1024>(pa, half ? va11 : va01, ring);
+    };
+    auto issue_w = [&]() {
+        const uint32_t ring = ring_lds + (uint32_t)(lt & 1) * (uint32_t)T21_STAGE;
+        glds16_sbase_off<2 * HALF_BYTES>(pw, voff_w, ring);
+        glds16_sbase_off<2 * HALF_BYTES + 1024>(pw, voff_w + row8_w, ring);
+    };
+    auto advance = [&]() {
+        ++lt;
+        va00 += 128; va01 += 128; va10 += 128; va11 += 128;
+        voff_w += 128;
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    // the load stream, waits and barriers below are the one-tile kernel's (tests/test_gemm_ring_schedule.py checks that the two K-loops
+    // are the same text modulo the operand addressing): prologue = K-tile 0 (A0, W, A1) and A0, W of K-tile 1
+    issue_a(I0{});
+    issue_w();
+    issue_a(I1{});
+    advance();
+    if (nk > 1) {
+        issue_a(I0{});
+        issue_w();
+    }
+
+    f32x4_t acc[8][2];   // [A half * 4 + m-fragment][n-fragment]
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    bf16x8_t af[4][2], wf[2][2];
+
+    auto wait = [&](bool steady) {
+        if (steady) wait_vmcnt<T21_WAIT>();
+        else wait_vmcnt<0>();
+    };
+    if (grp1) {
+        wait(nk >= 3);
+        cbarrier();
+    }
+    for (int t = 0; t < nk; ++t) {
+        const bool steady = t + 3 <= nk;
+        const char* buf = smem + (t & 1) * T21_STAGE;
+        // ---- phase 0: A0, W ----
+        if (!grp1) wait(steady);
+        cbarrier();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) wf[nb][ks] = read_frag(buf + 2 * HALF_BYTES, wn * 32 + nb * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i][ks] = read_frag(buf, wm * 64 + i * 16, ks, lane);
+        }
+        if (t + 1 < nk) issue_a(I1{});
+        if (grp1) wait(steady);
+        if (grp1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        cbarrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][ks], af[i][ks], acc[i][nb], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        // ---- phase 1: A1 ----
+        if (!grp1) wait(steady);
+        cbarrier();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i][ks] = read_frag(buf + HALF_BYTES, wm * 64 + i * 16, ks, lane);
+        advance();
+        if (t + 2 < nk) {
+            issue_a(I0{});
+            issue_w();
+        }
+        if (grp1) wait(t + 4 <= nk);
+        if (grp1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        cbarrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[4 + i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][ks], af[i][ks], acc[4 + i][nb], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    }
+    if (!grp1) cbarrier();
+    // ---- slab stores: accumulator fragment = row (lane & 15), columns nb * 16 + (lane >> 4) * 4 .. + 3 ----
+    float* slab = g.partial + ((int64_t)slice * M) * N + n0 + wn * 32 + (lane >> 4) * 4;
+#pragma unroll
+    for (int ai = 0; ai < 8; ++ai) {
+        const int row = (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16 + (lane & 15);
+        if (row < M) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) *reinterpret_cast<f32x4_t*>(slab + (int64_t)row * N + nb * 16) = acc[ai][nb];
+        }
+    }
+}
+
 // ---- GEMV for a handful of rows (M <= 4): the weight-streaming regime of small-batch decode ------------------------------
 // out[m, n] = epi(sum_k x[m, k] * W[n, k]).  One pass over W at HBM speed is the whole cost (N*K*2 bytes; x is a few KiB), so
 // the kernel is a pure streamer: a wave owns RW rows of W, every lane keeps 4 x 16-byte loads per row in flight (a 2048-wide
@@ -4284,6 +4453,8 @@ BT_KNOB int g_mid_tile = 0;       // fused one-slice QKV / h->4h GEMMs at >= 128
 BT_KNOB bool g_mid_attn = true;   // ... and the token decoder's local-window attention inside that reduce launch (false: A/B)
 BT_KNOB bool g_mid_dual = true;   // 17..256 rows: QKV and h->4h split-K GEMMs of a layer in one launch, their reductions in one (false: A/B)
 BT_KNOB bool g_mid_rows = true;   // 17..256-row stacks take the slab + fused-reduce path (false: A/B against the unfused launches)
+BT_KNOB int g_mid_tall = 1;       // 129..256 rows: the slab GEMMs run on 256 x 128 tiles (0: the 64 x 64 kernels, A/B; 2: from 65 rows, A/B)
+BT_KNOB int g_mid_tall_wgs = 256; // ... with about this many workgroups per launch (A/B)
 // <= 2 rows, local window: the attention computed inside the residual-stream GEMV.  Built and A/B-measured in round 4
 // (profiles/r4_ab_few_attn.jsonl, same box, interleaved): B = 1 1695 vs 1725 tok/s, B = 2 2950 vs 2921 -- a wash: the per-workgroup
 // attention arithmetic (latency chains of ~28 cross-lane ops per item, redundantly in 512 workgroups) costs what the dependent
@@ -5342,6 +5513,9 @@ static int mid_slice_len(int64_t tiles, int64_t K1, int64_t K2) {
     return best;
 }
 
+static bool mid_tall_rows(int64_t M);
+static void tall_slices(int tiles, int nk1, int nk2, int* s1, int* s2);
+
 bool mid_rows_ok(int64_t M, int64_t H, int64_t I, int head_dim, int rot) {
     // (bt_decoder_forward sends stacks of <= g_few_rows_max rows to the weight-streaming GEMV / MFMA-streamer launches first)
     return M >= 1 && M <= 256 && rot == 32 && head_dim % 32 == 0 && H % 256 == 0 && I % 256 == 0 && H <= 8192 &&
@@ -5363,7 +5537,48 @@ int64_t mid_slab_bytes(int64_t M, int64_t H, int64_t I) {
         const int ks = mid_slice_len(tm * (ceil_div(3 * H, 64) + ceil_div(I, 64)), H, 0);
         if (ks > 0) worst = std::max(worst, std::max<int64_t>(H / ks, 2) * M * (3 * H + I) * 4);   // (two slices are forced up to 224 rows)
     }
+    if (mid_tall_rows(M) && H % 128 == 0 && I % 128 == 0) {   // 256 x 128 tiles: K ranges sized to fill the chip
+        int s1 = 0, s2 = 0;
+        tall_slices((int)(H / 128), (int)(I / 64), (int)(H / 64), &s1, &s2);
+        worst = std::max(worst, (int64_t)(s1 + s2) * M * H * 4);
+        tall_slices((int)((3 * H + I) / 128), (int)(H / 64), 0, &s1, &s2);
+        worst = std::max(worst, (int64_t)s1 * M * (3 * H + I) * 4);
+    }
     return worst;
+}
+
+// ---- 129 .. 256 rows: 256 x 128 tiles, K ranges per workgroup (gemm_bf16_mfma256x128_slab_kernel) ----
+static bool mid_tall_rows(int64_t M) { return g_mid_tall != 0 && M <= 256 && M > (g_mid_tall == 2 ? 64 : 128); }
+
+// slices of the (up to two) operand pairs of one problem: about g_mid_tall_wgs workgroups in all, >= 4 K-tiles per slice, the second
+// pair's share in proportion to its K
+static void tall_slices(int tiles, int nk1, int nk2, int* s1, int* s2) {
+    const int total = std::max(1, g_mid_tall_wgs / std::max(tiles, 1));
+    if (nk2 <= 0) {
+        *s1 = std::max(1, std::min(total, nk1 / 4));
+        *s2 = 0;
+        return;
+    }
+    int a = (int)((int64_t)total * nk1 / (nk1 + nk2));
+    a = std::max(1, std::min(a, std::max(1, nk1 / 4)));
+    int b = std::max(1, std::min(total - a, std::max(1, nk2 / 4)));
+    *s1 = a;
+    *s2 = b;
+}
+
+static bool tall_operand_ok(const void* x, int64_t ld, int64_t K) {
+    return x && aligned16(x) && ld % 8 == 0 && K % 64 == 0 && K >= 256 && ld * 2 * 256 < ((int64_t)1 << 31);
+}
+
+static int tall_launch(hipStream_t s, int64_t M, const TallSide& g0, const TallSide* g1) {
+    TallArgs ta{};
+    ta.g[0] = g0;
+    ta.g[1] = g1 ? *g1 : g0;
+    const int wg0 = (g0.N / 128) * (g0.s1 + g0.s2);
+    const int wg1 = g1 ? (g1->N / 128) * (g1->s1 + g1->s2) : 0;
+    hipLaunchKernelGGL(gemm_bf16_mfma256x128_slab_kernel, dim3(wg0 + wg1), dim3(512), 0, s, ta, (int)M, wg0);
+    BT_LAUNCH_CHECK("mid-batch 256 x 128 slab GEMM launch");
+    return BT_OK;
 }
 
 static bool mid_fuse_now(int64_t M, int64_t N, int64_t K) {
@@ -5465,19 +5680,24 @@ int mid_qkv_gelu(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, c
     if (attn_done) *attn_done = false;
     if (!g_mid_dual || g_mid_fuse == 2 || N1 % 64 != 0 || N2 % 64 != 0) return BT_OK;
     const int tiles_m = (int)ceil_div(M, 64), t1 = (int)(N1 / 64), t2 = (int)(N2 / 64);
-    const int ks = mid_slice_len((int64_t)tiles_m * (t1 + t2), K, 0);
+    // 129 .. 256 rows: both problems on 256 x 128 tiles, two K ranges each (112 column tiles x 2 = 224 workgroups for the 1.2B layer)
+    const bool tall = mid_tall_rows(M) && N1 % 128 == 0 && N2 % 128 == 0 && tall_operand_ok(x1, H, K) && tall_operand_ok(x2, H, K) &&
+                      tall_operand_ok(qkv_w, K, K) && tall_operand_ok(h4_w, K, K);
+    int tall_s = 0, unused = 0;
+    if (tall) tall_slices((int)((N1 + N2) / 128), (int)(K / 64), 0, &tall_s, &unused);
+    const int ks = tall ? (int)K : mid_slice_len((int64_t)tiles_m * (t1 + t2), K, 0);
     if (ks <= 0) return BT_OK;
-    int slices = (int)(K / ks);
+    int slices = tall ? tall_s : (int)(K / ks);
     int ks_use = ks;
     // one K slice already fills the chip (M >~ 100).  A shared launch with both FUSED epilogues only lengthens the critical path there
     // (measured: B = 128 62.2k -> 59.3k, B = 256 78.7k -> 72.3k tok/s, profiles/r4_bench_dual_fused_mode_b*.json), but the 4-launch
     // structure itself still pays up to ~200 rows when the shared launch is cut into TWO K slices (slabs + the merged reduce with the
     // attention folded in): B = 96 +6.8 %, 128 +5.7 %, 192 +3.1 %, 256 -0.2 % (profiles/r4_ab_mid_force2.jsonl) -> forced up to 224 rows
-    if (slices < 2 && g_mid_force2 && M <= 224 && K % 128 == 0) {
+    if (!tall && slices < 2 && g_mid_force2 && M <= 224 && K % 128 == 0) {
         slices = 2;
         ks_use = (int)(K / 2);
     }
-    if (slices < 2 || g_mid_fuse == 0) return BT_OK;
+    if ((slices < 2 && !tall) || g_mid_fuse == 0) return BT_OK;
     if ((int64_t)slices * M * (N1 + N2) * 4 > slab_bytes) return BT_OK;
     EpiArgs e1{};
     e1.bias = (const bf16*)qkv_b;
@@ -5511,7 +5731,15 @@ int mid_qkv_gelu(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, c
     da.g[1] = GemmSide{(const bf16*)x2, (const bf16*)h4_w, H, K, p2, counters ? counters + tiles_m * t1 : nullptr};
     da.ep[0] = e1;
     da.ep[1] = e2;
-    {
+    if (tall) {
+        ProfScope ps(BT_PROF_LINEAR_MFMA, s);
+        TallSide g0{}, g1{};
+        g0.A = (const bf16*)x1; g0.W = (const bf16*)qkv_w; g0.lda = H; g0.ldw = K; g0.partial = p1; g0.N = (int)N1;
+        g0.nk1 = (int)(K / 64); g0.s1 = slices;
+        g1.A = (const bf16*)x2; g1.W = (const bf16*)h4_w; g1.lda = H; g1.ldw = K; g1.partial = p2; g1.N = (int)N2;
+        g1.nk1 = (int)(K / 64); g1.s1 = slices;
+        BT_TRY(tall_launch(s, M, g0, &g1));
+    } else {
         ProfScope ps(BT_PROF_LINEAR_MFMA, s);
         // slab mode: plain stores of the fp32 partial tiles (the epilogue arguments only carry M and N)
         hipLaunchKernelGGL(gemm_bf16_mfma_dual_kernel, dim3(tiles_m * (t1 + t2), slices), dim3(256), 0, s, da, ks_use, tiles_m, t1, t2);
@@ -5568,7 +5796,21 @@ int mid_res_ln(hipStream_t s, int64_t M, int64_t N, int64_t K1, const void* x1, 
                const void* ln1_b, void* ln1_out, const void* ln2_w, const void* ln2_b, void* ln2_out, int64_t ld_ln, float eps,
                void* slabs, int64_t slab_bytes) {
     int slices = 0;
-    BT_TRY(mid_gemm(s, M, N, x1, ldx1, w1, K1, x2, ldx2, w2, K2, slabs, slab_bytes, &slices));
+    int ts1 = 0, ts2 = 0;
+    const bool tall = mid_tall_rows(M) && N % 128 == 0 && tall_operand_ok(x1, ldx1, K1) && tall_operand_ok(w1, K1, K1) &&
+                      (K2 == 0 || (tall_operand_ok(x2, ldx2, K2) && tall_operand_ok(w2, K2, K2)));
+    if (tall) tall_slices((int)(N / 128), (int)(K1 / 64), (int)(K2 / 64), &ts1, &ts2);
+    if (tall && (int64_t)(ts1 + ts2) * M * N * 4 <= slab_bytes) {
+        ProfScope ps(BT_PROF_LINEAR_MFMA, s);
+        TallSide g0{};
+        g0.A = (const bf16*)x1; g0.W = (const bf16*)w1; g0.lda = ldx1; g0.ldw = K1; g0.nk1 = (int)(K1 / 64); g0.s1 = ts1;
+        g0.A2 = (const bf16*)x2; g0.W2 = (const bf16*)w2; g0.lda2 = ldx2; g0.ldw2 = K2; g0.nk2 = (int)(K2 / 64); g0.s2 = ts2;
+        g0.partial = (float*)slabs; g0.N = (int)N;
+        BT_TRY(tall_launch(s, M, g0, nullptr));
+        slices = ts1 + ts2;
+    } else {
+        BT_TRY(mid_gemm(s, M, N, x1, ldx1, w1, K1, x2, ldx2, w2, K2, slabs, slab_bytes, &slices));
+    }
     EpiArgs ep{};
     ep.bias = (const bf16*)b1;
     ep.res = (const bf16*)x;
@@ -5604,6 +5846,8 @@ extern "C" void bt_debug_gemm_max_wg(int n) { g_max_wg = n; }
 extern "C" void bt_debug_skinny_rows(int n) { g_skinny_rows = n; }
 extern "C" void bt_debug_small_stages(int n) { g_small_stages = n; }
 extern "C" void bt_debug_mid_rows(int on) { g_mid_rows = on != 0; }
+extern "C" void bt_debug_mid_tall(int mode) { g_mid_tall = mode; }
+extern "C" void bt_debug_mid_tall_wgs(int wgs) { g_mid_tall_wgs = wgs > 0 ? wgs : 256; }
 extern "C" void bt_debug_few_dual(int on) { g_few_dual = on != 0; }
 extern "C" void bt_debug_few_persist(int on) { g_few_persist = on != 0; }
 extern "C" void bt_debug_few_attn(int on) { g_few_attn = on != 0; }

@@ -70,6 +70,18 @@ def test_no_valu_written_sgpr_base_within_five_wait_states(gemm_asm):
     assert seen >= 8, seen                               # four stream-K + five persistent instantiations in the product build
 
 
+def test_one_tile_and_slab_kernels_have_no_valu_written_sgpr_base(gemm_asm):
+    """The 256 x 128 kernels (one tile per workgroup; K ranges into slabs for the mid-batch stacks) issue their LDS-DMA from an SGPR base
+    computed from v_readfirstlane(wave): the base must have gone through the scalar ALU (or 5 wait states) before the first DMA."""
+    seen = 0
+    for name, body in _kernels(gemm_asm, r"_ZN2bt\d+gemm_bf16_mfma256x128_(slab_)?kernel"):
+        total, hazards = _scan(body)
+        assert total >= 16, (name, total)
+        assert not hazards, (name, hazards[:3])
+        seen += 1
+    assert seen >= 3, seen
+
+
 def test_the_scan_catches_the_original_bug(gemm_asm):
     """The flag helpers without their leading s_nop 4 are what faulted: strip the nops from the stream-K kernels' text and the scan
     must report the v_readlane -> global_* sc1 pairs."""

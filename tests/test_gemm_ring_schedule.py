@@ -591,3 +591,27 @@ def test_one_tile_256x128_schedule(nk):
 def test_one_tile_256x128_model_detects_a_missing_drain():
     with pytest.raises(AssertionError, match="RAW"):
         t21_model(8, bad="always_steady")
+
+
+def _t21_loop_text(kernel_name):
+    """The K-loop of a 256 x 128 kernel as written in gemm.hip, comments and whitespace removed."""
+    body = SRC[SRC.index("void " + kernel_name + "("):]
+    body = body[body.index("for (int t = 0; t < nk; ++t) {"):]
+    body = body[:body.index("if (!grp1) cbarrier();")]
+    body = re.sub(r"//[^\n]*", "", body)
+    return re.sub(r"\s+", "", body)
+
+
+def test_slab_kernel_runs_the_one_tile_kernels_k_loop():
+    """gemm_bf16_mfma256x128_slab_kernel (mid-batch stacks, K ranges into fp32 slabs) claims the one-tile kernel's load stream, waits
+    and barriers, which t21_model above checks: its K-loop must be the same text once the template switches of the one-tile kernel are
+    resolved (SAFE = PRIO = true) and the cursor advance is spelled out."""
+    one = _t21_loop_text("gemm_bf16_mfma256x128_kernel")
+    one = one.replace("if(SAFE&&grp1)", "if(grp1)").replace("if(PRIO)", "")
+    one = one.replace("++lt;voff_a+=128;voff_w+=128;", "advance();")
+    assert one == _t21_loop_text("gemm_bf16_mfma256x128_slab_kernel")
+    # ... and the prologue issues the same five half-tiles in the same order
+    slab = SRC[SRC.index("void gemm_bf16_mfma256x128_slab_kernel("):]
+    pro = re.sub(r"\s+", "", slab[slab.index("issue_a(I0{});"):slab.index("f32x4_t acc[8][2];")])
+    assert pro == "issue_a(I0{});issue_w();issue_a(I1{});advance();if(nk>1){issue_a(I0{});issue_w();}"
+

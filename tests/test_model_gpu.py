@@ -1641,7 +1641,7 @@ def test_decoder_forward_rejects_cache_overflow_before_any_launch(B, q_len):
     assert rc == 0, lib().bt_last_error()
 
 
-@pytest.mark.parametrize("M", [3, 4, 6, 8, 16, 17, 32, 64, 128, 256])
+@pytest.mark.parametrize("M", [3, 4, 6, 8, 16, 17, 32, 64, 128, 129, 200, 255, 256])
 def test_mid_rows_decoder_stack_vs_fp32_oracle(M, dbg_lib):
     """3 .. 256 rows through bt_decoder_forward (round 4: the slab path starts at 3 rows): the split-K slab GEMMs + fused reduces (bias + RoPE + KV append; bias +
     GELU; both residual projections + residual + next-layer LayerNorm pair).  A decode step (q = 1 against a 40-row cache
@@ -1685,6 +1685,68 @@ def test_mid_rows_decoder_stack_vs_fp32_oracle(M, dbg_lib):
         got = model.block_decoder(inputs_embeds=x2.to(DEV), block_attention_mask=m2.to(DEV)).hidden_states.float().cpu()
         want, _ = o.block_decoder(x2.float(), m2)
         assert (got - want).abs().max().item() <= 3e-2 * want.abs().max().item() + 1e-2
+
+
+@pytest.mark.parametrize("M,mode", [(129, 1), (136, 1), (192, 1), (250, 1), (256, 1), (65, 2), (96, 2), (128, 2)])
+def test_mid_rows_tall_tiles_match_the_64x64_slab_kernels(M, mode, dbg_lib):
+    """129 .. 256 rows (round 5): the slab GEMMs of a layer run on 256 x 128 tiles with a K RANGE per workgroup
+    (gemm_bf16_mfma256x128_slab_kernel: rows >= M clamped in the DMA addresses, unequal slices, two problems per launch, two operand
+    pairs for the residual projections) instead of 64 x 64 tiles.  Same slab format, same reduce launches, another partition of K:
+    hidden states and appended K/V rows of a decode step (q = 1 over a 40-row cache) and of a q = 2 call against the 64 x 64 kernels
+    (bt_debug_mid_tall(0)) within fp32-summation-order noise after bf16 rounding, NaN-poisoned slab scratch (a row or column the
+    kernel failed to write would surface), and two other workgroup budgets (more / fewer slices).  mode 2 = the A/B setting that
+    takes 65 .. 128 rows too (half of the tile clamped)."""
+    from block_transformer_amd.runtime import _shared_ws
+    model, dims, o = _mid_stack(layers=3)
+    H = dims.bd.hidden
+    g = torch.Generator().manual_seed(1000 + M)
+    past_len = 40
+    xp = (torch.randn(M, past_len, H, generator=g) * 0.5).bfloat16()
+    xs = (torch.randn(M, 1, H, generator=g) * 0.5).bfloat16()
+    ones = torch.ones(M, past_len + 1, dtype=torch.long)
+    q2 = M % 2 == 0
+    x2 = (torch.randn(M // 2, 2, H, generator=g) * 0.5).bfloat16()
+    m2 = torch.ones(M // 2, 2, dtype=torch.long)
+
+    def run():
+        pre = model.block_decoder(inputs_embeds=xp.to(DEV), block_attention_mask=ones[:, :past_len].to(DEV))
+        if _shared_ws._buf is not None:                         # fp32 NaN pattern over the whole workspace incl. the slab region
+            _shared_ws._buf[:_shared_ws._buf.numel() // 4 * 4].view(torch.int32).fill_(0x7FC00000)
+        step = model.block_decoder(inputs_embeds=xs.to(DEV), block_attention_mask=ones.to(DEV),
+                                   past_key_values=pre.past_key_values)
+        k, v = step.past_key_values[2]
+        two = model.block_decoder(inputs_embeds=x2.to(DEV), block_attention_mask=m2.to(DEV)).hidden_states.float().cpu() if q2 else None
+        return step.hidden_states[:, 0].float().cpu(), k[:, :, past_len].float().cpu(), v[:, :, past_len].float().cpu(), two
+
+    outs = {}
+    try:
+        for key, (tall, wgs) in {"small": (0, 256), "tall": (mode, 256), "tall512": (mode, 512), "tall96": (mode, 96)}.items():
+            dbg_lib.bt_debug_mid_tall(tall)
+            dbg_lib.bt_debug_mid_tall_wgs(wgs)
+            outs[key] = run()
+    finally:
+        dbg_lib.bt_debug_mid_tall(1)
+        dbg_lib.bt_debug_mid_tall_wgs(256)
+    ref_pre, past = o.block_decoder(xp.float(), ones[:, :past_len])
+    ref, kv = o.block_decoder(xs.float(), ones, past)
+    ref = ref[:, 0]
+    scale = ref.abs().max().item()
+    base = outs["small"]
+    for key in ("tall", "tall512", "tall96"):
+        got = outs[key]
+        assert torch.isfinite(got[0]).all() and torch.isfinite(got[1]).all() and torch.isfinite(got[2]).all(), key
+        assert (got[0] - ref).abs().max().item() <= 3e-2 * scale + 1e-2, (key, (got[0] - ref).abs().max().item())
+        # against the 64 x 64 kernels: three layers of bf16 activations whose fp32 pre-rounding sums differ in the last bits
+        assert (got[0] - base[0]).abs().max().item() <= 1.5e-2 * scale, (key, (got[0] - base[0]).abs().max().item())
+        assert (got[0] - base[0]).abs().mean().item() <= 1e-3 * scale, (key, (got[0] - base[0]).abs().mean().item())
+        for i in (1, 2):
+            assert (got[i] - base[i]).abs().max().item() <= 1.5e-2 * base[i].abs().max().item(), (key, i)
+        if q2:
+            assert torch.isfinite(got[3]).all()
+            assert (got[3] - base[3]).abs().max().item() <= 1.5e-2 * base[3].abs().max().item(), key
+    if q2:
+        want, _ = o.block_decoder(x2.float(), m2)
+        assert (outs["tall"][3] - want).abs().max().item() <= 3e-2 * want.abs().max().item() + 1e-2
 
 
 @pytest.mark.parametrize("B", [24, 64, 200])
