@@ -3290,16 +3290,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_kernel(const bf16* 
 }
 
 // ---- 256 x 128 tiles cut along K into fp32 slabs: the mid-batch projections at 129 .. 256 rows (round 5) ----------------------------
-// At 129 .. 256 rows the 64 x 64 slab kernel above moves 16 KiB of operands from L2 per 0.5 MFLOP (32 flop per L2 -> LDS byte): its QKV
-// and h -> 4h launches sit on the L2 roof (22 us each at 256 rows = 0.29 PF, profiles/r4_bench_b256_kernel_stats.md), not on HBM.  This
-// kernel is the one-tile 256 x 128 kernel's K-loop (85 flop per byte, two staggered wave groups, half-tiles issued five ahead) with
-//   * the whole stack as ONE row tile: rows >= M are clamped in the LDS-DMA addresses (their products are never stored);
-//   * a K range per workgroup instead of the whole K: workgroup = (column tile, slice), slice s of a pair with nk K-tiles and S slices
-//     takes K-tiles [s nk / S, (s + 1) nk / S) -- slices need not be equal, which lets 16 column tiles x 16 slices cover the residual
-//     projections' 32 + 128 K-tiles with 256 workgroups; slices >= s1 belong to the optional second operand pair;
-//   * up to two problems per launch (the QKV projection and the MLP up-projection of a parallel-residual layer), each with its own
-//     operands, N and slab region;
+// At 129 .. 256 rows the 64 x 64 slab kernel above moves 16 KiB of operands from L2 per 0.5 MFLOP (32 flop per L2 -> LDS byte) and keeps
+// 48 KiB of weights in flight per CU: its QKV and h -> 4h launches take 22 us each at 256 rows (0.29 PF, 1.1-1.5 TB/s of weights;
+// profiles/r4_bench_b256_kernel_stats.md).  This kernel is the one-tile 256 x 128 kernel's tile and wave layout (8 waves = two groups half a
+// K-tile apart, a wave owns 64 rows of each A half x 32 columns, phase 0 = A0 + W, phase 1 = A1) with what this regime needs:
+//   * the whole stack is ONE row tile: rows >= M are clamped in the LDS-DMA addresses (their products are never stored);
+//   * a K range per workgroup: workgroup = (column tile, slice); slice s of a pair with nk K-tiles and S slices takes K-tiles
+//     [s nk / S, (s + 1) nk / S) -- slices need not be equal, so 16 column tiles x 16 slices cover the residual projections' 128 + 32
+//     K-tiles with 256 workgroups; slices >= s1 belong to the optional second operand pair;
+//   * up to two problems per launch (the QKV projection and the MLP up-projection of a parallel-residual layer);
+//   * the two operand streams are issued by DIFFERENT waves: group 0 streams A (activations: L2 hits, two K-tiles deep), group 1 streams
+//     W (weights: HBM, every byte used by one workgroup only) TS_WD K-tiles deep with the nt policy.  vmcnt retires in order per wave,
+//     so a wave that issued both could not wait for the next A tile without draining the deep W stream: with the first version's shared
+//     stream (the one-tile kernel's, five half-tiles ahead = 27 KiB of weights in flight per CU) the launches ran at 2.4-3 TB/s of
+//     weights (profiles/r5_bench_b256_kernel_stats_v1_shallow_w_ring.md); the guide's figure for an HBM-rate LDS-DMA stream is an
+//     8 x 16 KiB ring per CU;
 //   * the epilogue = plain 16-byte stores of the fp32 fragments into slab[slice][M][N] -- the format the mid-batch reduce kernels read.
+// Synchronisation (t = K-tile, barriers counted per group; group 1 runs one barrier behind group 0, as in the one-tile kernel):
+//   RAW  a wave waits for its own DMAs of a tile before a barrier that precedes every read of it: A0(t) / A1(t) by group 0 before the
+//        barrier that opens its phase 0 / 1 of t; W(t) by group 1 before the barrier that closes its phase 1 of t - 1 (= the one group 0
+//        opens phase 0 of t with);
+//   WAR  A0(t + 2) is issued in group 0's phase 1 of t and A1(t + 1) in its phase 0 of t, W(t + TS_WD) in group 1's phase 1 of t: every
+//        read of the slot's previous tenant was issued (group 1: completed, lgkmcnt(0)) at least one barrier earlier.
+//   tests/test_gemm_ring_schedule.py (slab_model) replays both groups' streams for every K-tile count.
 // Requires N % 128 == 0, K % 64 == 0, >= 4 K-tiles per slice (checked by the host).
 struct TallSide {
     const bf16* A;
@@ -3313,13 +3326,35 @@ struct TallSide {
 struct TallArgs {
     TallSide g[2];
 };
+constexpr int TS_WD = 5;                                    // depth of the W ring (K-tiles)
+constexpr int TS_A_STAGE = 2 * HALF_BYTES;                  // [A rows 0-127 | A rows 128-255] of one K-tile
+constexpr int TS_SMEM = 2 * TS_A_STAGE + TS_WD * HALF_BYTES;   // 64 + 80 = 144 KiB
+
+template <int OFF>
+__device__ inline void glds16_sbase_off_nt(const char* base_uniform, uint32_t voff, uint32_t lds_base_uniform) {
+    asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 nt"
+                 :
+                 : "v"(voff), "s"(base_uniform), "s"(lds_base_uniform), "n"(OFF)
+                 : "memory", "scc");
+}
+
+// s_waitcnt vmcnt(4 * tiles): a W tile (or an A half-tile) is four DMA instructions of the issuing wave
+__device__ inline void ts_wait_tiles(int tiles) {
+    if (tiles >= 4) wait_vmcnt_n<16>();
+    else if (tiles == 3) wait_vmcnt_n<12>();
+    else if (tiles == 2) wait_vmcnt_n<8>();
+    else if (tiles == 1) wait_vmcnt_n<4>();
+    else wait_vmcnt_n<0>();
+}
 
 __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const TallArgs a, int M, int wg_side1) {
-    __shared__ __attribute__((aligned(16))) char smem[T21_SMEM];
+    static_assert(TS_WD >= 2 && TS_WD <= 5, "ts_wait_tiles covers up to four W tiles in flight behind the awaited one");
+    __shared__ __attribute__((aligned(16))) char smem[TS_SMEM];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
     const bool grp1 = wave >= 4;
+    const int wq = wave & 3;                 // this wave's quarter of the tile its group streams
     // side, column tile and slice: workgroup-uniform index into the kernel-argument array (scalar loads at a computed offset)
     const int side = (int)blockIdx.x >= wg_side1 ? 1 : 0;
     const TallSide& g = a.g[side];
@@ -3328,7 +3363,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
     const int slice = id % S, tn = id / S;   // consecutive ids (= XCDs) take different slices: an XCD's L2 holds S / 8 of the A columns
     const bool second = slice >= g.s1;
     const int sidx = second ? slice - g.s1 : slice, scnt = second ? g.s2 : g.s1, nk_all = second ? g.nk2 : g.nk1;
-    const int kb = (int)((int64_t)sidx * nk_all / scnt), ke = (int)((int64_t)(sidx + 1) * nk_all / scnt);
+    const int kb = sidx * nk_all / scnt, ke = (sidx + 1) * nk_all / scnt;   // (slices x K-tiles << 2^31)
     const int nk = ke - kb;
     const bf16* A = second ? g.A2 : g.A;
     const bf16* W = second ? g.W2 : g.W;
@@ -3336,45 +3371,47 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
     const int N = g.N, n0 = tn * 128;
 
     const uint32_t lane_slot = (uint32_t)(((lane & 7) ^ ((lane >> 3) & 7)) * 16);
-    // A rows of this lane's four DMA instructions per K-tile (half 0 / 1, rows +0 / +8), clamped to the stack
-    const int r0 = wave * 16 + (lane >> 3);
-    uint32_t va00 = (uint32_t)min(r0, M - 1) * (uint32_t)(lda * 2) + lane_slot;
-    uint32_t va01 = (uint32_t)min(r0 + 8, M - 1) * (uint32_t)(lda * 2) + lane_slot;
-    uint32_t va10 = (uint32_t)min(r0 + 128, M - 1) * (uint32_t)(lda * 2) + lane_slot;
-    uint32_t va11 = (uint32_t)min(r0 + 136, M - 1) * (uint32_t)(lda * 2) + lane_slot;
-    uint32_t voff_w = (uint32_t)(lane >> 3) * (uint32_t)(ldw * 2) + lane_slot;
+    // group 0: rows h * 128 + wq * 32 + j * 8 + (lane >> 3) of A, clamped to the stack; group 1: rows n0 + wq * 32 + j * 8 + (lane >> 3) of W
+    uint32_t va[2][4];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            va[h][j] = (uint32_t)min(h * 128 + wq * 32 + j * 8 + (lane >> 3), M - 1) * (uint32_t)(lda * 2) + lane_slot;
+    const uint32_t vw = (uint32_t)(lane >> 3) * (uint32_t)(ldw * 2) + lane_slot;
     const uint32_t row8_w = (uint32_t)(8 * ldw * 2);
     const char* pa = reinterpret_cast<const char*>(A) + (int64_t)kb * (BK * 2);
-    const char* pw = reinterpret_cast<const char*>(W) + ((int64_t)(n0 + wave * 16) * ldw + (int64_t)kb * BK) * 2;
-    const uint32_t ring_lds = lds_addr(smem) + (uint32_t)wave * 2048u;
-    int lt = 0;
-    auto issue_a = [&](auto hc) {
+    const char* pw = reinterpret_cast<const char*>(W) + ((int64_t)(n0 + wq * 32) * ldw + (int64_t)kb * BK) * 2;
+    const uint32_t a_lds = lds_addr(smem) + (uint32_t)wq * 4096u;
+    const uint32_t w_lds = lds_addr(smem) + (uint32_t)(2 * TS_A_STAGE) + (uint32_t)wq * 4096u;
+    auto issue_a = [&](auto hc, int kt) {    // group 0: half-tile `half` of K-tile kt -> A ring stage kt & 1
         constexpr int half = decltype(hc)::value;
-        const uint32_t ring = ring_lds + (uint32_t)(lt & 1) * (uint32_t)T21_STAGE;
-        glds16_sbase_off<half * HALF_BYTES>(pa, half ? va10 : va00, ring);
-        glds16_sbase_off<half * HALF_BYTES + 1024>(pa, half ? va11 : va01, ring);
+        const uint32_t ring = a_lds + (uint32_t)(kt & 1) * (uint32_t)TS_A_STAGE;
+        const uint32_t koff = (uint32_t)kt * 128u;
+        glds16_sbase_off<half * HALF_BYTES>(pa, va[half][0] + koff, ring);
+        glds16_sbase_off<half * HALF_BYTES + 1024>(pa, va[half][1] + koff, ring);
+        glds16_sbase_off<half * HALF_BYTES + 2048>(pa, va[half][2] + koff, ring);
+        glds16_sbase_off<half * HALF_BYTES + 3072>(pa, va[half][3] + koff, ring);
     };
-    auto issue_w = [&]() {
-        const uint32_t ring = ring_lds + (uint32_t)(lt & 1) * (uint32_t)T21_STAGE;
-        glds16_sbase_off<2 * HALF_BYTES>(pw, voff_w, ring);
-        glds16_sbase_off<2 * HALF_BYTES + 1024>(pw, voff_w + row8_w, ring);
-    };
-    auto advance = [&]() {
-        ++lt;
-        va00 += 128; va01 += 128; va10 += 128; va11 += 128;
-        voff_w += 128;
+    int w_slot = 0;                          // group 1: ring slot of the next W tile to issue (= its K-tile mod TS_WD)
+    auto issue_w = [&](int kt) {
+        const uint32_t ring = w_lds + (uint32_t)w_slot * (uint32_t)HALF_BYTES;
+        const uint32_t v0 = vw + (uint32_t)kt * 128u;
+        glds16_sbase_off_nt<0>(pw, v0, ring);
+        glds16_sbase_off_nt<1024>(pw, v0 + row8_w, ring);
+        glds16_sbase_off_nt<2048>(pw, v0 + 2 * row8_w, ring);
+        glds16_sbase_off_nt<3072>(pw, v0 + 3 * row8_w, ring);
+        w_slot = w_slot + 1 == TS_WD ? 0 : w_slot + 1;
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    // the load stream, waits and barriers below are the one-tile kernel's (tests/test_gemm_ring_schedule.py checks that the two K-loops
-    // are the same text modulo the operand addressing): prologue = K-tile 0 (A0, W, A1) and A0, W of K-tile 1
-    issue_a(I0{});
-    issue_w();
-    issue_a(I1{});
-    advance();
-    if (nk > 1) {
-        issue_a(I0{});
-        issue_w();
+    // prologue: group 0 -> A0(0), A1(0), A0(1); group 1 -> W(0 .. TS_WD - 1)
+    if (!grp1) {
+        issue_a(I0{}, 0);
+        issue_a(I1{}, 0);
+        if (nk > 1) issue_a(I0{}, 1);
+    } else {
+        for (int kt = 0; kt < TS_WD && kt < nk; ++kt) issue_w(kt);
     }
 
     f32x4_t acc[8][2];   // [A half * 4 + m-fragment][n-fragment]
@@ -3384,30 +3421,27 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
     bf16x8_t af[4][2], wf[2][2];
 
-    auto wait = [&](bool steady) {
-        if (steady) wait_vmcnt<T21_WAIT>();
-        else wait_vmcnt<0>();
-    };
     if (grp1) {
-        wait(nk >= 3);
+        ts_wait_tiles(min(TS_WD, nk) - 1);   // W(0) has landed
         cbarrier();
     }
+    int r_slot = 0;                          // ring slot of W(t)
     for (int t = 0; t < nk; ++t) {
-        const bool steady = t + 3 <= nk;
-        const char* buf = smem + (t & 1) * T21_STAGE;
+        const char* abuf = smem + (t & 1) * TS_A_STAGE;
+        const char* wbuf = smem + 2 * TS_A_STAGE + r_slot * HALF_BYTES;
+        r_slot = r_slot + 1 == TS_WD ? 0 : r_slot + 1;
         // ---- phase 0: A0, W ----
-        if (!grp1) wait(steady);
+        if (!grp1) ts_wait_tiles(t + 1 < nk ? 2 : 1);        // A0(t) landed; A1(t) and A0(t + 1) may be in flight
         cbarrier();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) wf[nb][ks] = read_frag(buf + 2 * HALF_BYTES, wn * 32 + nb * 16, ks, lane);
+            for (int nb = 0; nb < 2; ++nb) wf[nb][ks] = read_frag(wbuf, wn * 32 + nb * 16, ks, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i][ks] = read_frag(buf, wm * 64 + i * 16, ks, lane);
+            for (int i = 0; i < 4; ++i) af[i][ks] = read_frag(abuf, wm * 64 + i * 16, ks, lane);
         }
-        if (t + 1 < nk) issue_a(I1{});
-        if (grp1) wait(steady);
-        if (grp1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!grp1 && t + 1 < nk) issue_a(I1{}, t + 1);
+        if (grp1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // A0 / W reads done before their slots may be refilled
         cbarrier();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
@@ -3420,19 +3454,18 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
                     acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][ks], af[i][ks], acc[i][nb], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         // ---- phase 1: A1 ----
-        if (!grp1) wait(steady);
+        if (!grp1) ts_wait_tiles(t + 1 < nk ? 2 : 0);        // A1(t) landed; A0(t + 1) and A1(t + 1) may be in flight
         cbarrier();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i][ks] = read_frag(buf + HALF_BYTES, wm * 64 + i * 16, ks, lane);
-        advance();
-        if (t + 2 < nk) {
-            issue_a(I0{});
-            issue_w();
+            for (int i = 0; i < 4; ++i) af[i][ks] = read_frag(abuf + HALF_BYTES, wm * 64 + i * 16, ks, lane);
+        if (!grp1 && t + 2 < nk) issue_a(I0{}, t + 2);
+        if (grp1) {
+            if (t + TS_WD < nk) issue_w(t + TS_WD);
+            ts_wait_tiles(min(t + TS_WD, nk - 1) - (t + 1));   // W(t + 1) landed (its wait for phase 0 of K-tile t + 1)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // A1 reads done before group 0 may refill the slot
         }
-        if (grp1) wait(t + 4 <= nk);
-        if (grp1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         cbarrier();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
@@ -5548,7 +5581,7 @@ int64_t mid_slab_bytes(int64_t M, int64_t H, int64_t I) {
 }
 
 // ---- 129 .. 256 rows: 256 x 128 tiles, K ranges per workgroup (gemm_bf16_mfma256x128_slab_kernel) ----
-static bool mid_tall_rows(int64_t M) { return g_mid_tall != 0 && M <= 256 && M > (g_mid_tall == 2 ? 64 : 128); }
+static bool mid_tall_rows(int64_t M) { return g_mid_tall != 0 && M <= 256 && M > (g_mid_tall >= 2 ? 64 : 128); }
 
 // slices of the (up to two) operand pairs of one problem: about g_mid_tall_wgs workgroups in all, >= 4 K-tiles per slice, the second
 // pair's share in proportion to its K

@@ -593,25 +593,104 @@ def test_one_tile_256x128_model_detects_a_missing_drain():
         t21_model(8, bad="always_steady")
 
 
-def _t21_loop_text(kernel_name):
-    """The K-loop of a 256 x 128 kernel as written in gemm.hip, comments and whitespace removed."""
-    body = SRC[SRC.index("void " + kernel_name + "("):]
-    body = body[body.index("for (int t = 0; t < nk; ++t) {"):]
-    body = body[:body.index("if (!grp1) cbarrier();")]
-    body = re.sub(r"//[^\n]*", "", body)
-    return re.sub(r"\s+", "", body)
+# ---- 256 x 128 slab kernel of the mid-batch stacks (gemm_bf16_mfma256x128_slab_kernel): A streamed by group 0 (two K-tiles deep), W by
+# group 1 (TS_WD K-tiles deep): each group has its own vmcnt queue ----------------------------------------------------------------
+TS_WD = int(re.search(r"constexpr int TS_WD = (\d+);", SRC).group(1))
+_SLAB = SRC[SRC.index("void gemm_bf16_mfma256x128_slab_kernel("):]
+_SLAB = re.sub(r"\s+", "", re.sub(r"//[^\n]*", "", _SLAB[:_SLAB.index("// ---- slab stores")]))
+# the lines the streams below restate (comments and whitespace removed)
+for piece in ("if(!grp1){issue_a(I0{},0);issue_a(I1{},0);if(nk>1)issue_a(I0{},1);}else{for(intkt=0;kt<TS_WD&&kt<nk;++kt)issue_w(kt);}",
+              "if(grp1){ts_wait_tiles(min(TS_WD,nk)-1);cbarrier();}",
+              "if(!grp1)ts_wait_tiles(t+1<nk?2:1);cbarrier();",
+              "if(!grp1&&t+1<nk)issue_a(I1{},t+1);if(grp1)asmvolatile(\"s_waitcntlgkmcnt(0)\":::\"memory\");cbarrier();",
+              "if(!grp1)ts_wait_tiles(t+1<nk?2:0);cbarrier();",
+              "if(!grp1&&t+2<nk)issue_a(I0{},t+2);if(grp1){if(t+TS_WD<nk)issue_w(t+TS_WD);ts_wait_tiles(min(t+TS_WD,nk-1)-(t+1));"
+              "asmvolatile(\"s_waitcntlgkmcnt(0)\":::\"memory\");}cbarrier();",
+              "if(!grp1)cbarrier();"):
+    assert piece in _SLAB, piece
+assert _SLAB.count("cbarrier();") == 6 and _SLAB.count("ts_wait_tiles(") == 4
+assert "if(tiles>=4)wait_vmcnt_n<16>();elseif(tiles==3)wait_vmcnt_n<12>();elseif(tiles==2)wait_vmcnt_n<8>();elseif(tiles==1)wait_vmcnt_n<4>();elsewait_vmcnt_n<0>();" \
+    in re.sub(r"\s+", "", SRC[SRC.index("__device__ inline void ts_wait_tiles(int tiles)"):][:400])
 
 
-def test_slab_kernel_runs_the_one_tile_kernels_k_loop():
-    """gemm_bf16_mfma256x128_slab_kernel (mid-batch stacks, K ranges into fp32 slabs) claims the one-tile kernel's load stream, waits
-    and barriers, which t21_model above checks: its K-loop must be the same text once the template switches of the one-tile kernel are
-    resolved (SAFE = PRIO = true) and the cursor advance is spelled out."""
-    one = _t21_loop_text("gemm_bf16_mfma256x128_kernel")
-    one = one.replace("if(SAFE&&grp1)", "if(grp1)").replace("if(PRIO)", "")
-    one = one.replace("++lt;voff_a+=128;voff_w+=128;", "advance();")
-    assert one == _t21_loop_text("gemm_bf16_mfma256x128_slab_kernel")
-    # ... and the prologue issues the same five half-tiles in the same order
-    slab = SRC[SRC.index("void gemm_bf16_mfma256x128_slab_kernel("):]
-    pro = re.sub(r"\s+", "", slab[slab.index("issue_a(I0{});"):slab.index("f32x4_t acc[8][2];")])
-    assert pro == "issue_a(I0{});issue_w();issue_a(I1{});advance();if(nk>1){issue_a(I0{});issue_w();}"
+def _slab_stream(grp, nk, bad=None):
+    """program order of one wave; a tile (A half-tile or W) is four DMA instructions of the issuing wave"""
+    ev = []
 
+    def dma(tag):
+        for _ in range(4):
+            ev.append(("vm", tag))
+
+    def wait_tiles(n):
+        ev.append(("wait", 4 * min(max(n, 0), 4)))
+
+    if grp == 0:
+        dma(("a0", 0))
+        dma(("a1", 0))
+        if nk > 1:
+            dma(("a0", 1))
+    else:
+        for kt in range(min(TS_WD, nk)):
+            dma(("w", kt))
+        wait_tiles(min(TS_WD, nk) - 1)
+        ev.append(("bar",))
+    for t in range(nk):
+        if grp == 0:
+            wait_tiles(2 if t + 1 < nk else 1)
+        ev.append(("bar",))
+        ev.append(("read", ("w", t)))
+        ev.append(("read", ("a0", t)))
+        if grp == 0 and t + 1 < nk:
+            dma(("a1", t + 1))
+        ev.append(("bar",))
+        if grp == 0:
+            wait_tiles((2 if t + 1 < nk else 0) + (1 if bad == "a1_late" else 0))
+        ev.append(("bar",))
+        ev.append(("read", ("a1", t)))
+        if grp == 0 and t + 2 < nk:
+            dma(("a0", t + 2))
+        if grp == 1:
+            if t + TS_WD < nk:
+                dma(("w", t + TS_WD))
+            wait_tiles(min(t + TS_WD, nk - 1) - (t + 1) + (1 if bad == "w_late" else 0))
+        ev.append(("bar",))
+    if grp == 0:
+        ev.append(("bar",))
+    return ev
+
+
+def slab_model(nk, bad=None, depth=None):
+    waves = {g: _pp_analyse(_slab_stream(g, nk, bad)) for g in (0, 1)}
+    assert len({v[3] for v in waves.values()}) == 1, "barrier counts differ between wave groups"
+    owner = {"a0": 0, "a1": 0, "w": 1}
+    ring = {"a0": 2, "a1": 2, "w": depth or TS_WD}
+    last_read = {}
+    for key, (issue, done, reads, _) in waves.items():
+        for tag, b in reads:
+            last_read[tag] = max(last_read.get(tag, -1), b)
+            odone = waves[owner[tag[0]]][1]
+            assert tag in odone and odone[tag] <= b - 1, f"RAW nk={nk}: {tag} read by group {key} before its issuer waited"
+    for key, (issue, done, reads, _) in waves.items():
+        for tag, b in list(issue.items()):
+            if tag[0] in ring and tag[1] >= ring[tag[0]]:
+                prev = (tag[0], tag[1] - ring[tag[0]])
+                assert b >= last_read[prev] + 1, f"WAR nk={nk}: {tag} issued by group {key} too early"
+    # every tile is issued exactly once, by its owner, and read by both groups
+    for kind in ring:
+        assert sorted(t[1] for t in waves[owner[kind]][0] if t[0] == kind) == list(range(nk))
+        for g in (0, 1):
+            assert sorted(t[1] for t, _ in waves[g][2] if t[0] == kind) == list(range(nk))
+
+
+@pytest.mark.parametrize("nk", [1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 16, 32])
+def test_slab_kernel_schedule(nk):
+    slab_model(nk)
+
+
+def test_slab_kernel_model_detects_errors():
+    with pytest.raises(AssertionError, match="RAW"):
+        slab_model(8, bad="w_late")              # one more W tile left in flight than was issued behind the awaited one
+    with pytest.raises(AssertionError, match="RAW"):
+        slab_model(8, bad="a1_late")
+    with pytest.raises(AssertionError, match="WAR"):
+        slab_model(12, depth=TS_WD - 1)          # a ring one slot shorter than the issue distance

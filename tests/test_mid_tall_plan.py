@@ -19,7 +19,7 @@ for line in ("const int total = std::max(1, g_mid_tall_wgs / std::max(tiles, 1))
              "int a = (int)((int64_t)total * nk1 / (nk1 + nk2));",
              "a = std::max(1, std::min(a, std::max(1, nk1 / 4)));",
              "int b = std::max(1, std::min(total - a, std::max(1, nk2 / 4)));",
-             "const int kb = (int)((int64_t)sidx * nk_all / scnt), ke = (int)((int64_t)(sidx + 1) * nk_all / scnt);",
+             "const int kb = sidx * nk_all / scnt, ke = (sidx + 1) * nk_all / scnt;",
              "const int slice = id % S, tn = id / S;",
              "const bool second = slice >= g.s1;"):
     assert line in SRC, line
