@@ -26,6 +26,16 @@ namespace bt {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+// raw (untyped, unbounded) buffer descriptor whose base is a wave-uniform pointer: offsets are 32-bit, so the base is the
+// origin of the tile being written, not of the tensor
+__device__ inline __amdgpu_buffer_rsrc_t tile_rsrc(const char* base_uniform) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base_uniform);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
+}
 
 __device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
@@ -100,6 +110,7 @@ struct EpiArgs {
     QkvEpi q;
     uint2* amax;      // PP_ARGMAX: per (row, 64-column slab) {bits of the largest bf16-rounded value, its column}; [M][amax_ld]
     int amax_ld;
+    int slab_wt;      // split-K slab kernels: fp32 partial tiles stored write-through (sc1) instead of left dirty in L2 for the end-of-kernel release
     // LayerNorm folded into the GEMM (round 5; persistent kernel, EABL bit 32): the GEMM runs on the RAW rows x with the weight
     // W' = W diag(gamma), and the epilogue turns  acc = W' x  into  W (gamma (x - mu) rstd + beta) + b  =  rstd (acc - mu s) + c
     // with  s[n] = sum_k W'[n, k]  and  c[n] = (W beta)[n] + b[n]:
@@ -423,7 +434,7 @@ template <int TBM, int TBN, bool SPLITK, int NS, bool FUSE>
 __device__ __forceinline__ void gemm_mfma_body(char* smem, const int tm, const int tn, const bf16* __restrict__ A, int64_t lda,
                                                const bf16* __restrict__ W, int64_t ldw, const EpiArgs& ep, int K, int tiles_n,
                                                float* __restrict__ partial, const Seg2& s2, int slices1,
-                                               int* __restrict__ counters) {
+                                               int* __restrict__ counters, const bool wt) {
     const int M = ep.M, N = ep.N;
     constexpr int A_BYTES = TBM * BK * 2, W_BYTES = TBN * BK * 2, STAGE = A_BYTES + W_BYTES;
     constexpr int FM = TBM / 32, FN = TBN / 32;  // 16x16 fragments per wave along m / n
@@ -519,6 +530,8 @@ __device__ __forceinline__ void gemm_mfma_body(char* smem, const int tm, const i
 
     if (SPLITK && !(FUSE && gridDim.y == 1)) {  // fp32 partials: lane owns 4 consecutive columns of one row -> one 16-byte store per fragment
         float* slab = partial + (int64_t)blockIdx.y * M * N;
+        // (descriptor-addressed: slab origin of this slice in SGPRs, 32-bit lane offsets -- M <= 256 rows on every split-K path)
+        const __amdgpu_buffer_rsrc_t srs = tile_rsrc(reinterpret_cast<const char*>(slab));
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
             const int m = m0 + wm * (TBM / 2) + j * 16 + (lane & 15);
@@ -526,7 +539,12 @@ __device__ __forceinline__ void gemm_mfma_body(char* smem, const int tm, const i
 #pragma unroll
             for (int i = 0; i < FN; ++i) {
                 const int n = n0 + wn * (TBN / 2) + i * 16 + (lane >> 4) * 4;
-                if (n < N) *reinterpret_cast<f32x4_t*>(slab + (int64_t)m * N + n) = acc[i][j];
+                if (n >= N) continue;
+                const f32x4_t v = acc[i][j];
+                const u32x4_t u = u32x4_t{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                const uint32_t off = ((uint32_t)m * (uint32_t)N + (uint32_t)n) * 4u;
+                if (wt) __builtin_amdgcn_raw_buffer_store_b128(u, srs, off, 0, 16 /* sc1 */);
+                else __builtin_amdgcn_raw_buffer_store_b128(u, srs, off, 0, 0);
             }
         }
         if (!FUSE) return;
@@ -607,7 +625,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_kernel(const bf16* __restr
     __shared__ __attribute__((aligned(16))) char smem[NS * (TBM + TBN) * BK * 2];
     int tm, tn;
     tile_coords(tiles_m, tiles_n, tm, tn);
-    gemm_mfma_body<TBM, TBN, SPLITK, NS, FUSE>(smem, tm, tn, A, lda, W, ldw, ep, K, tiles_n, partial, s2, slices1, counters);
+    gemm_mfma_body<TBM, TBN, SPLITK, NS, FUSE>(smem, tm, tn, A, lda, W, ldw, ep, K, tiles_n, partial, s2, slices1, counters,
+                                               ep.slab_wt != 0);
 }
 
 // Two problems with the same M, K and K slicing in ONE launch (round 4; the mid-batch decoder layer: the QKV projection reads
@@ -624,13 +643,14 @@ struct GemmSide {
 struct DualArgs {
     GemmSide g[2];
     EpiArgs ep[2];
+    int wt;          // slab stores write-through (EpiArgs::slab_wt; a scalar here: the body reads it before it indexes the arrays)
 };
 // (out of line: with the body inlined into a kernel that picks its operands at run time this compiler's simplifycfg pass crashes;
 //  one call per workgroup costs nothing against a ~10 us tile)
 __device__ __attribute__((noinline)) void gemm_mfma_body_64x64_split4(char* smem, int tm, int tn, const bf16* A, int64_t lda,
                                                                      const bf16* W, int64_t ldw, const EpiArgs& ep, int K,
-                                                                     int tiles_n, float* partial, int* counters) {
-    gemm_mfma_body<64, 64, true, 4, false>(smem, tm, tn, A, lda, W, ldw, ep, K, tiles_n, partial, Seg2{}, 1 << 30, counters);
+                                                                     int tiles_n, float* partial, int* counters, bool wt) {
+    gemm_mfma_body<64, 64, true, 4, false>(smem, tm, tn, A, lda, W, ldw, ep, K, tiles_n, partial, Seg2{}, 1 << 30, counters, wt);
 }
 __global__ __launch_bounds__(256) void gemm_bf16_mfma_dual_kernel(const DualArgs a, int K, int tiles_m, int tiles_n1, int tiles_n2) {
     __shared__ __attribute__((aligned(16))) char smem[4 * (64 + 64) * BK * 2];
@@ -641,7 +661,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_mfma_dual_kernel(const DualArgs
     const int side = tn >= tiles_n1 ? 1 : 0;
     const GemmSide& g = a.g[side];
     gemm_mfma_body_64x64_split4(smem, tm, tn - side * tiles_n1, g.A, g.lda, g.W, g.ldw, a.ep[side], K, side ? tiles_n2 : tiles_n1,
-                                g.partial, g.counters);
+                                g.partial, g.counters, a.wt != 0);
 }
 
 // sum the K-slice partials and apply the shared epilogue (bias, GELU, residual): 8 columns per thread, 16-byte accesses
@@ -1505,16 +1525,7 @@ enum { PP_PLAIN = 0, PP_GELU = 1, PP_RES = 2, PP_QKV = 3, PP_ARGMAX = 4 };   // 
 // materialised logits row -- and writes 8 bytes per row; the logits tile itself is only stored when e.out != nullptr.  A
 // [4096, 50304] bf16 logits matrix is 412 MB written and read back per token step; the partials are 26 MB.
 
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
-// raw (untyped, unbounded) buffer descriptor whose base is a wave-uniform pointer: offsets are 32-bit, so the base is the
-// origin of the tile being written, not of the tensor
-__device__ inline __amdgpu_buffer_rsrc_t tile_rsrc(const char* base_uniform) {
-    const uint64_t a = reinterpret_cast<uint64_t>(base_uniform);
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
-}
 
 // (b, t) = (m / q_len, m % q_len) for the rows of one tile: q_len == 1 (decode) is the identity; for q_len >= 256 a tile's 256 rows
 // cross at most one sequence boundary, so the tile's first row is divided once (scalar) and lanes add / wrap; otherwise divide.
@@ -3347,6 +3358,10 @@ __device__ inline void ts_wait_tiles(int tiles) {
     else wait_vmcnt_n<0>();
 }
 
+// WT: the slab stores are write-through (sc1).  With plain stores the 29-34 MB of slabs sit dirty in the eight L2s until the end-of-kernel
+// release writes them back -- after the last workgroup, on the critical path of the reduce launch that follows; written through they
+// drain while the other workgroups still compute (guide "publish-large" / "splitk-seam": 64 KB fp32 slabs per workgroup at M = 256).
+template <bool WT>
 __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const TallArgs a, int M, int wg_side1) {
     static_assert(TS_WD >= 2 && TS_WD <= 5, "ts_wait_tiles covers up to four W tiles in flight behind the awaited one");
     __shared__ __attribute__((aligned(16))) char smem[TS_SMEM];
@@ -3480,13 +3495,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
     }
     if (!grp1) cbarrier();
     // ---- slab stores: accumulator fragment = row (lane & 15), columns nb * 16 + (lane >> 4) * 4 .. + 3 ----
-    float* slab = g.partial + ((int64_t)slice * M) * N + n0 + wn * 32 + (lane >> 4) * 4;
+    const __amdgpu_buffer_rsrc_t srs = tile_rsrc(reinterpret_cast<const char*>(g.partial + ((int64_t)slice * M) * N + n0 + wn * 32));
+    const uint32_t svoff = ((uint32_t)(lane & 15) * (uint32_t)N + (uint32_t)(lane >> 4) * 4u) * 4u;
 #pragma unroll
     for (int ai = 0; ai < 8; ++ai) {
-        const int row = (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16 + (lane & 15);
-        if (row < M) {
+        const int row0 = (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16;
+        if (row0 + (lane & 15) < M) {
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) *reinterpret_cast<f32x4_t*>(slab + (int64_t)row * N + nb * 16) = acc[ai][nb];
+            for (int nb = 0; nb < 2; ++nb) {
+                const f32x4_t v = acc[ai][nb];
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
+                                                               __float_as_uint(v[3])},
+                                                       srs, svoff, ((uint32_t)row0 * (uint32_t)N + (uint32_t)nb * 16u) * 4u, WT ? 16 : 0);
+            }
         }
     }
 }
@@ -4486,8 +4507,11 @@ BT_KNOB int g_mid_tile = 0;       // fused one-slice QKV / h->4h GEMMs at >= 128
 BT_KNOB bool g_mid_attn = true;   // ... and the token decoder's local-window attention inside that reduce launch (false: A/B)
 BT_KNOB bool g_mid_dual = true;   // 17..256 rows: QKV and h->4h split-K GEMMs of a layer in one launch, their reductions in one (false: A/B)
 BT_KNOB bool g_mid_rows = true;   // 17..256-row stacks take the slab + fused-reduce path (false: A/B against the unfused launches)
+BT_KNOB bool g_mid_wt = true;     // split-K slab stores of the 64 x 64 kernels write-through (false: plain, A/B)
 BT_KNOB int g_mid_tall = 1;       // 129..256 rows: the slab GEMMs run on 256 x 128 tiles (0: the 64 x 64 kernels, A/B; 2: from 65 rows, A/B)
 BT_KNOB int g_mid_tall_wgs = 256; // ... with about this many workgroups per launch (A/B)
+BT_KNOB int g_mid_tall_wgs_res = 256; // ... (the launch with two operand pairs: the residual projections)
+BT_KNOB bool g_mid_tall_wt = true; // ... and write-through slab stores (false: plain stores, A/B)
 // <= 2 rows, local window: the attention computed inside the residual-stream GEMV.  Built and A/B-measured in round 4
 // (profiles/r4_ab_few_attn.jsonl, same box, interleaved): B = 1 1695 vs 1725 tok/s, B = 2 2950 vs 2921 -- a wash: the per-workgroup
 // attention arithmetic (latency chains of ~28 cross-lane ops per item, redundantly in 512 workgroups) costs what the dependent
@@ -5586,7 +5610,7 @@ static bool mid_tall_rows(int64_t M) { return g_mid_tall != 0 && M <= 256 && M >
 // slices of the (up to two) operand pairs of one problem: about g_mid_tall_wgs workgroups in all, >= 4 K-tiles per slice, the second
 // pair's share in proportion to its K
 static void tall_slices(int tiles, int nk1, int nk2, int* s1, int* s2) {
-    const int total = std::max(1, g_mid_tall_wgs / std::max(tiles, 1));
+    const int total = std::max(1, (nk2 > 0 ? g_mid_tall_wgs_res : g_mid_tall_wgs) / std::max(tiles, 1));
     if (nk2 <= 0) {
         *s1 = std::max(1, std::min(total, nk1 / 4));
         *s2 = 0;
@@ -5609,7 +5633,10 @@ static int tall_launch(hipStream_t s, int64_t M, const TallSide& g0, const TallS
     ta.g[1] = g1 ? *g1 : g0;
     const int wg0 = (g0.N / 128) * (g0.s1 + g0.s2);
     const int wg1 = g1 ? (g1->N / 128) * (g1->s1 + g1->s2) : 0;
-    hipLaunchKernelGGL(gemm_bf16_mfma256x128_slab_kernel, dim3(wg0 + wg1), dim3(512), 0, s, ta, (int)M, wg0);
+    if (g_mid_tall_wt)
+        hipLaunchKernelGGL(gemm_bf16_mfma256x128_slab_kernel<true>, dim3(wg0 + wg1), dim3(512), 0, s, ta, (int)M, wg0);
+    else
+        hipLaunchKernelGGL(gemm_bf16_mfma256x128_slab_kernel<false>, dim3(wg0 + wg1), dim3(512), 0, s, ta, (int)M, wg0);
     BT_LAUNCH_CHECK("mid-batch 256 x 128 slab GEMM launch");
     return BT_OK;
 }
@@ -5637,6 +5664,12 @@ static int mid_gemm(hipStream_t s, int64_t M, int64_t N, const void* A, int64_t 
     EpiArgs ep{};
     ep.M = (int)M;
     ep.N = (int)N;
+    ep.slab_wt = g_mid_wt ? 1 : 0;
+    EpiArgs fep{};
+    if (fused_ep) {
+        fep = *fused_ep;
+        fep.slab_wt = ep.slab_wt;
+    }
     Seg2 s2{};
     s2.x = (const bf16*)A2;
     s2.w = (const bf16*)W2;
@@ -5659,7 +5692,7 @@ static int mid_gemm(hipStream_t s, int64_t M, int64_t N, const void* A, int64_t 
     }
     if (fused_ep)
         hipLaunchKernelGGL((gemm_bf16_mfma_kernel<64, 64, true, 4, true>), dim3(tiles_m * tiles_n, sl1 + sl2), dim3(256), 0, s,
-                           (const bf16*)A, lda, (const bf16*)W, K1, *fused_ep, ks, tiles_m, tiles_n, (float*)slabs, s2, sl1,
+                           (const bf16*)A, lda, (const bf16*)W, K1, fep, ks, tiles_m, tiles_n, (float*)slabs, s2, sl1,
                            counters);
     else
         hipLaunchKernelGGL((gemm_bf16_mfma_kernel<64, 64, true, 4>), dim3(tiles_m * tiles_n, sl1 + sl2), dim3(256), 0, s,
@@ -5757,6 +5790,7 @@ int mid_qkv_gelu(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, c
     e2.M = (int)M;
     e2.N = (int)N2;
     e2.act = BT_ACT_GELU;
+    e1.slab_wt = e2.slab_wt = g_mid_wt ? 1 : 0;
     float* p1 = (float*)slabs;
     float* p2 = p1 + (int64_t)slices * M * N1;
     DualArgs da;
@@ -5764,6 +5798,7 @@ int mid_qkv_gelu(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, c
     da.g[1] = GemmSide{(const bf16*)x2, (const bf16*)h4_w, H, K, p2, counters ? counters + tiles_m * t1 : nullptr};
     da.ep[0] = e1;
     da.ep[1] = e2;
+    da.wt = g_mid_wt ? 1 : 0;
     if (tall) {
         ProfScope ps(BT_PROF_LINEAR_MFMA, s);
         TallSide g0{}, g1{};
@@ -5881,6 +5916,9 @@ extern "C" void bt_debug_small_stages(int n) { g_small_stages = n; }
 extern "C" void bt_debug_mid_rows(int on) { g_mid_rows = on != 0; }
 extern "C" void bt_debug_mid_tall(int mode) { g_mid_tall = mode; }
 extern "C" void bt_debug_mid_tall_wgs(int wgs) { g_mid_tall_wgs = wgs > 0 ? wgs : 256; }
+extern "C" void bt_debug_mid_tall_wt(int on) { g_mid_tall_wt = on != 0; }
+extern "C" void bt_debug_mid_wt(int on) { g_mid_wt = on != 0; }
+extern "C" void bt_debug_mid_tall_wgs_res(int wgs) { g_mid_tall_wgs_res = wgs > 0 ? wgs : 256; }
 extern "C" void bt_debug_few_dual(int on) { g_few_dual = on != 0; }
 extern "C" void bt_debug_few_persist(int on) { g_few_persist = on != 0; }
 extern "C" void bt_debug_few_attn(int on) { g_few_attn = on != 0; }

@@ -14,7 +14,8 @@ from conftest import ROOT
 
 SRC = open(os.path.join(ROOT, "block_transformer_amd", "csrc", "gemm.hip")).read()
 WGS = int(re.search(r"BT_KNOB int g_mid_tall_wgs = (\d+);", SRC).group(1))
-for line in ("const int total = std::max(1, g_mid_tall_wgs / std::max(tiles, 1));",
+assert WGS == int(re.search(r"BT_KNOB int g_mid_tall_wgs_res = (\d+);", SRC).group(1))
+for line in ("const int total = std::max(1, (nk2 > 0 ? g_mid_tall_wgs_res : g_mid_tall_wgs) / std::max(tiles, 1));",
              "*s1 = std::max(1, std::min(total, nk1 / 4));",
              "int a = (int)((int64_t)total * nk1 / (nk1 + nk2));",
              "a = std::max(1, std::min(a, std::max(1, nk1 / 4)));",

@@ -1694,8 +1694,8 @@ def test_mid_rows_tall_tiles_match_the_64x64_slab_kernels(M, mode, dbg_lib):
     pairs for the residual projections) instead of 64 x 64 tiles.  Same slab format, same reduce launches, another partition of K:
     hidden states and appended K/V rows of a decode step (q = 1 over a 40-row cache) and of a q = 2 call against the 64 x 64 kernels
     (bt_debug_mid_tall(0)) within fp32-summation-order noise after bf16 rounding, NaN-poisoned slab scratch (a row or column the
-    kernel failed to write would surface), and two other workgroup budgets (more / fewer slices).  mode 2 = the A/B setting that
-    takes 65 .. 128 rows too (half of the tile clamped)."""
+    kernel failed to write would surface), two other workgroup budgets (more / fewer slices) and plain instead of write-through slab
+    stores (bit-identical).  mode 2 = the A/B setting that takes 65 .. 128 rows too (half of the tile clamped)."""
     from block_transformer_amd.runtime import _shared_ws
     model, dims, o = _mid_stack(layers=3)
     H = dims.bd.hidden
@@ -1720,18 +1720,25 @@ def test_mid_rows_tall_tiles_match_the_64x64_slab_kernels(M, mode, dbg_lib):
 
     outs = {}
     try:
-        for key, (tall, wgs) in {"small": (0, 256), "tall": (mode, 256), "tall512": (mode, 512), "tall96": (mode, 96)}.items():
+        for key, (tall, wgs, wt) in {"small": (0, 256, 1), "tall": (mode, 256, 1), "tall512": (mode, 512, 1), "tall96": (mode, 96, 1),
+                                     "plain": (mode, 256, 0)}.items():
             dbg_lib.bt_debug_mid_tall(tall)
             dbg_lib.bt_debug_mid_tall_wgs(wgs)
+            dbg_lib.bt_debug_mid_tall_wgs_res(wgs)
+            dbg_lib.bt_debug_mid_tall_wt(wt)
             outs[key] = run()
     finally:
         dbg_lib.bt_debug_mid_tall(1)
         dbg_lib.bt_debug_mid_tall_wgs(256)
+        dbg_lib.bt_debug_mid_tall_wgs_res(256)
+        dbg_lib.bt_debug_mid_tall_wt(1)
     ref_pre, past = o.block_decoder(xp.float(), ones[:, :past_len])
     ref, kv = o.block_decoder(xs.float(), ones, past)
     ref = ref[:, 0]
     scale = ref.abs().max().item()
     base = outs["small"]
+    for a_, b_ in zip(outs["plain"], outs["tall"]):               # the store policy of the slabs changes no value
+        assert a_ is None or torch.equal(a_, b_)
     for key in ("tall", "tall512", "tall96"):
         got = outs[key]
         assert torch.isfinite(got[0]).all() and torch.isfinite(got[1]).all() and torch.isfinite(got[2]).all(), key
