@@ -707,10 +707,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 // The split-K GEMM above leaves fp32 slabs [slices][M][N]; these kernels sum them and do everything the layer needs next at
 // that point, so that no separate RoPE / KV-append / LayerNorm launch remains (a 17..256-row decode step is bound by the
 // number of dependent launches, ~5-10 us each, not by bytes or flops).
+// (slice order, whatever the count: the in-launch reductions and every reduce kernel produce the same bits.  Four slices' loads are
+//  issued before the first add -- with 16 slices of the 256 x 128 slab kernel a one-load-at-a-time loop is sixteen dependent round trips)
 __device__ inline void sum_slabs8(const float* __restrict__ partial, int slices, int64_t slab, int64_t off, float (&v)[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = 0.f;
-    for (int s = 0; s < slices; ++s) {
+    int s = 0;
+    for (; s + 4 <= slices; s += 4) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float* p = partial + (int64_t)(s + u) * slab + off;
+            a[u] = *reinterpret_cast<const float4*>(p);
+            b[u] = *reinterpret_cast<const float4*>(p + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w;
+            v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
+        }
+    }
+    for (; s < slices; ++s) {
         const float* p = partial + (int64_t)s * slab + off;
         const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
         v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w;
@@ -910,9 +927,25 @@ __device__ __forceinline__ void mid_reduce_qkv_attn_body(const int item, const f
 template <int KMAX>
 __global__ __launch_bounds__(256) void mid_reduce_qkv_attn_gelu_kernel(const float* __restrict__ p1, const EpiArgs ep1, int nb1,
                                                                       const float* __restrict__ p2, const EpiArgs ep2, int slices,
-                                                                      bf16* __restrict__ att, int64_t ld_att, float scale) {
-    if ((int)blockIdx.x < nb1) mid_reduce_qkv_attn_body<KMAX>((int)blockIdx.x * 4 + (int)(threadIdx.x >> 6), p1, slices, ep1, att, ld_att, scale);
-    else splitk_reduce_body((int64_t)(blockIdx.x - nb1) * 256 + threadIdx.x, p2, slices, ep2);
+                                                                      bf16* __restrict__ att, int64_t ld_att, float scale,
+                                                                      const bool g_interleave) {
+    // the two kinds of workgroup alternate while both last: the attention items are chains of dependent round trips, the GELU
+    // reduction streams -- side by side on a CU they overlap, one kind after the other they do not (256 rows: 1024 + 1024
+    // workgroups at four per CU; profiles/r5_ab_mid_reduce_interleave.jsonl)
+    const int b = (int)blockIdx.x, nb2 = (int)gridDim.x - nb1, both = 2 * min(nb1, nb2);
+    int kind, idx;
+    if (!g_interleave) {
+        kind = b < nb1 ? 0 : 1;
+        idx = b < nb1 ? b : b - nb1;
+    } else if (b < both) {
+        kind = b & 1;
+        idx = b >> 1;
+    } else {
+        kind = nb1 > nb2 ? 0 : 1;
+        idx = b - both + (both >> 1);
+    }
+    if (kind == 0) mid_reduce_qkv_attn_body<KMAX>(idx * 4 + (int)(threadIdx.x >> 6), p1, slices, ep1, att, ld_att, scale);
+    else splitk_reduce_body((int64_t)idx * 256 + threadIdx.x, p2, slices, ep2);
 }
 
 // Residual stream: x[m, :] += sum(slabs) + bias + bias2 (in place, rounded to bf16 like the unfused epilogues), then the NEXT
@@ -3300,8 +3333,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_kernel(const bf16* 
     }
 }
 
-// ---- 256 x 128 tiles cut along K into fp32 slabs: the mid-batch projections at 129 .. 256 rows (round 5) ----------------------------
-// At 129 .. 256 rows the 64 x 64 slab kernel above moves 16 KiB of operands from L2 per 0.5 MFLOP (32 flop per L2 -> LDS byte) and keeps
+// ---- 256 x 128 tiles cut along K into fp32 slabs: the mid-batch projections at 97 .. 256 rows (round 5) ----------------------------
+// At 97 .. 256 rows the 64 x 64 slab kernel above moves 16 KiB of operands from L2 per 0.5 MFLOP (32 flop per L2 -> LDS byte) and keeps
 // 48 KiB of weights in flight per CU: its QKV and h -> 4h launches take 22 us each at 256 rows (0.29 PF, 1.1-1.5 TB/s of weights;
 // profiles/r4_bench_b256_kernel_stats.md).  This kernel is the one-tile 256 x 128 kernel's tile and wave layout (8 waves = two groups half a
 // K-tile apart, a wave owns 64 rows of each A half x 32 columns, phase 0 = A0 + W, phase 1 = A1) with what this regime needs:
@@ -4507,8 +4540,10 @@ BT_KNOB int g_mid_tile = 0;       // fused one-slice QKV / h->4h GEMMs at >= 128
 BT_KNOB bool g_mid_attn = true;   // ... and the token decoder's local-window attention inside that reduce launch (false: A/B)
 BT_KNOB bool g_mid_dual = true;   // 17..256 rows: QKV and h->4h split-K GEMMs of a layer in one launch, their reductions in one (false: A/B)
 BT_KNOB bool g_mid_rows = true;   // 17..256-row stacks take the slab + fused-reduce path (false: A/B against the unfused launches)
-BT_KNOB bool g_mid_wt = true;     // split-K slab stores of the 64 x 64 kernels write-through (false: plain, A/B)
-BT_KNOB int g_mid_tall = 1;       // 129..256 rows: the slab GEMMs run on 256 x 128 tiles (0: the 64 x 64 kernels, A/B; 2: from 65 rows, A/B)
+BT_KNOB bool g_mid_wt = false;    // split-K slab stores of the 64 x 64 kernels write-through: measured -0.8 ... -2.6 % at B = 32 ... 128
+                                  // (profiles/r5_ab_mid_write_through_slabs.jsonl; their slabs are a few MB and stay in L2) -> off (true: A/B)
+BT_KNOB bool g_mid_interleave = true;   // QKV + attention + GELU reduce launch: the two kinds of workgroup alternate (false: A/B)
+BT_KNOB int g_mid_tall = 1;       // 97..256 rows: the slab GEMMs run on 256 x 128 tiles (0: the 64 x 64 kernels, A/B; 2: from 65 rows, A/B)
 BT_KNOB int g_mid_tall_wgs = 256; // ... with about this many workgroups per launch (A/B)
 BT_KNOB int g_mid_tall_wgs_res = 256; // ... (the launch with two operand pairs: the residual projections)
 BT_KNOB bool g_mid_tall_wt = true; // ... and write-through slab stores (false: plain stores, A/B)
@@ -5604,8 +5639,8 @@ int64_t mid_slab_bytes(int64_t M, int64_t H, int64_t I) {
     return worst;
 }
 
-// ---- 129 .. 256 rows: 256 x 128 tiles, K ranges per workgroup (gemm_bf16_mfma256x128_slab_kernel) ----
-static bool mid_tall_rows(int64_t M) { return g_mid_tall != 0 && M <= 256 && M > (g_mid_tall >= 2 ? 64 : 128); }
+// ---- 97 .. 256 rows: 256 x 128 tiles, K ranges per workgroup (gemm_bf16_mfma256x128_slab_kernel) ----
+static bool mid_tall_rows(int64_t M) { return g_mid_tall != 0 && M <= 256 && M > (g_mid_tall >= 2 ? 64 : 96); }
 
 // slices of the (up to two) operand pairs of one problem: about g_mid_tall_wgs workgroups in all, >= 4 K-tiles per slice, the second
 // pair's share in proportion to its K
@@ -5746,7 +5781,7 @@ int mid_qkv_gelu(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, c
     if (attn_done) *attn_done = false;
     if (!g_mid_dual || g_mid_fuse == 2 || N1 % 64 != 0 || N2 % 64 != 0) return BT_OK;
     const int tiles_m = (int)ceil_div(M, 64), t1 = (int)(N1 / 64), t2 = (int)(N2 / 64);
-    // 129 .. 256 rows: both problems on 256 x 128 tiles, two K ranges each (112 column tiles x 2 = 224 workgroups for the 1.2B layer)
+    // 97 .. 256 rows: both problems on 256 x 128 tiles, two K ranges each (112 column tiles x 2 = 224 workgroups for the 1.2B layer)
     const bool tall = mid_tall_rows(M) && N1 % 128 == 0 && N2 % 128 == 0 && tall_operand_ok(x1, H, K) && tall_operand_ok(x2, H, K) &&
                       tall_operand_ok(qkv_w, K, K) && tall_operand_ok(h4_w, K, K);
     int tall_s = 0, unused = 0;
@@ -5823,10 +5858,10 @@ int mid_qkv_gelu(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, c
         const float scale = 1.0f / sqrtf(128.0f);
         if (pos0_host + q_len <= 8)
             hipLaunchKernelGGL((mid_reduce_qkv_attn_gelu_kernel<8>), dim3(nb1 + nb2), dim3(256), 0, s, p1, e1, nb1, p2, e2, slices,
-                               (bf16*)att, ld_att, scale);
+                               (bf16*)att, ld_att, scale, g_mid_interleave);
         else
             hipLaunchKernelGGL((mid_reduce_qkv_attn_gelu_kernel<12>), dim3(nb1 + nb2), dim3(256), 0, s, p1, e1, nb1, p2, e2, slices,
-                               (bf16*)att, ld_att, scale);
+                               (bf16*)att, ld_att, scale, g_mid_interleave);
         BT_LAUNCH_CHECK("mid-batch QKV + attention + GELU reduce launch");
         *attn_done = true;
         return BT_OK;
@@ -5918,6 +5953,7 @@ extern "C" void bt_debug_mid_tall(int mode) { g_mid_tall = mode; }
 extern "C" void bt_debug_mid_tall_wgs(int wgs) { g_mid_tall_wgs = wgs > 0 ? wgs : 256; }
 extern "C" void bt_debug_mid_tall_wt(int on) { g_mid_tall_wt = on != 0; }
 extern "C" void bt_debug_mid_wt(int on) { g_mid_wt = on != 0; }
+extern "C" void bt_debug_mid_interleave(int on) { g_mid_interleave = on != 0; }
 extern "C" void bt_debug_mid_tall_wgs_res(int wgs) { g_mid_tall_wgs_res = wgs > 0 ? wgs : 256; }
 extern "C" void bt_debug_few_dual(int on) { g_few_dual = on != 0; }
 extern "C" void bt_debug_few_persist(int on) { g_few_persist = on != 0; }

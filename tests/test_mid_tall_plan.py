@@ -1,4 +1,4 @@
-"""K ranges of the 256 x 128 slab kernel (gemm_bf16_mfma256x128_slab_kernel, mid-batch stacks of 129 .. 256 rows; round 5).
+"""K ranges of the 256 x 128 slab kernel (gemm_bf16_mfma256x128_slab_kernel, mid-batch stacks of 97 .. 256 rows; round 5).
 
 DOCUMENTATION / PROOF test of the slicing, not of the HIP code: `tall_slices` (host) and the kernel's slice -> K-tile range are
 restated here and checked for what the kernel and the reduce launches rely on -- the ranges of a pair partition its K-tiles, no range
