@@ -160,7 +160,7 @@ _DEBUG_SIGS = {
     "bt_debug_mid_tall_wgs": (None, [c_int]),
     "bt_debug_mid_tall_wt": (None, [c_int]),
     "bt_debug_mid_wt": (None, [c_int]),
-    "bt_debug_mid_interleave": (None, [c_int]),
+    "bt_debug_mid_rows_max": (None, [c_int]),
     "bt_debug_mid_tall_wgs_res": (None, [c_int]),
     "bt_debug_no_qkv_fusion": (None, [c_int]),
     "bt_debug_flash_variant": (None, [c_int]),

@@ -927,23 +927,11 @@ __device__ __forceinline__ void mid_reduce_qkv_attn_body(const int item, const f
 template <int KMAX>
 __global__ __launch_bounds__(256) void mid_reduce_qkv_attn_gelu_kernel(const float* __restrict__ p1, const EpiArgs ep1, int nb1,
                                                                       const float* __restrict__ p2, const EpiArgs ep2, int slices,
-                                                                      bf16* __restrict__ att, int64_t ld_att, float scale,
-                                                                      const bool g_interleave) {
-    // the two kinds of workgroup alternate while both last: the attention items are chains of dependent round trips, the GELU
-    // reduction streams -- side by side on a CU they overlap, one kind after the other they do not (256 rows: 1024 + 1024
-    // workgroups at four per CU; profiles/r5_ab_mid_reduce_interleave.jsonl)
-    const int b = (int)blockIdx.x, nb2 = (int)gridDim.x - nb1, both = 2 * min(nb1, nb2);
-    int kind, idx;
-    if (!g_interleave) {
-        kind = b < nb1 ? 0 : 1;
-        idx = b < nb1 ? b : b - nb1;
-    } else if (b < both) {
-        kind = b & 1;
-        idx = b >> 1;
-    } else {
-        kind = nb1 > nb2 ? 0 : 1;
-        idx = b - both + (both >> 1);
-    }
+                                                                      bf16* __restrict__ att, int64_t ld_att, float scale) {
+    // (alternating the two kinds of workgroup instead -- dependent round trips next to a stream -- measured 16.7 -> 24.9 us per launch at
+    //  256 rows, -1.5 ... -2.4 % end to end at B = 64 ... 256: profiles/r5_ab_mid_reduce_interleave_rejected.jsonl)
+    const int b = (int)blockIdx.x;
+    const int kind = b < nb1 ? 0 : 1, idx = b < nb1 ? b : b - nb1;
     if (kind == 0) mid_reduce_qkv_attn_body<KMAX>(idx * 4 + (int)(threadIdx.x >> 6), p1, slices, ep1, att, ld_att, scale);
     else splitk_reduce_body((int64_t)idx * 256 + threadIdx.x, p2, slices, ep2);
 }
@@ -3338,7 +3326,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_kernel(const bf16* 
 // 48 KiB of weights in flight per CU: its QKV and h -> 4h launches take 22 us each at 256 rows (0.29 PF, 1.1-1.5 TB/s of weights;
 // profiles/r4_bench_b256_kernel_stats.md).  This kernel is the one-tile 256 x 128 kernel's tile and wave layout (8 waves = two groups half a
 // K-tile apart, a wave owns 64 rows of each A half x 32 columns, phase 0 = A0 + W, phase 1 = A1) with what this regime needs:
-//   * the whole stack is ONE row tile: rows >= M are clamped in the LDS-DMA addresses (their products are never stored);
+//   * the whole stack is ONE row tile (two at 257 .. 512 rows): rows >= M are clamped in the LDS-DMA addresses (their products are never
+//     stored);
 //   * a K range per workgroup: workgroup = (column tile, slice); slice s of a pair with nk K-tiles and S slices takes K-tiles
 //     [s nk / S, (s + 1) nk / S) -- slices need not be equal, so 16 column tiles x 16 slices cover the residual projections' 128 + 32
 //     K-tiles with 256 workgroups; slices >= s1 belong to the optional second operand pair;
@@ -3408,7 +3397,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
     const TallSide& g = a.g[side];
     const int id = (int)blockIdx.x - side * wg_side1;
     const int S = g.s1 + g.s2;
-    const int slice = id % S, tn = id / S;   // consecutive ids (= XCDs) take different slices: an XCD's L2 holds S / 8 of the A columns
+    const int slice = id % S, tile = id / S;   // consecutive ids (= XCDs) take different slices: an XCD's L2 holds S / 8 of the A columns
+    const int tiles_n = g.N >> 7;
+    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;   // 257 .. 512 rows: two row tiles
+    const int m0 = tm * 256;
     const bool second = slice >= g.s1;
     const int sidx = second ? slice - g.s1 : slice, scnt = second ? g.s2 : g.s1, nk_all = second ? g.nk2 : g.nk1;
     const int kb = sidx * nk_all / scnt, ke = (sidx + 1) * nk_all / scnt;   // (slices x K-tiles << 2^31)
@@ -3425,7 +3417,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            va[h][j] = (uint32_t)min(h * 128 + wq * 32 + j * 8 + (lane >> 3), M - 1) * (uint32_t)(lda * 2) + lane_slot;
+            va[h][j] = (uint32_t)min(m0 + h * 128 + wq * 32 + j * 8 + (lane >> 3), M - 1) * (uint32_t)(lda * 2) + lane_slot;
     const uint32_t vw = (uint32_t)(lane >> 3) * (uint32_t)(ldw * 2) + lane_slot;
     const uint32_t row8_w = (uint32_t)(8 * ldw * 2);
     const char* pa = reinterpret_cast<const char*>(A) + (int64_t)kb * (BK * 2);
@@ -3532,7 +3524,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
     const uint32_t svoff = ((uint32_t)(lane & 15) * (uint32_t)N + (uint32_t)(lane >> 4) * 4u) * 4u;
 #pragma unroll
     for (int ai = 0; ai < 8; ++ai) {
-        const int row0 = (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16;
+        const int row0 = m0 + (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16;
         if (row0 + (lane & 15) < M) {
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
@@ -4542,8 +4534,8 @@ BT_KNOB bool g_mid_dual = true;   // 17..256 rows: QKV and h->4h split-K GEMMs o
 BT_KNOB bool g_mid_rows = true;   // 17..256-row stacks take the slab + fused-reduce path (false: A/B against the unfused launches)
 BT_KNOB bool g_mid_wt = false;    // split-K slab stores of the 64 x 64 kernels write-through: measured -0.8 ... -2.6 % at B = 32 ... 128
                                   // (profiles/r5_ab_mid_write_through_slabs.jsonl; their slabs are a few MB and stay in L2) -> off (true: A/B)
-BT_KNOB bool g_mid_interleave = true;   // QKV + attention + GELU reduce launch: the two kinds of workgroup alternate (false: A/B)
 BT_KNOB int g_mid_tall = 1;       // 97..256 rows: the slab GEMMs run on 256 x 128 tiles (0: the 64 x 64 kernels, A/B; 2: from 65 rows, A/B)
+BT_KNOB int g_mid_rows_max = 512;  // ... and take stacks of up to this many rows (two row tiles; 256: the round-4 limit, A/B)
 BT_KNOB int g_mid_tall_wgs = 256; // ... with about this many workgroups per launch (A/B)
 BT_KNOB int g_mid_tall_wgs_res = 256; // ... (the launch with two operand pairs: the residual projections)
 BT_KNOB bool g_mid_tall_wt = true; // ... and write-through slab stores (false: plain stores, A/B)
@@ -5610,8 +5602,9 @@ static void tall_slices(int tiles, int nk1, int nk2, int* s1, int* s2);
 
 bool mid_rows_ok(int64_t M, int64_t H, int64_t I, int head_dim, int rot) {
     // (bt_decoder_forward sends stacks of <= g_few_rows_max rows to the weight-streaming GEMV / MFMA-streamer launches first)
-    return M >= 1 && M <= 256 && rot == 32 && head_dim % 32 == 0 && H % 256 == 0 && I % 256 == 0 && H <= 8192 &&
-           !g_force_generic && g_gemm_variant == 0 && g_mid_rows;
+    // (257 .. 512 rows, round 5: only with the 256 x 128 slab kernel -- the 64 x 64 kernels lose to the large-M launches there)
+    return M >= 1 && (M <= 256 || (mid_tall_rows(M) && M <= 512)) && rot == 32 && head_dim % 32 == 0 && H % 256 == 0 && I % 256 == 0 &&
+           H <= 8192 && !g_force_generic && g_gemm_variant == 0 && g_mid_rows;
 }
 
 int64_t mid_slab_bytes(int64_t M, int64_t H, int64_t I) {
@@ -5631,16 +5624,17 @@ int64_t mid_slab_bytes(int64_t M, int64_t H, int64_t I) {
     }
     if (mid_tall_rows(M) && H % 128 == 0 && I % 128 == 0) {   // 256 x 128 tiles: K ranges sized to fill the chip
         int s1 = 0, s2 = 0;
-        tall_slices((int)(H / 128), (int)(I / 64), (int)(H / 64), &s1, &s2);
+        const int tmr = (int)ceil_div(M, 256);
+        tall_slices(tmr * (int)(H / 128), (int)(I / 64), (int)(H / 64), &s1, &s2);
         worst = std::max(worst, (int64_t)(s1 + s2) * M * H * 4);
-        tall_slices((int)((3 * H + I) / 128), (int)(H / 64), 0, &s1, &s2);
+        tall_slices(tmr * (int)((3 * H + I) / 128), (int)(H / 64), 0, &s1, &s2);
         worst = std::max(worst, (int64_t)s1 * M * (3 * H + I) * 4);
     }
     return worst;
 }
 
 // ---- 97 .. 256 rows: 256 x 128 tiles, K ranges per workgroup (gemm_bf16_mfma256x128_slab_kernel) ----
-static bool mid_tall_rows(int64_t M) { return g_mid_tall != 0 && M <= 256 && M > (g_mid_tall >= 2 ? 64 : 96); }
+static bool mid_tall_rows(int64_t M) { return g_mid_tall != 0 && M <= g_mid_rows_max && M > (g_mid_tall >= 2 ? 64 : 96); }
 
 // slices of the (up to two) operand pairs of one problem: about g_mid_tall_wgs workgroups in all, >= 4 K-tiles per slice, the second
 // pair's share in proportion to its K
@@ -5659,15 +5653,16 @@ static void tall_slices(int tiles, int nk1, int nk2, int* s1, int* s2) {
 }
 
 static bool tall_operand_ok(const void* x, int64_t ld, int64_t K) {
-    return x && aligned16(x) && ld % 8 == 0 && K % 64 == 0 && K >= 256 && ld * 2 * 256 < ((int64_t)1 << 31);
+    return x && aligned16(x) && ld % 8 == 0 && K % 64 == 0 && K >= 256 && ld * 2 * 512 < ((int64_t)1 << 31);
 }
 
 static int tall_launch(hipStream_t s, int64_t M, const TallSide& g0, const TallSide* g1) {
     TallArgs ta{};
     ta.g[0] = g0;
     ta.g[1] = g1 ? *g1 : g0;
-    const int wg0 = (g0.N / 128) * (g0.s1 + g0.s2);
-    const int wg1 = g1 ? (g1->N / 128) * (g1->s1 + g1->s2) : 0;
+    const int tiles_m = (int)ceil_div(M, 256);
+    const int wg0 = tiles_m * (g0.N / 128) * (g0.s1 + g0.s2);
+    const int wg1 = g1 ? tiles_m * (g1->N / 128) * (g1->s1 + g1->s2) : 0;
     if (g_mid_tall_wt)
         hipLaunchKernelGGL(gemm_bf16_mfma256x128_slab_kernel<true>, dim3(wg0 + wg1), dim3(512), 0, s, ta, (int)M, wg0);
     else
@@ -5785,7 +5780,7 @@ int mid_qkv_gelu(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, c
     const bool tall = mid_tall_rows(M) && N1 % 128 == 0 && N2 % 128 == 0 && tall_operand_ok(x1, H, K) && tall_operand_ok(x2, H, K) &&
                       tall_operand_ok(qkv_w, K, K) && tall_operand_ok(h4_w, K, K);
     int tall_s = 0, unused = 0;
-    if (tall) tall_slices((int)((N1 + N2) / 128), (int)(K / 64), 0, &tall_s, &unused);
+    if (tall) tall_slices((int)(ceil_div(M, 256) * ((N1 + N2) / 128)), (int)(K / 64), 0, &tall_s, &unused);
     const int ks = tall ? (int)K : mid_slice_len((int64_t)tiles_m * (t1 + t2), K, 0);
     if (ks <= 0) return BT_OK;
     int slices = tall ? tall_s : (int)(K / ks);
@@ -5858,10 +5853,10 @@ int mid_qkv_gelu(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, c
         const float scale = 1.0f / sqrtf(128.0f);
         if (pos0_host + q_len <= 8)
             hipLaunchKernelGGL((mid_reduce_qkv_attn_gelu_kernel<8>), dim3(nb1 + nb2), dim3(256), 0, s, p1, e1, nb1, p2, e2, slices,
-                               (bf16*)att, ld_att, scale, g_mid_interleave);
+                               (bf16*)att, ld_att, scale);
         else
             hipLaunchKernelGGL((mid_reduce_qkv_attn_gelu_kernel<12>), dim3(nb1 + nb2), dim3(256), 0, s, p1, e1, nb1, p2, e2, slices,
-                               (bf16*)att, ld_att, scale, g_mid_interleave);
+                               (bf16*)att, ld_att, scale);
         BT_LAUNCH_CHECK("mid-batch QKV + attention + GELU reduce launch");
         *attn_done = true;
         return BT_OK;
@@ -5902,7 +5897,7 @@ int mid_res_ln(hipStream_t s, int64_t M, int64_t N, int64_t K1, const void* x1, 
     int ts1 = 0, ts2 = 0;
     const bool tall = mid_tall_rows(M) && N % 128 == 0 && tall_operand_ok(x1, ldx1, K1) && tall_operand_ok(w1, K1, K1) &&
                       (K2 == 0 || (tall_operand_ok(x2, ldx2, K2) && tall_operand_ok(w2, K2, K2)));
-    if (tall) tall_slices((int)(N / 128), (int)(K1 / 64), (int)(K2 / 64), &ts1, &ts2);
+    if (tall) tall_slices((int)(ceil_div(M, 256) * (N / 128)), (int)(K1 / 64), (int)(K2 / 64), &ts1, &ts2);
     if (tall && (int64_t)(ts1 + ts2) * M * N * 4 <= slab_bytes) {
         ProfScope ps(BT_PROF_LINEAR_MFMA, s);
         TallSide g0{};
@@ -5953,7 +5948,7 @@ extern "C" void bt_debug_mid_tall(int mode) { g_mid_tall = mode; }
 extern "C" void bt_debug_mid_tall_wgs(int wgs) { g_mid_tall_wgs = wgs > 0 ? wgs : 256; }
 extern "C" void bt_debug_mid_tall_wt(int on) { g_mid_tall_wt = on != 0; }
 extern "C" void bt_debug_mid_wt(int on) { g_mid_wt = on != 0; }
-extern "C" void bt_debug_mid_interleave(int on) { g_mid_interleave = on != 0; }
+extern "C" void bt_debug_mid_rows_max(int rows) { g_mid_rows_max = rows; }
 extern "C" void bt_debug_mid_tall_wgs_res(int wgs) { g_mid_tall_wgs_res = wgs > 0 ? wgs : 256; }
 extern "C" void bt_debug_few_dual(int on) { g_few_dual = on != 0; }
 extern "C" void bt_debug_few_persist(int on) { g_few_persist = on != 0; }

@@ -1,4 +1,4 @@
-"""K ranges of the 256 x 128 slab kernel (gemm_bf16_mfma256x128_slab_kernel, mid-batch stacks of 97 .. 256 rows; round 5).
+"""K ranges of the 256 x 128 slab kernel (gemm_bf16_mfma256x128_slab_kernel, mid-batch stacks of 97 .. 512 rows; round 5).
 
 DOCUMENTATION / PROOF test of the slicing, not of the HIP code: `tall_slices` (host) and the kernel's slice -> K-tile range are
 restated here and checked for what the kernel and the reduce launches rely on -- the ranges of a pair partition its K-tiles, no range
@@ -21,7 +21,8 @@ for line in ("const int total = std::max(1, (nk2 > 0 ? g_mid_tall_wgs_res : g_mi
              "a = std::max(1, std::min(a, std::max(1, nk1 / 4)));",
              "int b = std::max(1, std::min(total - a, std::max(1, nk2 / 4)));",
              "const int kb = sidx * nk_all / scnt, ke = (sidx + 1) * nk_all / scnt;",
-             "const int slice = id % S, tn = id / S;",
+             "const int slice = id % S, tile = id / S;",
+             "const int tm = tile / tiles_n, tn = tile - tm * tiles_n;",
              "const bool second = slice >= g.s1;"):
     assert line in SRC, line
 
@@ -63,6 +64,17 @@ def test_k_ranges_partition_each_pair_and_respect_the_prologue(N, K1, K2):
         assert max(e - b for b, e in r) - min(e - b for b, e in r) <= 1     # balanced
     wgs = tiles * (s1 + s2)
     assert wgs <= max(WGS, tiles) + tiles                                    # about one workgroup per CU, never a second round by much
+
+
+def test_two_row_tiles_halve_the_slices():
+    """257 .. 512 rows: two row tiles per column tile -> the K split that fills the chip is half as deep (the QKV + h->4h launch needs
+    none at all: 224 workgroups, no second slab)."""
+    s, _ = tall_slices(2 * (6144 + 8192) // 128, 32, 0)
+    assert s == 1
+    s1, s2 = tall_slices(2 * 16, 128, 32)
+    assert (s1, s2) == (6, 2) and 2 * 16 * (s1 + s2) == 256
+    # slab bytes of the 1.2B layer at 512 rows fit the 64 MiB stream-K scratch the engine's workspace carries above 256 rows
+    assert max(1 * 512 * (6144 + 8192) * 4, (s1 + s2) * 512 * 2048 * 4) + 4096 <= 64 << 20
 
 
 def test_the_1p2b_layer_fills_the_chip():

@@ -1641,7 +1641,7 @@ def test_decoder_forward_rejects_cache_overflow_before_any_launch(B, q_len):
     assert rc == 0, lib().bt_last_error()
 
 
-@pytest.mark.parametrize("M", [3, 4, 6, 8, 16, 17, 32, 64, 96, 97, 128, 129, 200, 255, 256])
+@pytest.mark.parametrize("M", [3, 4, 6, 8, 16, 17, 32, 64, 96, 97, 128, 129, 200, 255, 256, 257, 400, 512])
 def test_mid_rows_decoder_stack_vs_fp32_oracle(M, dbg_lib):
     """3 .. 256 rows through bt_decoder_forward (round 4: the slab path starts at 3 rows): the split-K slab GEMMs + fused reduces (bias + RoPE + KV append; bias +
     GELU; both residual projections + residual + next-layer LayerNorm pair).  A decode step (q = 1 against a 40-row cache
@@ -1679,7 +1679,7 @@ def test_mid_rows_decoder_stack_vs_fp32_oracle(M, dbg_lib):
     assert (k_new - k_ref).abs().max().item() <= 3e-2 * k_ref.abs().max().item() + 1e-2
     assert (v_new - v_ref).abs().max().item() <= 3e-2 * v_ref.abs().max().item() + 1e-2
     assert (k_new - k_u).abs().max().item() <= 3e-2 * k_ref.abs().max().item() + 1e-2
-    if M <= 128:   # q = 2 rows per sequence (token-decoder step 0 shape): M rows = M/2 sequences
+    if M <= 128 or M in (400, 512):   # q = 2 rows per sequence (token-decoder step 0 shape): M rows = M/2 sequences
         x2 = (torch.randn(M // 2, 2, H, generator=g) * 0.5).bfloat16()
         m2 = torch.ones(M // 2, 2, dtype=torch.long)
         got = model.block_decoder(inputs_embeds=x2.to(DEV), block_attention_mask=m2.to(DEV)).hidden_states.float().cpu()
@@ -1687,7 +1687,8 @@ def test_mid_rows_decoder_stack_vs_fp32_oracle(M, dbg_lib):
         assert (got - want).abs().max().item() <= 3e-2 * want.abs().max().item() + 1e-2
 
 
-@pytest.mark.parametrize("M,mode", [(97, 1), (128, 1), (129, 1), (136, 1), (192, 1), (250, 1), (256, 1), (65, 2), (96, 2)])
+@pytest.mark.parametrize("M,mode", [(97, 1), (128, 1), (129, 1), (136, 1), (192, 1), (250, 1), (256, 1), (257, 1), (300, 1), (384, 1),
+                                    (510, 1), (512, 1), (65, 2), (96, 2)])
 def test_mid_rows_tall_tiles_match_the_64x64_slab_kernels(M, mode, dbg_lib):
     """97 .. 256 rows (round 5): the slab GEMMs of a layer run on 256 x 128 tiles with a K RANGE per workgroup
     (gemm_bf16_mfma256x128_slab_kernel: rows >= M clamped in the DMA addresses, unequal slices, two problems per launch, two operand
@@ -1743,14 +1744,16 @@ def test_mid_rows_tall_tiles_match_the_64x64_slab_kernels(M, mode, dbg_lib):
         got = outs[key]
         assert torch.isfinite(got[0]).all() and torch.isfinite(got[1]).all() and torch.isfinite(got[2]).all(), key
         assert (got[0] - ref).abs().max().item() <= 3e-2 * scale + 1e-2, (key, (got[0] - ref).abs().max().item())
-        # against the 64 x 64 kernels: three layers of bf16 activations whose fp32 pre-rounding sums differ in the last bits
-        assert (got[0] - base[0]).abs().max().item() <= 1.5e-2 * scale, (key, (got[0] - base[0]).abs().max().item())
-        assert (got[0] - base[0]).abs().mean().item() <= 1e-3 * scale, (key, (got[0] - base[0]).abs().mean().item())
+        # against the 64 x 64 kernels (above 256 rows: against the large-M launch sequence, which the stack takes with the knob off):
+        # three layers of bf16 activations whose fp32 pre-rounding sums differ in the last bits
+        tol = 1.5e-2 if M <= 256 else 3e-2
+        assert (got[0] - base[0]).abs().max().item() <= tol * scale, (key, (got[0] - base[0]).abs().max().item())
+        assert (got[0] - base[0]).abs().mean().item() <= tol / 15 * scale, (key, (got[0] - base[0]).abs().mean().item())
         for i in (1, 2):
-            assert (got[i] - base[i]).abs().max().item() <= 1.5e-2 * base[i].abs().max().item(), (key, i)
+            assert (got[i] - base[i]).abs().max().item() <= tol * base[i].abs().max().item(), (key, i)
         if q2:
             assert torch.isfinite(got[3]).all()
-            assert (got[3] - base[3]).abs().max().item() <= 1.5e-2 * base[3].abs().max().item(), key
+            assert (got[3] - base[3]).abs().max().item() <= tol * base[3].abs().max().item(), key
     if q2:
         want, _ = o.block_decoder(x2.float(), m2)
         assert (outs["tall"][3] - want).abs().max().item() <= 3e-2 * want.abs().max().item() + 1e-2
@@ -1933,18 +1936,12 @@ def test_mid_batch_dual_gemm_matches_separate_launches(B, L, dbg_lib):
         model._engine = None
         model.use_graphs = False
         eager = model.generate(prompt, max_length=P + 4 * L).cpu()
-        model.use_graphs = True
-        dbg_lib.bt_debug_mid_interleave(0)                      # attention workgroups first, then the GELU reduction (round 4 order)
-        model._engine = None
-        in_order = model.generate(prompt, max_length=P + 4 * L).cpu()
     finally:
         dbg_lib.bt_debug_mid_dual(1)
         dbg_lib.bt_debug_mid_attn(1)
-        dbg_lib.bt_debug_mid_interleave(1)
         model.use_graphs = True
         model._engine = None
     assert torch.equal(outs["dual+attn"], eager)
-    assert torch.equal(outs["dual+attn"], in_order)             # which workgroup takes which item changes no value
     assert torch.equal(outs["dual+attn"][:, :P], prompt.cpu())
     if B > 224:   # the 64 x 64 kernels at > 224 rows: one K slice, fused epilogues, no shared launch -> the knobs change nothing
         try:
