@@ -206,7 +206,7 @@ int few_rows_attn_res(hipStream_t s, int64_t M, int q_len, int heads, int64_t I,
                       const void* qkv, int64_t ld_qkv, const void* kc, const void* vc, int64_t n_max, int pos0_host,
                       const void* dense_w, const void* dense_b, void* x, int64_t ldx);
 
-// ---- mid-batch (17 .. 256 rows) decoder-layer pieces (gemm.hip), used by bt_decoder_forward (engine.hip) -------------------
+// ---- mid-batch (3 .. 512 rows) decoder-layer pieces (gemm.hip), used by bt_decoder_forward (engine.hip) -------------------
 bool mid_rows_ok(int64_t M, int64_t H, int64_t I, int head_dim, int rot);
 int64_t mid_slab_bytes(int64_t M, int64_t H, int64_t I);
 int mid_qkv(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, const void* x, int64_t ldx, const void* w,

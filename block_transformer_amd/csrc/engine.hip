@@ -121,7 +121,8 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
     const bool few_rows = dtype == BT_BF16 && M <= g_few_rows_max && (M > 4 ? (H % 32 == 0 && I % 32 == 0) : (H % 512 == 0 && H <= 2048)) &&
                           dims->rot == 32 &&
                           dims->head_dim % 32 == 0 && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0) && !g_no_few_rows_fusion;
-    // 3 .. 256 rows (small- / mid-batch decode): split-K slabs + fused reduce kernels -- 4 (token decoder) or 5 launches per layer
+    // 3 .. 512 rows (small- / mid-batch decode; above 256 rows with the 256 x 128 slab kernel only, its slabs in the stream-K scratch):
+    // split-K slabs + fused reduce kernels -- 4 (token decoder) or 5 launches per layer
     // instead of 11, no separate LayerNorm / RoPE / KV-append launch (the step is bound by its count of dependent launches).  Like the few-rows
     // path it runs every layer on every row (the tail-only shortcut is not worth a second launch sequence here).
     const bool mid_rows = dtype == BT_BF16 && !few_rows && mid_rows_ok(M, H, I, dims->head_dim, dims->rot) && scratch &&

@@ -530,7 +530,7 @@ __device__ __forceinline__ void gemm_mfma_body(char* smem, const int tm, const i
 
     if (SPLITK && !(FUSE && gridDim.y == 1)) {  // fp32 partials: lane owns 4 consecutive columns of one row -> one 16-byte store per fragment
         float* slab = partial + (int64_t)blockIdx.y * M * N;
-        // (descriptor-addressed: slab origin of this slice in SGPRs, 32-bit lane offsets -- M <= 256 rows on every split-K path)
+        // (descriptor-addressed: slab origin of this slice in SGPRs, 32-bit lane offsets -- a few MB of slab per slice on every split-K path)
         const __amdgpu_buffer_rsrc_t srs = tile_rsrc(reinterpret_cast<const char*>(slab));
 #pragma unroll
         for (int j = 0; j < FM; ++j) {
@@ -703,7 +703,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     splitk_reduce_body((int64_t)blockIdx.x * 256 + threadIdx.x, partial, slices, ep);
 }
 
-// ---- fused reduce kernels of the mid-batch path (17 .. 256 rows, bt_decoder_forward) ----------------------------------------
+// ---- fused reduce kernels of the mid-batch path (3 .. 512 rows, bt_decoder_forward) ----------------------------------------
 // The split-K GEMM above leaves fp32 slabs [slices][M][N]; these kernels sum them and do everything the layer needs next at
 // that point, so that no separate RoPE / KV-append / LayerNorm launch remains (a 17..256-row decode step is bound by the
 // number of dependent launches, ~5-10 us each, not by bytes or flops).
@@ -3321,10 +3321,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_kernel(const bf16* 
     }
 }
 
-// ---- 256 x 128 tiles cut along K into fp32 slabs: the mid-batch projections at 97 .. 256 rows (round 5) ----------------------------
-// At 97 .. 256 rows the 64 x 64 slab kernel above moves 16 KiB of operands from L2 per 0.5 MFLOP (32 flop per L2 -> LDS byte) and keeps
-// 48 KiB of weights in flight per CU: its QKV and h -> 4h launches take 22 us each at 256 rows (0.29 PF, 1.1-1.5 TB/s of weights;
-// profiles/r4_bench_b256_kernel_stats.md).  This kernel is the one-tile 256 x 128 kernel's tile and wave layout (8 waves = two groups half a
+// ---- 256 x 128 tiles cut along K into fp32 slabs: the mid-batch projections at 97 .. 512 rows (round 5) ----------------------------
+// At 256 rows the 64 x 64 slab kernel above takes 22 us for each of the QKV and h -> 4h launches (0.29 PF, 1.1-1.5 TB/s of weights;
+// profiles/r4_bench_b256_kernel_stats.md) and 30 us for the residual launch; above 256 rows the stack used to fall to the large-M launch
+// sequence, whose 256 x 256 tiles leave most CUs idle at 257 .. 512 rows.  This kernel is the one-tile 256 x 128 kernel's tile and wave layout (8 waves = two groups half a
 // K-tile apart, a wave owns 64 rows of each A half x 32 columns, phase 0 = A0 + W, phase 1 = A1) with what this regime needs:
 //   * the whole stack is ONE row tile (two at 257 .. 512 rows): rows >= M are clamped in the LDS-DMA addresses (their products are never
 //     stored);
@@ -3334,11 +3334,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_kernel(const bf16* 
 //   * up to two problems per launch (the QKV projection and the MLP up-projection of a parallel-residual layer);
 //   * the two operand streams are issued by DIFFERENT waves: group 0 streams A (activations: L2 hits, two K-tiles deep), group 1 streams
 //     W (weights: HBM, every byte used by one workgroup only) TS_WD K-tiles deep with the nt policy.  vmcnt retires in order per wave,
-//     so a wave that issued both could not wait for the next A tile without draining the deep W stream: with the first version's shared
-//     stream (the one-tile kernel's, five half-tiles ahead = 27 KiB of weights in flight per CU) the launches ran at 2.4-3 TB/s of
-//     weights (profiles/r5_bench_b256_kernel_stats_v1_shallow_w_ring.md); the guide's figure for an HBM-rate LDS-DMA stream is an
-//     8 x 16 KiB ring per CU;
-//   * the epilogue = plain 16-byte stores of the fp32 fragments into slab[slice][M][N] -- the format the mid-batch reduce kernels read.
+//     so a wave that issued both could not wait for the next A tile without draining the deep W stream.  Measured against the first
+//     version (the one-tile kernel's shared stream, five half-tiles ahead = 27 KiB of weights in flight per CU): 26.9 -> 25.8 us for the
+//     QKV + h -> 4h launch at 256 rows, 22.0 -> 22.2 us for the residual launch (profiles/r5_bench_b256_kernel_stats_v{1,2}_*.md) -- the
+//     K-loop was not the bound: the two launches differ by 5 K-tiles and 3.6 us, i.e. 0.72 us per K-tile (5 TB/s of weights inside the
+//     loop) on top of ~14 us that do not depend on K (cold start of 224-256 workgroups, 29-34 MB of slab stores, the drain);
+//   * the epilogue = 16-byte write-through stores of the fp32 fragments into slab[slice][M][N] -- the format the mid-batch reduce
+//     kernels read.
 // Synchronisation (t = K-tile, barriers counted per group; group 1 runs one barrier behind group 0, as in the one-tile kernel):
 //   RAW  a wave waits for its own DMAs of a tile before a barrier that precedes every read of it: A0(t) / A1(t) by group 0 before the
 //        barrier that opens its phase 0 / 1 of t; W(t) by group 1 before the barrier that closes its phase 1 of t - 1 (= the one group 0
@@ -5582,7 +5584,7 @@ int few_rows_attn_res(hipStream_t s, int64_t M, int q_len, int heads, int64_t I,
 
 }  // namespace bt
 
-// ---- mid-batch path (17 .. 256 rows): split-K slabs + fused reduces; called by bt_decoder_forward (engine.hip) ------------------
+// ---- mid-batch path (3 .. 512 rows): split-K slabs + fused reduces; called by bt_decoder_forward (engine.hip) ------------------
 namespace bt {
 
 // K-slice length: the largest of {8192 .. 256} that divides both operand pairs' K and still gives every CU a workgroup
@@ -5633,7 +5635,7 @@ int64_t mid_slab_bytes(int64_t M, int64_t H, int64_t I) {
     return worst;
 }
 
-// ---- 97 .. 256 rows: 256 x 128 tiles, K ranges per workgroup (gemm_bf16_mfma256x128_slab_kernel) ----
+// ---- 97 .. 512 rows: 256 x 128 tiles, K ranges per workgroup (gemm_bf16_mfma256x128_slab_kernel) ----
 static bool mid_tall_rows(int64_t M) { return g_mid_tall != 0 && M <= g_mid_rows_max && M > (g_mid_tall >= 2 ? 64 : 96); }
 
 // slices of the (up to two) operand pairs of one problem: about g_mid_tall_wgs workgroups in all, >= 4 K-tiles per slice, the second
@@ -5776,7 +5778,8 @@ int mid_qkv_gelu(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, c
     if (attn_done) *attn_done = false;
     if (!g_mid_dual || g_mid_fuse == 2 || N1 % 64 != 0 || N2 % 64 != 0) return BT_OK;
     const int tiles_m = (int)ceil_div(M, 64), t1 = (int)(N1 / 64), t2 = (int)(N2 / 64);
-    // 97 .. 256 rows: both problems on 256 x 128 tiles, two K ranges each (112 column tiles x 2 = 224 workgroups for the 1.2B layer)
+    // 97 .. 512 rows: both problems on 256 x 128 tiles, two K ranges each up to 256 rows (112 column tiles x 2 = 224 workgroups for the
+    // 1.2B layer), one above (two row tiles)
     const bool tall = mid_tall_rows(M) && N1 % 128 == 0 && N2 % 128 == 0 && tall_operand_ok(x1, H, K) && tall_operand_ok(x2, H, K) &&
                       tall_operand_ok(qkv_w, K, K) && tall_operand_ok(h4_w, K, K);
     int tall_s = 0, unused = 0;
