@@ -73,8 +73,13 @@ def test_two_row_tiles_halve_the_slices():
     assert s == 1
     s1, s2 = tall_slices(2 * 16, 128, 32)
     assert (s1, s2) == (6, 2) and 2 * 16 * (s1 + s2) == 256
-    # slab bytes of the 1.2B layer at 512 rows fit the 64 MiB stream-K scratch the engine's workspace carries above 256 rows
-    assert max(1 * 512 * (6144 + 8192) * 4, (s1 + s2) * 512 * 2048 * 4) + 4096 <= 64 << 20
+    # slab bytes of the 1.2B layer at 512 rows (incl. the 64 x 64 kernels' two-slice worst case mid_slab_bytes also counts) fit the
+    # stream-K scratch the engine's workspace carries above 256 rows -- asked of the library itself (host function, no GPU needed)
+    from block_transformer_amd._lib import lib
+    room = lib().bt_stream_k_scratch_bytes()
+    assert max(2 * 512 * (6144 + 8192) * 4, (s1 + s2) * 512 * 2048 * 4) + 4096 <= room, room
+    assert "return M <= 256 ? 16 * M * (int64_t)d->inter * 4 : sk_scratch_bytes();" in \
+        open(os.path.join(ROOT, "block_transformer_amd", "csrc", "engine.hip")).read()
 
 
 def test_the_1p2b_layer_fills_the_chip():
