@@ -1667,7 +1667,7 @@ def test_decoder_forward_rejects_cache_overflow_before_any_launch(B, q_len):
     assert rc == 0, lib().bt_last_error()
 
 
-@pytest.mark.parametrize("M", [3, 4, 6, 8, 16, 17, 32, 64, 96, 97, 128, 129, 200, 255, 256, 257, 400, 512])
+@pytest.mark.parametrize("M", [3, 4, 6, 8, 16, 17, 32, 64, 97, 128, 200, 255, 256, 257, 400, 512])
 def test_mid_rows_decoder_stack_vs_fp32_oracle(M, dbg_lib):
     """3 .. 256 rows through bt_decoder_forward (round 4: the slab path starts at 3 rows): the split-K slab GEMMs + fused reduces (bias + RoPE + KV append; bias +
     GELU; both residual projections + residual + next-layer LayerNorm pair).  A decode step (q = 1 against a 40-row cache
@@ -1713,8 +1713,7 @@ def test_mid_rows_decoder_stack_vs_fp32_oracle(M, dbg_lib):
         assert (got - want).abs().max().item() <= 3e-2 * want.abs().max().item() + 1e-2
 
 
-@pytest.mark.parametrize("M,mode", [(97, 1), (128, 1), (129, 1), (136, 1), (192, 1), (250, 1), (256, 1), (257, 1), (300, 1), (384, 1),
-                                    (510, 1), (512, 1), (65, 2), (96, 2)])
+@pytest.mark.parametrize("M,mode", [(97, 1), (129, 1), (192, 1), (250, 1), (256, 1), (257, 1), (300, 1), (510, 1), (512, 1), (96, 2)])
 def test_mid_rows_tall_tiles_match_the_64x64_slab_kernels(M, mode, dbg_lib):
     """97 .. 256 rows (round 5): the slab GEMMs of a layer run on 256 x 128 tiles with a K RANGE per workgroup
     (gemm_bf16_mfma256x128_slab_kernel: rows >= M clamped in the DMA addresses, unequal slices, two problems per launch, two operand
