@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbt_hip.s
 DEBUG_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libbt_hip_dbg.so")
 
 BT_F32, BT_BF16 = 0, 1
-BT_DEV_ERR_CACHE_FULL, BT_DEV_ERR_BLOCK_RANGE = 1, 2
+BT_DEV_ERR_CACHE_FULL, BT_DEV_ERR_BLOCK_RANGE, BT_DEV_ERR_HANDOFF_TIMEOUT = 1, 2, 4
 BT_ACT_NONE, BT_ACT_GELU = 0, 1
 ATTN_ROWS, ATTN_FLASH = 0, 1
 
@@ -69,7 +69,7 @@ class bt_attn_args(Structure):
                 ("pos0_dev", c_void_p), ("pos0_host", c_int32), ("pos_table", c_void_p), ("mask", c_void_p),
                 ("mask_ld", c_int64), ("cos_tab", c_void_p), ("sin_tab", c_void_p), ("mode", c_int32),
                 ("n_split", c_int32), ("split_ws", c_void_p), ("split_ws_bytes", c_int64), ("seq_skip", c_void_p),
-                ("aux_stream", c_void_p), ("ev_fork", c_void_p), ("ev_join", c_void_p)]
+                ("aux_stream", c_void_p), ("ev_fork", c_void_p), ("ev_join", c_void_p), ("err_flag", c_void_p)]
 
     def __init__(self, *args, **kw):
         super().__init__(ctypes.sizeof(type(self)), *args, **kw)    # struct_size first; positional fields follow as before
@@ -97,6 +97,8 @@ _SIGS = {
     "bt_linear2": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                            c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "bt_stream_k_scratch_bytes": (c_int64, []),
+    "bt_stream_k_reset": (c_int, [c_void_p, c_int64, c_void_p]),
+    "bt_stream_k_status": (c_int, [c_void_p, c_int64, c_void_p, c_void_p]),
     "bt_linear2_ws": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_void_p, c_int64,
                               c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]),
     "bt_ln_qkv_rope_append": (c_int, [c_int, c_int64, c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_void_p,
@@ -178,6 +180,7 @@ _DEBUG_SIGS = {
     "bt_debug_linear_lnfold": (c_int, [c_int, c_int64, c_int64, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_int64, c_int, c_void_p]),
     "bt_debug_stream_k": (None, [c_int]),
+    "bt_debug_stream_k_drop": (None, [c_int, c_int]),
     "bt_debug_no_two_branch": (None, [c_int]),
     "bt_debug_ln_streaming": (None, [c_int]),
     "bt_debug_tr_probe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),

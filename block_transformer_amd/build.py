@@ -25,6 +25,7 @@ LIB = os.path.join(HERE, "libbt_hip.so")
 LIB_DBG = os.path.join(HERE, "libbt_hip_dbg.so")
 SOURCES = ["core.hip", "gemm.hip", "norm.hip", "misc.hip", "attention.hip", "engine.hip"]
 HEADERS = [os.path.join(CSRC, "bt_common.h"), os.path.join(os.path.dirname(HERE), "include", "bt_hip.h")]
+EXPORTS = os.path.join(CSRC, "exports.map")   # linker version script: bt_* global, everything else local
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
@@ -69,8 +70,8 @@ def build(force: bool = False, verbose: bool = True, debug: bool = True) -> str:
         list(ex.map(compile_one, jobs))
     for suffix, _, lib in flavours:
         objs = [os.path.join(BUILD, s.replace(".hip", suffix + ".o")) for s in SOURCES]
-        if force or jobs or _stale(lib, objs):
-            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
+        if force or jobs or _stale(lib, objs + [EXPORTS]):
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", f"-Wl,--version-script={EXPORTS}", "-o", lib] + objs
             r = subprocess.run(cmd, capture_output=True, text=True)
             if r.returncode != 0:
                 raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

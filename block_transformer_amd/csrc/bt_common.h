@@ -209,6 +209,7 @@ int few_rows_attn_res(hipStream_t s, int64_t M, int q_len, int heads, int64_t I,
 // ---- mid-batch (3 .. 512 rows) decoder-layer pieces (gemm.hip), used by bt_decoder_forward (engine.hip) -------------------
 bool mid_rows_ok(int64_t M, int64_t H, int64_t I, int head_dim, int rot);
 int64_t mid_slab_bytes(int64_t M, int64_t H, int64_t I);
+bool mid_tall_layer_ok(int64_t H, int64_t I, const void* qkv_w, const void* h4_w, const void* h_w, const void* dense_w);   // > 256 rows
 int mid_qkv(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, const void* x, int64_t ldx, const void* w,
             const void* bias, void* qkv, int64_t ld_qkv, void* kc, void* vc, int64_t n_max, const int32_t* pos0_dev, int pos0_host,
             const int32_t* pos_table, const float* cos_tab, const float* sin_tab, void* slabs, int64_t slab_bytes, int* counters);
@@ -229,7 +230,9 @@ int mid_res_ln(hipStream_t s, int64_t M, int64_t N, int64_t K1, const void* x1, 
 // may dispatch to it (`sk_clean`: the flag words of `scratch` are known to be zero -- bt_decoder_forward clears them once per pass)
 int64_t sk_scratch_bytes();
 bool sk_linear2_ok(int64_t M, int64_t N, int64_t K1, int64_t K2, int64_t scratch_bytes);
-int sk_clear_flags(void* scratch, int64_t scratch_bytes, hipStream_t s);
+int sk_clear_flags(void* scratch, int64_t scratch_bytes, hipStream_t s);                              // hand-off flags only (per launch)
+int sk_reset(void* scratch, int64_t scratch_bytes, hipStream_t s);                                    // flags + sticky time-out word
+int sk_status(const void* scratch, int64_t scratch_bytes, int32_t* err_flag, hipStream_t s);          // sticky word -> BT_DEV_ERR_HANDOFF_TIMEOUT
 int linear_ws_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A, int64_t lda, const void* W, const void* bias,
                    const void* residual, int64_t ldr, void* out, int64_t ldo, int act, void* scratch, int64_t scratch_bytes,
                    bool sk_clean, bt_stream stream);

@@ -58,15 +58,17 @@ static constexpr int g_lin2_sk = 2;
 static int64_t ws_elems(const bt_decoder_dims* d, int64_t M) {
     return M * ((int64_t)d->hidden * 5 + d->inter);
 }
-// GEMM scratch: split-K slabs for skinny GEMMs (M <= 256 rows: up to 16 fp32 partial slabs of [M, inter]); above that the
-// stream-K kernel's hand-off slabs + flag words (one 256 KiB slab per CU: 64 MiB on MI355X)
-static int64_t splitk_bytes(const bt_decoder_dims* d, int64_t M) {
-    return M <= 256 ? 16 * M * (int64_t)d->inter * 4 : sk_scratch_bytes();
+// GEMM scratch: split-K slabs for skinny GEMMs (M <= 256 rows: up to 16 fp32 partial slabs of [M, inter]); above that, for bf16 (the
+// only dtype with those kernels), the stream-K kernel's hand-off slabs + flag words (one 256 KiB slab per CU: 64 MiB on MI355X; the
+// 257 ... 512-row slab GEMMs of the mid-batch path live in the same region) -- fp32 stacks above 256 rows get none
+static int64_t splitk_bytes(const bt_decoder_dims* d, int dtype, int64_t M) {
+    if (M <= 256) return 16 * M * (int64_t)d->inter * 4;
+    return dtype == BT_BF16 ? sk_scratch_bytes() : 0;
 }
 
 extern "C" int64_t bt_decoder_workspace_bytes(const bt_decoder_dims* dims, int dtype, int64_t M) {
     if (!dims || M < 0) return -1;
-    return ws_elems(dims, M) * (int64_t)dtype_size(dtype) + splitk_bytes(dims, M) + 512;
+    return ws_elems(dims, M) * (int64_t)dtype_size(dtype) + splitk_bytes(dims, dtype, M) + 512;
 }
 
 extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const bt_decoder_weights* w, int64_t B,
@@ -107,7 +109,7 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
     void* h4 = p + 5 * M * H * es;
     void* att = ln1;
     char* sk = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(p + ws_elems(dims, M) * es) + 255u) & ~(uintptr_t)255u);
-    int64_t sk_bytes = splitk_bytes(dims, M);
+    int64_t sk_bytes = splitk_bytes(dims, dtype, M);
     if (sk_bytes && (sk + sk_bytes) > (reinterpret_cast<char*>(ws) + ws_bytes)) sk_bytes = 0;
     void* scratch = sk_bytes ? sk : nullptr;
 
@@ -125,10 +127,17 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
     // split-K slabs + fused reduce kernels -- 4 (token decoder) or 5 launches per layer
     // instead of 11, no separate LayerNorm / RoPE / KV-append launch (the step is bound by its count of dependent launches).  Like the few-rows
     // path it runs every layer on every row (the tail-only shortcut is not worth a second launch sequence here).
-    const bool mid_rows = dtype == BT_BF16 && !few_rows && mid_rows_ok(M, H, I, dims->head_dim, dims->rot) && scratch &&
-                          mid_slab_bytes(M, H, I) >= 0 && mid_slab_bytes(M, H, I) + MID_COUNTER_BYTES <= sk_bytes &&
-                          ceil_div(M, 64) * ceil_div(std::max(3 * H, I), 64) * 4 <= MID_COUNTER_BYTES &&
-                          ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+    bool mid_rows = dtype == BT_BF16 && !few_rows && mid_rows_ok(M, H, I, dims->head_dim, dims->rot) && scratch &&
+                    mid_slab_bytes(M, H, I) >= 0 && mid_slab_bytes(M, H, I) + MID_COUNTER_BYTES <= sk_bytes &&
+                    ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+    if (mid_rows && M <= 256) {   // tile counters of the in-launch reductions (64 x 64 kernels; the dual launch counts both problems' tiles)
+        mid_rows = ceil_div(M, 64) * (ceil_div(3 * H, 64) + ceil_div(I, 64)) * 4 <= MID_COUNTER_BYTES;
+    } else if (mid_rows) {        // 257 .. 512 rows: every layer must take the 256 x 128 slab kernel (no counters), or none does
+        for (int l = 0; l < dims->layers && mid_rows; ++l) {
+            const bt_layer_weights& lw = w->layers_host[l];
+            mid_rows = mid_tall_layer_ok(H, I, lw.qkv_w, lw.h4_w, lw.h_w, lw.dense_w);
+        }
+    }
     if (mid_rows) {
         hipStream_t hs = (hipStream_t)stream;
         // tile counters of the in-launch split-K reductions: the last 4 KiB of the scratch region, cleared once per pass (each
@@ -171,10 +180,12 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
                               more ? nx.ln2_b : nullptr, ln2, H, dims->ln_eps, scratch, slab_room));
         }
     }
-    // stream-K hand-off flags of the large-M GEMMs (QKV at M = 4096: 1.5 rounds of tiles; the fused residual projections): cleared
-    // once per pass, the kernels leave them zero -> the layers below pass sk_clean = true (no memset in front of every launch)
+    // stream-K hand-off flags of the large-M GEMMs (the fused residual projections; QKV shapes whose tile count the persistent kernel
+    // refuses): flags + the sticky time-out word zeroed once per pass, the kernels leave the flags zero -> the layers below pass
+    // sk_clean = true (no memset in front of every launch); the sticky word is reported at the end of THIS pass (sk_status below), so
+    // the next pass's reset cannot erase an unread time-out
     const bool sk_ws = !mid_rows && !few_rows && dtype == BT_BF16 && M > 256 && scratch && sk_bytes >= sk_scratch_bytes();
-    if (sk_ws) BT_TRY(sk_clear_flags(scratch, sk_bytes, (hipStream_t)stream));
+    if (sk_ws) BT_TRY(sk_reset(scratch, sk_bytes, (hipStream_t)stream));
     for (int l = 0; l < dims->layers && !mid_rows; ++l) {
         const bt_layer_weights& lw = w->layers_host[l];
         char* kc = reinterpret_cast<char*>(attn->k_cache) + (int64_t)l * attn->layer_stride * es;
@@ -348,6 +359,8 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
                                 BT_ACT_NONE, scratch, sk_bytes, stream));
         }
     }
+    // a consumer of a stream-K hand-off that gave up waiting -> BT_DEV_ERR_HANDOFF_TIMEOUT in the caller's sticky error word
+    if (sk_ws && attn->err_flag) BT_TRY(sk_status(scratch, sk_bytes, attn->err_flag, (hipStream_t)stream));
     // final_layer_norm of the rows the caller consumes
     const int count = q_len - first_out_row;
     if (first_out_row == 0) {
@@ -415,6 +428,7 @@ static bt_attn_args local_attn(const bt_engine_desc* e, int32_t pos0) {
     a.aux_stream = e->aux_stream;
     a.ev_fork = e->ev_fork;
     a.ev_join = e->ev_join;
+    a.err_flag = e->err_flag;
     return a;
 }
 
@@ -492,6 +506,7 @@ extern "C" int bt_roll_over_enqueue(const bt_engine_desc* e, bt_stream stream) {
     a.aux_stream = e->aux_stream;
     a.ev_fork = e->ev_fork;
     a.ev_join = e->ev_join;
+    a.err_flag = e->err_flag;
     BT_TRY(bt_decoder_forward(e->dtype, &e->bd_dims, &e->bd_w, B, 1, e->x_blk, &a, 0, e->ctx, e->ws_step, e->ws_step_bytes,
                               stream));
     return bt_bump(e->n_cur, 1, stream);
@@ -536,6 +551,7 @@ extern "C" int bt_prefill_enqueue(const bt_engine_desc* e, const int64_t* block_
     a.aux_stream = e->aux_stream;
     a.ev_fork = e->ev_fork;
     a.ev_join = e->ev_join;
+    a.err_flag = e->err_flag;
     return bt_decoder_forward(e->dtype, &e->bd_dims, &e->bd_w, nseq, nb, x, &a, nb - 1,
                               reinterpret_cast<char*>(e->ctx) + b0 * Hbd * es, ws, ws_bytes, stream);
 }

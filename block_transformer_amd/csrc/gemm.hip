@@ -2746,10 +2746,14 @@ struct SkArgs {
     int q;               // items per workgroup
     int nk;              // K-tiles per item (>= 4)
     float* slabs;        // [G][8 waves][32][64 lanes][4] fp32: slab vw = partial tile of virtual workgroup vw's consume chain
-    uint32_t* flags;     // [G][8] one word per (consumer workgroup, wave), zero at launch and left zero; + [8 G] sticky timeout word
+    uint32_t* flags;     // [G][8] one word per (consumer workgroup, wave), zero at launch and left zero; word [8 G] = STICKY time-out word
+                         // (SK_TIMEOUT_MAGIC once any consumer gave up; cleared by sk_reset only, never by the per-launch sk_clear_flags)
+    int dbg_drop_vw;     // debug build: the publishing workgroup with this virtual id never raises its flags (-1: none) -> its consumer
+    uint32_t dbg_spin;   //              times out after dbg_spin polls (0: SK_SPIN_LIMIT); the product build ignores both
 };
 constexpr int SK_SLAB_FLOATS = 8 * 32 * 64 * 4;          // 256 KiB per workgroup
 constexpr uint32_t SK_SPIN_LIMIT = 1u << 20;              // polls (x ~1 us) before a consumer gives up and flags the launch
+constexpr uint32_t SK_TIMEOUT_MAGIC = 0x534b544fu;        // "SKTO": value of the sticky word after a time-out
 
 // flag words of the hand-off (wave-uniform addresses): relaxed agent-scope accesses = `sc1` loads / stores (CDNA guide, visibility
 // table).  Inline asm with its own zero offset register: the compiler's form kept that zero in a VGPR across the K-loop, spilled it,
@@ -3071,20 +3075,34 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256sk_kernel(const bf16* __
                                                            srs, svoff, (uint32_t)((i * P::NB + nb) * 1024), 16 /* sc1: write-through */);
                 }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every store of this wave has left the CU (and the loads issued before them)
+#ifdef BT_DEBUG_HOOKS
+            if (vw == sk.dbg_drop_vw) continue;                // test hook: a producer that never arrives
+#endif
             sk_flag_store(sk.flags + (int64_t)(vw + 1) * 8 + wave, 1u);
             continue;
         }
         if (consume) {
             uint32_t* flag = sk.flags + (int64_t)vw * 8 + wave;
             uint32_t seen = 0;
-            for (uint32_t spins = 0; spins < SK_SPIN_LIMIT; ++spins) {
+#ifdef BT_DEBUG_HOOKS
+            const uint32_t spin_limit = sk.dbg_spin ? sk.dbg_spin : SK_SPIN_LIMIT;
+#else
+            constexpr uint32_t spin_limit = SK_SPIN_LIMIT;
+#endif
+            for (uint32_t spins = 0; spins < spin_limit; ++spins) {
                 seen = sk_flag_load(flag);
                 if (seen != 0) break;
                 __builtin_amdgcn_s_sleep(8);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            if (seen == 0)    // the producer never arrived (cannot happen with G resident workgroups): flag the launch, go on
-                sk_flag_store(sk.flags + (int64_t)G * 8, 1u);
+            if (seen == 0) {
+                // The producer never arrived.  All G workgroups are resident when the launch has the GPU to itself, so this takes
+                // another process's kernels, a profiler or a hung partner.  The slab is NOT added (its bytes are undefined): the tile
+                // is left incomplete and the launch is flagged through the sticky word, which only sk_reset clears; bt_decoder_forward /
+                // bt_stream_k_status turn it into BT_DEV_ERR_HANDOFF_TIMEOUT and the host discards the pass.  The flag word stays as
+                // it is -- a producer that arrives late leaves it at 1, and whoever runs next on this scratch starts from sk_reset.
+                sk_flag_store(sk.flags + (int64_t)G * 8, SK_TIMEOUT_MAGIC);
+            } else {
             const float* slab = sk.slabs + ((int64_t)vw * 8 + wave) * (32 * 64 * 4);
             const __amdgpu_buffer_rsrc_t srs = tile_rsrc(reinterpret_cast<const char*>(slab));
             uint32_t svoff = (uint32_t)lane * 16u;
@@ -3111,6 +3129,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256sk_kernel(const bf16* __
                 asm volatile("" : "+v"(svoff) : "v"(acc[h * P::MI + P::MI - 1][P::NB - 1][3]) : "memory");
             }
             sk_flag_store(flag, 0u);   // ready for the next launch
+            }
         }
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
@@ -4552,6 +4571,8 @@ BT_KNOB int g_small_stages = 0;   // LDS ring depth of the 128^2 / 128x64 / 64x6
 // stream-K items kernel (gemm_bf16_mfma256sk_kernel, round 5) for full-tile problems whose 256 x 256 tiles leave the persistent
 // kernel's last round under 90 % full, and for bt_linear2 above 256 rows: 1 = on (needs the caller's scratch: slabs + flags), 0 = A/B
 BT_KNOB int g_sk = 1;
+BT_KNOB int g_sk_drop_vw = -1;    // debug build (bt_debug_stream_k_drop): this publishing workgroup never raises its flags ...
+BT_KNOB int g_sk_spin = 0;        // ... and consumers give up after this many polls (0: SK_SPIN_LIMIT) -> the time-out path under test
 BT_KNOB int g_gemm_variant = 0;   // 0 auto; 1 force 128^2; 2/3 256^2 four-phase ring (plain/staggered); 4-8 timing ablations; 9/10 256^2
 // two-phase ring, one tile per workgroup (staggered/plain); 14 persistent on 32x32x16 MFMA; default: persistent two-phase ring.
 
@@ -4606,22 +4627,53 @@ static SkPlan sk_plan(int64_t M, int64_t N, int64_t K1, int64_t K2, int G) {
 }
 static int64_t sk_ws_bytes(int G) { return (int64_t)G * SK_SLAB_FLOATS * 4 + ((int64_t)G * 8 + 8) * 4; }
 namespace bt {
-// scratch layout of the stream-K kernel: [G slabs of 256 KiB][G * 8 + 1 flag words]; bt_decoder_forward sizes its scratch for it
-// (engine.hip) and clears the flag words once per pass with sk_clear_flags(); the kernels leave them zero
+// scratch layout of the stream-K kernel: [G slabs of 256 KiB][G * 8 flag words][sticky time-out word + 7 spare]; bt_decoder_forward
+// sizes its scratch for it (engine.hip), zeroes flags + sticky word once per pass with sk_reset() and reports the sticky word at the end
+// of the pass with sk_status(); the kernels leave the flag words zero
 int64_t sk_scratch_bytes() { return sk_ws_bytes(num_cus()); }
 // does bt_linear2 (M rows, N outputs, operand pairs of K1 and K2) run as ONE stream-K GEMM with this much scratch?
 bool sk_linear2_ok(int64_t M, int64_t N, int64_t K1, int64_t K2, int64_t scratch_bytes) {
     const int G = num_cus();
     return g_sk != 0 && M > 256 && scratch_bytes >= sk_ws_bytes(G) && sk_plan(M, N, K1, K2, G).ok;
 }
+// per launch (callers without sk_clean): the G * 8 hand-off flags only -- an unread time-out (the sticky word behind them) survives
 int sk_clear_flags(void* scratch, int64_t scratch_bytes, hipStream_t s) {
     const int G = num_cus();
     if (!scratch || scratch_bytes < sk_ws_bytes(G)) return BT_OK;
-    hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(scratch) + (int64_t)G * SK_SLAB_FLOATS * 4, 0, ((size_t)G * 8 + 8) * 4, s);
+    hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(scratch) + (int64_t)G * SK_SLAB_FLOATS * 4, 0, (size_t)G * 8 * 4, s);
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(stream-K flags)");
     return BT_OK;
 }
+// flags AND the sticky word: a fresh scratch (undefined bytes), the start of a bt_decoder_forward pass (which reports the word itself
+// at its end), or the caller's acknowledgement of a reported time-out
+int sk_reset(void* scratch, int64_t scratch_bytes, hipStream_t s) {
+    const int G = num_cus();
+    if (!scratch || scratch_bytes < sk_ws_bytes(G)) return BT_OK;
+    hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(scratch) + (int64_t)G * SK_SLAB_FLOATS * 4, 0, ((size_t)G * 8 + 8) * 4, s);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(stream-K flags + sticky word)");
+    return BT_OK;
+}
+__global__ void sk_status_kernel(const uint32_t* sticky, int32_t* err_flag) {
+    if (*sticky != 0) atomicOr(err_flag, (int32_t)BT_DEV_ERR_HANDOFF_TIMEOUT);
+}
+int sk_status(const void* scratch, int64_t scratch_bytes, int32_t* err_flag, hipStream_t s) {
+    const int G = num_cus();
+    if (!scratch || !err_flag || scratch_bytes < sk_ws_bytes(G)) return BT_OK;
+    const uint32_t* sticky = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(scratch) + (int64_t)G * SK_SLAB_FLOATS * 4) + (int64_t)G * 8;
+    hipLaunchKernelGGL(sk_status_kernel, dim3(1), dim3(1), 0, s, sticky, err_flag);
+    BT_LAUNCH_CHECK("stream-K status launch");
+    return BT_OK;
+}
 }  // namespace bt
+
+extern "C" int bt_stream_k_reset(void* scratch, int64_t scratch_bytes, bt_stream stream) {
+    BT_CHECK_ARG(scratch_bytes >= 0 && (scratch || scratch_bytes == 0), "bt_stream_k_reset: bad scratch");
+    return bt::sk_reset(scratch, scratch_bytes, (hipStream_t)stream);
+}
+extern "C" int bt_stream_k_status(const void* scratch, int64_t scratch_bytes, int32_t* err_flag, bt_stream stream) {
+    BT_CHECK_ARG(scratch_bytes >= 0 && (scratch || scratch_bytes == 0) && err_flag, "bt_stream_k_status: null pointer");
+    return bt::sk_status(scratch, scratch_bytes, err_flag, (hipStream_t)stream);
+}
 
 // amax (bt_logits_argmax): when the persistent kernel takes the problem, run its PP_ARGMAX epilogue (per-slab argmax partials
 // into amax[M][amax_ld]; the logits tile is stored only if store_out) and report it through *amax_done
@@ -4726,6 +4778,8 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                 sk.nk = pl.nk;
                 sk.slabs = reinterpret_cast<float*>(scratch);
                 sk.flags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(scratch) + (int64_t)G * SK_SLAB_FLOATS * 4);
+                sk.dbg_drop_vw = g_sk_drop_vw;
+                sk.dbg_spin = (uint32_t)g_sk_spin;
                 if (!sk_clean) BT_TRY(bt::sk_clear_flags(scratch, scratch_bytes, s));
                 const int tiles_m = (int)(M / BM2), tiles_n = (int)(N / BN2);
 #define BT_LAUNCH_SK(MODE_)                                                                                                  \
@@ -4987,8 +5041,11 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
             const int tiles_m = (int)ceil_div(M, 64), tiles_n = (int)ceil_div(N, 64);
             const int nk = (int)(K / BK);
             int slices = 1;
+            // a scratch of the stream-K size carries that kernel's flag words behind its slabs: the partials stay in front of them
+            // (a later sk_clean launch of the same pass assumes the words are zero -- ADVICE r5)
+            const int64_t room = scratch_bytes >= sk_ws_bytes(num_cus()) ? (int64_t)num_cus() * SK_SLAB_FLOATS * 4 : scratch_bytes;
             while (slices < 16 && tiles_m * tiles_n * slices < 256 && nk % (slices * 2) == 0 && nk / (slices * 2) >= 2 &&
-                   (int64_t)(slices * 2) * M * N * 4 <= scratch_bytes)
+                   (int64_t)(slices * 2) * M * N * 4 <= room)
                 slices *= 2;
             if (slices > 1) {
                 if (g_small_stages == 2)
@@ -5658,6 +5715,15 @@ static bool tall_operand_ok(const void* x, int64_t ld, int64_t K) {
     return x && aligned16(x) && ld % 8 == 0 && K % 64 == 0 && K >= 256 && ld * 2 * 512 < ((int64_t)1 << 31);
 }
 
+// 257 .. 512 rows are on the mid-batch path ONLY with the 256 x 128 slab kernel (the 64 x 64 slab kernels lose to the large-M launch
+// sequence there, and their dual launch would need more tile counters than MID_COUNTER_BYTES holds): the per-call `tall` predicates of
+// mid_qkv_gelu / mid_res_ln restated for one layer's weights, so that bt_decoder_forward decides ONCE, before the first launch, and a
+// stack whose weights fail them (an unaligned view, a row pitch beyond the 32-bit lane offsets) takes the large-M sequence
+bool mid_tall_layer_ok(int64_t H, int64_t I, const void* qkv_w, const void* h4_w, const void* h_w, const void* dense_w) {
+    return H % 128 == 0 && I % 128 == 0 && (3 * H) % 128 == 0 && tall_operand_ok(qkv_w, H, H) && tall_operand_ok(h4_w, H, H) &&
+           tall_operand_ok(h_w, I, I) && tall_operand_ok(dense_w, H, H);
+}
+
 static int tall_launch(hipStream_t s, int64_t M, const TallSide& g0, const TallSide* g1) {
     TallArgs ta{};
     ta.g[0] = g0;
@@ -5943,6 +6009,7 @@ int mid_res_ln(hipStream_t s, int64_t M, int64_t N, int64_t K1, const void* x1, 
 extern "C" void bt_debug_force_generic_gemm(int on) { g_force_generic = on != 0; }
 extern "C" void bt_debug_gemm_variant(int v) { g_gemm_variant = v; }
 extern "C" void bt_debug_stream_k(int on) { g_sk = on; }
+extern "C" void bt_debug_stream_k_drop(int vw, int spin) { g_sk_drop_vw = vw; g_sk_spin = spin; }
 extern "C" void bt_debug_gemm_max_wg(int n) { g_max_wg = n; }
 extern "C" void bt_debug_skinny_rows(int n) { g_skinny_rows = n; }
 extern "C" void bt_debug_small_stages(int n) { g_small_stages = n; }

@@ -513,7 +513,10 @@ class DecodeEngine:
             with torch.inference_mode():
                 self.err_flag.zero_()
             what = [n for b, n in ((_lib.BT_DEV_ERR_CACHE_FULL, "global KV cache full (roll-over past g_nmax)"),
-                                   (_lib.BT_DEV_ERR_BLOCK_RANGE, "block index past out_ids / mask")) if bits & b]
+                                   (_lib.BT_DEV_ERR_BLOCK_RANGE, "block index past out_ids / mask"),
+                                   (_lib.BT_DEV_ERR_HANDOFF_TIMEOUT, "a stream-K GEMM hand-off timed out (the GPU is shared with another "
+                                                                     "process or a profiler?): activations incomplete, tokens discarded"))
+                    if bits & b]
             raise _lib.BtError("device-side guard tripped: " + ", ".join(what))
 
     # ---- compaction of finished sequences --------------------------------------------------------------------------------

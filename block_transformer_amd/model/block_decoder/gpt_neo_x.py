@@ -82,6 +82,7 @@ class GPTNeoXBlockDecoder(nn.Module, BaseBlockDecoder):
             x = inputs_embeds[b0:b1].reshape((b1 - b0) * q, H).clone()  # residual stream is updated in place
             rt.forward(x, q, cache, b0=b0, pos0=pos0, mask=None if mask is None else mask[b0:b1], mode=mode,
                        out=out[b0:b1].view(-1, H))
+        rt.check_errors()
         cache.length = n_total
         return CausalLMOutputWithPast(loss=None, logits=None, past_key_values=cache, hidden_states=out,
                                       attentions=None)

@@ -158,6 +158,7 @@ class GPTNeoXTokenDecoder(nn.Module, BaseTokenDecoder):
         hidden = self._rt.forward(x.view(bs * q, H), q, cache, pos0=past_len, pos_table=pos_table,
                                   mask=key_mask.contiguous(), first_out_row=first_out,
                                   rope=self._rt.rope(max(table) + 1))
+        self._rt.check_errors()
         cache.length = n_total
         n_out = q - first_out
         logits = self.compute_logits(hidden).view(bs, n_out, cfg.vocab_size)

@@ -51,8 +51,21 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 
 def stream_k_scratch(device) -> torch.Tensor:
     """Scratch for the stream-K GEMM path of bt_linear_ws / bt_qkv_rope_append / bt_linear2_ws (hand-off slabs + flag words; the
-    entry points clear the flag words themselves)."""
-    return torch.empty(int(lib().bt_stream_k_scratch_bytes()), dtype=torch.uint8, device=device)
+    entry points clear the flag words themselves, the sticky time-out word behind them is zeroed here and read by
+    ``stream_k_check``)."""
+    scratch = torch.empty(int(lib().bt_stream_k_scratch_bytes()), dtype=torch.uint8, device=device)
+    check(lib().bt_stream_k_reset(ptr(scratch), scratch.numel(), current_stream()), "bt_stream_k_reset")
+    return scratch
+
+
+def stream_k_check(scratch: torch.Tensor) -> None:
+    """Raise if a stream-K launch on ``scratch`` flagged a hand-off time-out since the last reset (synchronises)."""
+    err = torch.zeros(1, dtype=torch.int32, device=scratch.device)
+    check(lib().bt_stream_k_status(ptr(scratch), scratch.numel() * scratch.element_size(), ptr(err), current_stream()),
+          "bt_stream_k_status")
+    if int(err.item()) & _lib.BT_DEV_ERR_HANDOFF_TIMEOUT:
+        check(lib().bt_stream_k_reset(ptr(scratch), scratch.numel() * scratch.element_size(), current_stream()), "bt_stream_k_reset")
+        raise _lib.BtError("stream-K GEMM hand-off timed out: the results of the launches on this scratch are incomplete")
 
 
 def linear2(x1: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, x2: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor,

@@ -104,6 +104,8 @@ class DecoderRuntime:
         self._layers = None
         self._weights = None
         self._tables = {}
+        self._err = {}            # device -> int32[1]: sticky BT_DEV_ERR_* bits of the passes run through forward() (check_errors)
+        self._err_armed = False
         # per layer (qkv_wf, qkv_s, qkv_c, h4_wf, h4_s, h4_c): LayerNorm folded into its consumers -- a round-5 experiment that measured
         # no net gain (profiles/r5_ab_ln_fused.jsonl): built only on request AND with the debug library active (tests, A/B); the
         # product library ignores the fields
@@ -222,11 +224,32 @@ class DecoderRuntime:
                             cache.n_max, ptr(pos0_dev), int(pos0), ptr(pos_table), ptr(mask),
                             0 if mask is None else mask.stride(0), rope[0].data_ptr(), rope[1].data_ptr(), int(mode),
                             int(n_split), ptr(split_ws), 0 if split_ws is None else split_ws.numel() * split_ws.element_size())
+        if M > 256 and x.dtype == torch.bfloat16:   # the pass may run stream-K GEMMs: give their hand-off a place to report a time-out
+            err = self._err.get(x.device)
+            if err is None:
+                err = self._err[x.device] = torch.zeros(1, dtype=torch.int32, device=x.device)
+            args.err_flag = err.data_ptr()
+            self._err_armed = True
         w = self.weights()
         check(lib().bt_decoder_forward(dtype_code(x.dtype), ctypes.byref(self.dims), ctypes.byref(w), B, q_len, ptr(x),
                                        ctypes.byref(args), first_out_row, ptr(out), ptr(ws), ws.numel(),
                                        current_stream()), "bt_decoder_forward")
         return out
+
+
+    def check_errors(self) -> None:
+        """Raise if a pass since the last check set a sticky device-side error bit (bt_attn_args.err_flag): today a stream-K GEMM
+        hand-off time-out, after which the activations of that pass are incomplete.  Synchronises; the module-level ``forward``s
+        call it once per call, only when a pass that could set the bit ran."""
+        if not self._err_armed:
+            return
+        self._err_armed = False
+        for err in self._err.values():
+            bits = int(err.item())
+            if bits:
+                err.zero_()
+                raise _lib.BtError(f"device-side guard tripped (bits {bits}): a stream-K GEMM hand-off timed out -- the GPU is "
+                                   "shared with another process or a profiler? -- the outputs of this call are incomplete")
 
 
 class Graph:

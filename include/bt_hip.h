@@ -38,9 +38,11 @@
 extern "C" {
 #endif
 
-#define BT_VERSION 300 /* 0.3.0: bt_attn_args / bt_engine_desc start with struct_size (NOT binary compatible with 0.2.x: a binder
+#define BT_VERSION 310 /* 0.3.0: bt_attn_args / bt_engine_desc start with struct_size (NOT binary compatible with 0.2.x: a binder
                           * compiled against an older header is rejected by the size check instead of having fields read past the
-                          * end of its struct); stream-K GEMM path (bt_linear2_ws, bt_stream_k_scratch_bytes); bt_ceiling_* */
+                          * end of its struct); stream-K GEMM path (bt_linear2_ws, bt_stream_k_scratch_bytes); bt_ceiling_*
+                          * 0.3.1: bt_attn_args.err_flag (the struct grew: the size check rejects 0.3.0 binders), BT_DEV_ERR_HANDOFF_TIMEOUT,
+                          * bt_stream_k_reset / bt_stream_k_status; the shared object exports bt_* symbols only */
 
 typedef void* bt_stream; /* hipStream_t */
 
@@ -175,6 +177,19 @@ int bt_linear2(int dtype, int64_t M, int64_t N, int64_t K1, const void* x1, int6
  * scratch when their 256 x 256 tiles do not fill whole rounds of CUs (M = 4096 QKV: 384 tiles).  Results are not bit-identical to
  * the two-launch form (one bf16 rounding of the sum instead of two, fp32 summation split at the hand-off). */
 int64_t bt_stream_k_scratch_bytes(void);
+/* The hand-off of the stream-K path cannot deadlock, but it CAN time out: the workgroup that finishes a shared tile polls its
+ * partner's flag a bounded number of times (~1 s) -- every workgroup of the launch is resident on an otherwise idle GPU, not
+ * necessarily beside another process's kernels.  A consumer that gives up does NOT add the (unwritten) slab: it sets a sticky
+ * word inside `scratch`, and the results of that launch are incomplete.  The sticky word survives the per-launch clearing of the
+ * flag words; it is how a caller of bt_linear_ws / bt_linear2_ws / bt_qkv_rope_append learns about it:
+ *   bt_stream_k_reset   zero the flag words AND the sticky word (once after allocating `scratch`, whose bytes are otherwise
+ *                       undefined, and to acknowledge a reported time-out);
+ *   bt_stream_k_status  enqueue a one-thread kernel that ORs BT_DEV_ERR_HANDOFF_TIMEOUT into *err_flag (device int32) when the
+ *                       sticky word of `scratch` is set; the host reads *err_flag whenever it synchronises anyway.
+ * bt_decoder_forward does both itself around every pass that may take the path (bt_attn_args.err_flag), and so do the
+ * bt_*_enqueue entry points (bt_engine_desc.err_flag).  A scratch smaller than bt_stream_k_scratch_bytes() is ignored (BT_OK). */
+int bt_stream_k_reset(void* scratch, int64_t scratch_bytes, bt_stream stream);
+int bt_stream_k_status(const void* scratch, int64_t scratch_bytes, int32_t* err_flag, bt_stream stream);
 int bt_linear2_ws(int dtype, int64_t M, int64_t N, int64_t K1, const void* x1, int64_t ldx1, const void* W1, const void* bias1,
                   int64_t K2, const void* x2, int64_t ldx2, const void* W2, const void* bias2, const void* residual,
                   int64_t ldr, void* out, int64_t ldo, void* scratch, int64_t scratch_bytes, bt_stream stream);
@@ -255,6 +270,9 @@ typedef struct bt_attn_args {
     bt_stream aux_stream;
     void* ev_fork;           /* hipEvent_t, created by the caller (hipEventDisableTiming is enough) */
     void* ev_join;
+    /* ---- since 0.3.1 ---- */
+    int32_t* err_flag;       /* device int32 or NULL: sticky BT_DEV_ERR_* bits of this pass -- today BT_DEV_ERR_HANDOFF_TIMEOUT of the
+                                stream-K GEMMs (see bt_stream_k_status); with NULL a time-out goes unreported */
 } bt_attn_args;
 
 /* x[M,H] (row stride H) -> NL x {LN1|LN2, QKV, RoPE+append, attention, dense(+x), h_to_4h+GELU, 4h_to_h(+)} ->
@@ -351,7 +369,9 @@ typedef struct bt_engine_desc {
 
 enum bt_dev_err {
     BT_DEV_ERR_CACHE_FULL = 1, /* bt_roll_over_enqueue found *n_cur >= g_nmax */
-    BT_DEV_ERR_BLOCK_RANGE = 2 /* bt_finish_block found *n_cur >= nb_max (out_ids) or >= mask_ld (mask): nothing was written */
+    BT_DEV_ERR_BLOCK_RANGE = 2, /* bt_finish_block found *n_cur >= nb_max (out_ids) or >= mask_ld (mask): nothing was written */
+    BT_DEV_ERR_HANDOFF_TIMEOUT = 4 /* a stream-K GEMM's consumer workgroup gave up waiting for its partner's partial tile: the
+                                      activations of that pass (and every token derived from them) are incomplete -- discard them */
 };
 
 /* Prefill of sequences [b0, b0+nseq): embed their nb prompt blocks (block_ids [B, nb, L] int64 on device), run the block

@@ -56,7 +56,7 @@ def test_overrides():
 def test_library_exports_every_declared_symbol():
     """The C-ABI library loads and exports exactly what include/bt_hip.h declares (no compute without a GPU)."""
     lib = _lib.lib()
-    assert lib.bt_version() == 300
+    assert lib.bt_version() == 310
     header = open(os.path.join(ROOT, "include", "bt_hip.h")).read()
     declared = set(re.findall(r"^\s*(?:int|int32_t|int64_t|const char\*)\s+(bt_\w+)\(", header, flags=re.M))
     assert declared == set(_lib.EXPORTED_SYMBOLS), declared ^ set(_lib.EXPORTED_SYMBOLS)
@@ -108,15 +108,20 @@ def test_product_library_has_no_debug_hooks():
     import subprocess
     prod = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "bt_linear" in prod and "bt_debug" not in prod
+    # the symbol table IS the C ABI: every dynamic symbol the product defines is a bt_* function of include/bt_hip.h --
+    # no C++-mangled internals (namespace bt), no kernel host stubs (csrc/exports.map)
+    names = [ln.split()[-1] for ln in prod.splitlines() if ln.strip()]
+    assert names and sorted(names) == sorted(_lib.EXPORTED_SYMBOLS), sorted(set(names) ^ set(_lib.EXPORTED_SYMBOLS))
     blob = open(_lib.LIB_PATH, "rb").read()
     for kern in (b"gemm_bf16_mfma256_kernelILb", b"flash_prefill_kernelILi", b"tr_probe_kernel", b"Mma32"):
         assert kern not in blob, kern
     dbg = subprocess.run(["nm", "-D", "--defined-only", _lib.DEBUG_LIB_PATH], capture_output=True, text=True).stdout
     for name in _lib._DEBUG_SIGS:
         assert name in dbg, name
+    assert all(ln.split()[-1].startswith("bt_") for ln in dbg.splitlines() if ln.strip())
     prev = _lib.use_debug_library(True)
     try:
-        assert _lib.lib().bt_version() == 300 and hasattr(_lib.lib(), "bt_debug_gemm_variant")
+        assert _lib.lib().bt_version() == 310 and hasattr(_lib.lib(), "bt_debug_gemm_variant")
     finally:
         _lib.use_debug_library(prev)
     assert not hasattr(_lib.lib(), "bt_debug_gemm_variant_missing")

@@ -78,8 +78,16 @@ def test_two_row_tiles_halve_the_slices():
     from block_transformer_amd._lib import lib
     room = lib().bt_stream_k_scratch_bytes()
     assert max(2 * 512 * (6144 + 8192) * 4, (s1 + s2) * 512 * 2048 * 4) + 4096 <= room, room
-    assert "return M <= 256 ? 16 * M * (int64_t)d->inter * 4 : sk_scratch_bytes();" in \
-        open(os.path.join(ROOT, "block_transformer_amd", "csrc", "engine.hip")).read()
+    # ... and the engine's workspace of a bf16 stack above 256 rows does carry that scratch (fp32 stacks, which have no such
+    # kernels, carry none: ADVICE r5) -- asked of bt_decoder_workspace_bytes itself
+    import ctypes
+    from block_transformer_amd import _lib
+    dims = _lib.bt_decoder_dims(2048, 16, 128, 32, 8192, 12, 1e-5)
+    acts = lambda rows, es: rows * (5 * 2048 + 8192) * es + 512       # noqa: E731  (activation buffers + alignment slack)
+    assert lib().bt_decoder_workspace_bytes(ctypes.byref(dims), _lib.BT_BF16, 512) == acts(512, 2) + room
+    assert lib().bt_decoder_workspace_bytes(ctypes.byref(dims), _lib.BT_BF16, 4096) == acts(4096, 2) + room
+    assert lib().bt_decoder_workspace_bytes(ctypes.byref(dims), _lib.BT_F32, 512) == acts(512, 4)
+    assert lib().bt_decoder_workspace_bytes(ctypes.byref(dims), _lib.BT_F32, 256) == acts(256, 4) + 16 * 256 * 8192 * 4
 
 
 def test_the_1p2b_layer_fills_the_chip():

@@ -1279,6 +1279,41 @@ def test_device_guard_flags_a_replay_past_the_cache(gpu_model):
     assert torch.equal(again, out)
 
 
+def test_stream_k_handoff_timeout_makes_generate_raise(dbg_lib):
+    """the stream-K GEMM's bounded hand-off must fail LOUDLY.  Two-layer block_main_b4_1.2b (H = 2048), B = 4096: every
+    decoder step runs the fused residual projections as one stream-K GEMM whose 128 tiles are each shared by two workgroups.  With the
+    debug hook that makes workgroup 9 skip its publish (consumers give up after 2000 polls) generate() raises BtError -- the tokens
+    are not returned -- through bt_attn_args.err_flag -> bt_engine_desc.err_flag (BT_DEV_ERR_HANDOFF_TIMEOUT); the scoring path
+    (decoder module forward -> DecoderRuntime.check_errors) raises too; and without the hook the same engine generates again."""
+    import dataclasses
+    from block_transformer_amd import _lib
+    base = named_dims("block_main_b4_1.2b")
+    dims = dataclasses.replace(base, name="b4_1.2b_1layer", bd=dataclasses.replace(base.bd, layers=1),
+                               td=dataclasses.replace(base.td, layers=1))
+    torch.manual_seed(3)
+    with torch.device(DEV):
+        model = load_block_transformer_from_dims(dims, "bf16", keep_unused_embed_in=False)
+    model.token_decoder.generation_config.eos_token_id = None
+    B, P = 4096, 8
+    prompt = torch.randint(0, dims.vocab, (B, P), generator=torch.Generator().manual_seed(1)).to(DEV)
+    model.use_graphs = False                 # (a captured graph carries the kernel arguments of its capture, the hook included)
+    good = model.generate(prompt, max_length=P + 8).cpu()
+    emb = torch.randn(B, 1, dims.bd.hidden, device=DEV, dtype=torch.bfloat16)       # 4096 rows through the block decoder MODULE
+    _lib.lib().bt_debug_stream_k_drop(9, 2000)
+    try:
+        with pytest.raises(_lib.BtError, match="hand-off timed out"):
+            model.generate(prompt, max_length=P + 8)
+        assert int(model._engine.err_flag.item()) == 0             # read and cleared by the raise
+        with pytest.raises(_lib.BtError, match="hand-off timed out"):
+            model.block_decoder(inputs_embeds=emb)
+    finally:
+        _lib.lib().bt_debug_stream_k_drop(-1, 0)
+    assert torch.equal(model.generate(prompt, max_length=P + 8).cpu(), good)
+    model.block_decoder(inputs_embeds=emb)
+    del model
+    torch.cuda.empty_cache()
+
+
 @pytest.mark.perf
 def test_compaction_speeds_up_an_eos_heavy_batch(dbg_lib):
     """2-layer 1.2B-shaped bf16 model, B = 1024, half of the rows finish at the start of the third
