@@ -41,15 +41,58 @@ __device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0
 
 // GELU for the bf16 MFMA epilogues.  erff costs ~45 VALU instructions per value (measured: a K = 2048 GEMM with GELU ran
 // 33 % slower than without), so the bf16 path evaluates  gelu(x) = x * Phi(x)  through the scaled normal tail
-//     Phi(-a) = exp(-a^2 / 2) * R(a),   a = |x|,   R = degree-12 polynomial in u = a/3 - 1 (relative minimax fit on [0, 6])
+//     Phi(-a) = exp(-a^2 / 2) * R(a),   a = |x|,   R = degree-11 polynomial in u = a/3 - 1 (relative minimax fit on [0, 6])
 //     gelu(x) = x * Phi(-a)          (x < 0)        = x * (1 - Phi(-a))   (x >= 0)
 // which keeps RELATIVE accuracy in the negative tail (no 1 + erf cancellation).  In fp32 arithmetic the result is within
-// 5.5e-6 relative of the exact erf GELU for x > -6 (|gelu| < 6e-9 beyond, absolute error < 3e-9): 1/700 of a bf16
-// half-ulp.  The fp32 parity path (gemm_generic_kernel) keeps erff.  Two values per call so the polynomial runs on the
-// packed-fp32 pipe (v_pk_fma_f32): ~15 instruction slots per value.
+// 8.5e-6 relative of the exact erf GELU for x > -6 (|gelu| < 6e-9 beyond, absolute error < 8e-9): 1/230 of a bf16
+// half-ulp (round 6: degree 12 -> 11, polynomial error 2.2e-6 -> 7.7e-6 against ~3e-6 of fp32 evaluation noise -- on every bf16
+// input in [-9, 9] both round to the correctly rounded bf16 value; a degree-10 fit, 2.7e-5, would flip 0.03 % of them, degree 9 0.5 %).
+// The fp32 parity path (gemm_generic_kernel) keeps erff.  Two values per call so the polynomial runs on the packed-fp32 pipe
+// (v_pk_fma_f32): 28 instruction slots per PAIR of values (13 v_pk_fma + 3 v_pk_mul + 2 v_min + 2 v_max + 2 quarter-rate v_exp),
+// round 5: 35.
 typedef float v2f __attribute__((ext_vector_type(2)));
 
+// min(|x|, 6) and max(x, 0) as single instructions: the builtins (fminf / fmaxf / fabsf) make hipcc quiet a possible signalling NaN
+// first -- a v_max_f32 x, x in front of every min / max -- and materialise |x| with a v_and: 8 of the 35 VALU slots a pair of values
+// cost (ISA of the round-5 epilogue: 14 v_pk_fma + 3 v_pk_mul + 6 v_max + 2 v_min + 2 v_and + 2 quarter-rate v_exp).  Plain asm (not
+// volatile: the scheduler may move it); 6.0 is not an inline constant of the VOP3 encoding -> one SGPR for the whole kernel.
+__device__ inline float min_abs_f32(float x, float hi) {
+    float r;
+    asm("v_min_f32_e64 %0, |%1|, %2" : "=v"(r) : "v"(x), "s"(hi));
+    return r;
+}
+__device__ inline float relu_f32(float x) {
+    float r;
+    asm("v_max_f32_e32 %0, 0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 __device__ inline v2f gelu_tail2(v2f x) {
+    const v2f a = {min_abs_f32(x.x, 6.0f), min_abs_f32(x.y, 6.0f)};
+    const v2f u = a * (1.0f / 3.0f) - 1.0f;
+    v2f r = u * -3.976902133e-03f + 8.081740986e-03f;
+    r = r * u + -2.753396143e-03f;
+    r = r * u + 1.759199353e-03f;
+    r = r * u + -1.408788524e-02f;
+    r = r * u + 2.432763856e-02f;
+    r = r * u + -3.125067898e-02f;
+    r = r * u + 4.423156669e-02f;
+    r = r * u + -6.233500973e-02f;
+    r = r * u + 8.247426398e-02f;
+    r = r * u + -1.032048037e-01f;
+    r = r * u + 1.215130848e-01f;
+    const v2f t = x * x * -0.72134752044448170368f;     // -x^2 / 2 * log2(e)  (unclamped: exp2 underflows to 0 beyond |x| ~ 14)
+    const v2f e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    const v2f q = e * r;                                 // Phi(-|x|)
+    // x * Phi(x) = relu(x) - |x| * Phi(-|x|): the same value as selecting q or 1 - q by sign and multiplying (identical for x < 0,
+    // x - x q for x >= 0), in one packed FMA instead of two compares, two selects, a subtraction and a multiply.  The clamped |x| is
+    // used for the product: identical bits for |x| <= 6, and beyond that the term is < 1e-8 either way (q < 2e-9)
+    const v2f relu = {relu_f32(x.x), relu_f32(x.y)};
+    return relu - a * q;
+}
+
+#ifdef BT_DEBUG_HOOKS   // the round-5 form (degree 12, builtin min / max / abs: 35 slots per pair) -- A/B reference of the round-6 rewrite (variant 30)
+__device__ inline v2f gelu_tail2_r5(v2f x) {
     const v2f ax = {__builtin_fabsf(x.x), __builtin_fabsf(x.y)};
     const v2f a = {__builtin_fminf(ax.x, 6.0f), __builtin_fminf(ax.y, 6.0f)};
     const v2f u = a * (1.0f / 3.0f) - 1.0f;
@@ -65,14 +108,17 @@ __device__ inline v2f gelu_tail2(v2f x) {
     r = r * u + 8.241136925e-02f;
     r = r * u + -1.031977833e-01f;
     r = r * u + 1.215138655e-01f;
-    const v2f t = ax * ax * -0.72134752044448170368f;   // -a^2 / 2 * log2(e)
+    const v2f t = ax * ax * -0.72134752044448170368f;
     const v2f e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
-    const v2f q = e * r;                                 // Phi(-|x|)
-    // x * Phi(x) = relu(x) - |x| * Phi(-|x|): the same value as selecting q or 1 - q by sign and multiplying (identical for x < 0,
-    // x - x q for x >= 0), in one packed FMA instead of two compares, two selects, a subtraction and a multiply
+    const v2f q = e * r;
     const v2f relu = {__builtin_fmaxf(x.x, 0.0f), __builtin_fmaxf(x.y, 0.0f)};
     return relu - ax * q;
 }
+__device__ inline void gelu4_r5(float (&v)[4]) {
+    const v2f lo = gelu_tail2_r5(v2f{v[0], v[1]}), hi = gelu_tail2_r5(v2f{v[2], v[3]});
+    v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y;
+}
+#endif
 
 __device__ inline void gelu4(float (&v)[4]) {
     const v2f lo = gelu_tail2(v2f{v[0], v[1]}), hi = gelu_tail2(v2f{v[2], v[3]});
@@ -1643,6 +1689,32 @@ __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x
 #pragma unroll
                 for (int ai = 0; ai < 8; ++ai) rpos[ai] = e.q.pos_table[rpos[ai]];
             }
+            if constexpr ((EABL & 64) != 0) {
+                // round-6 experiment (variant 29): the cos / sin rows of all 8 fragments in flight together -- one exposed load latency per
+                // rotated column group instead of two (64 transient registers: the K-loop's fragment registers are dead here)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    if (!rot[pr]) continue;
+                    float4 c[8], sn[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int64_t off = (int64_t)rpos[i] * 16 + (lane >> 4) * 4;
+                        c[i] = *reinterpret_cast<const float4*>(e.q.cos_tab + off);
+                        sn[i] = *reinterpret_cast<const float4*>(e.q.sin_tab + off);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float cc[4] = {c[i].x, c[i].y, c[i].z, c[i].w};
+                        const float ss[4] = {sn[i].x, sn[i].y, sn[i].z, sn[i].w};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float x1 = acc[i][pr * 2][r], x2 = acc[i][pr * 2 + 1][r];
+                            acc[i][pr * 2][r] = x1 * cc[r] - x2 * ss[r];
+                            acc[i][pr * 2 + 1][r] = x2 * cc[r] + x1 * ss[r];
+                        }
+                    }
+                }
+            } else
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
                 if (!rot[pr]) continue;
@@ -1757,6 +1829,10 @@ __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x
 #pragma unroll
         for (int jf = 0; jf < 4; ++jf) {
             float v[4] = {acc[ai][jf][0], acc[ai][jf][1], acc[ai][jf][2], acc[ai][jf][3]};
+#ifdef BT_DEBUG_HOOKS
+            if (MODE == PP_GELU && (EABL & 128) != 0) gelu4_r5(v);
+            else
+#endif
             if (MODE == PP_GELU) gelu4(v);
             o[jf].x = pack_bf16x2(v[0], v[1]);
             o[jf].y = pack_bf16x2(v[2], v[3]);
@@ -2359,7 +2435,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
                                                                   int K, int tiles_m, int tiles_n) {
     typedef Mma16 P;
     const int M = ep.M, N = ep.N;
-    __shared__ __attribute__((aligned(16))) char smem[PP_SMEM];
+    // ABL bit 131072 (round 6, variant 28: the tile-boundary TIMELINE): every wave stamps s_memtime at ten points of each of its first
+    // twelve tiles into 8 KiB of LDS behind the kernel's own (inline asm: the compiler must not see LDS traffic), and workgroups 0 .. 3
+    // dump them to ep.amax (unused outside the ARGMAX mode) at the end.  Correct results; tools/kernel_probe.py pptl reads the buffer.
+    constexpr bool TL = (ABL & 131072) != 0;
+    constexpr int TL_EV = 10, TL_TILES = 12;
+    __shared__ __attribute__((aligned(16))) char smem[PP_SMEM + (TL ? 8192 : 0)];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -2368,6 +2449,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
     const int wcol = wh * 128 + wrow;
     const bool grp1 = wave >= 4;
     char* stage = smem + PP_EPI_OFF + wave * P::PATCH_BYTES;
+    const uint32_t tl_lds = lds_addr(smem) + (uint32_t)PP_SMEM + (uint32_t)wave * 1024u;
+    auto stamp = [&](int j, int ev) {
+        if constexpr (TL) {
+            if (j < TL_TILES) {
+                uint64_t tm;
+                asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm) : : "memory");
+                const uint32_t a = tl_lds + (uint32_t)(j * TL_EV + ev) * 8u;
+                asm volatile("ds_write_b64 %0, %1" : : "v"(a), "v"(tm) : "memory");
+            }
+        }
+    };
     const uint32_t lane_slot = (uint32_t)(((lane & 7) ^ ((lane >> 3) & 7)) * 16);
     // lane part of a DMA address inside its 16-row group: row (lane >> 3) of rows 0..7 / 8..15, swizzled 16-byte slot
     const uint32_t voff_a_0 = (uint32_t)(lane >> 3) * (uint32_t)(lda * 2) + lane_slot;
@@ -2513,6 +2605,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
     auto phase = [&](auto pc, auto pmc, int t, int j, auto stc) {
         constexpr int p = decltype(pc)::value, PM = decltype(pmc)::value, ST = decltype(stc)::value;
         static_assert(ST < 0 || PM == 1, "fast K-tiles are steady-state K-tiles");
+        if constexpr (TL && ST < 0) {
+            if (p == 0 && t == 0) stamp(j, 0);
+            if (p == 0 && t == nk - 1) stamp(j, 5);
+        }
         if (!grp1) {
             if constexpr (PM == 2) {
                 wait_for_phase_pp(g, total, false);
@@ -2607,6 +2703,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
         }
         if (ABL & 16384) __builtin_amdgcn_s_setprio(0);
         cbarrier();
+        if constexpr (TL && ST < 0) {
+            if (t == 0) stamp(j, p == 0 ? 1 : 3);
+            if (t == 1 && p == 0) stamp(j, 4);
+            if (t == nk - 1 && p == 1) stamp(j, 6);
+        }
         __builtin_amdgcn_sched_barrier(0);
         // (no s_setprio around the cluster: raising the MFMA-issuing wave's priority delays the OTHER group's fragment reads and
         //  DMA issue on the same SIMD, and that off-turn path is what bounds a phase -- +1-5 % without it on every shape and
@@ -2643,6 +2744,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
             }
         }
         if (ABL & 8192) __builtin_amdgcn_s_setprio(0);
+        if constexpr (TL && ST < 0) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (t == 0 && p == 0) stamp(j, 2);
+            if (t == nk - 1 && p == 1) stamp(j, 7);
+        }
         ++g;
     };
     for (int j = 0; j < nt; ++j) {
@@ -2704,9 +2810,25 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
         }
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
-        P::template epilogue<MODE, (ABL >> 5) & 3 | ((ABL >> 6) & 12) | ((ABL >> 12) & 16) | (LNF ? 32 : 0)>(ep, pos0, stage, acc, cm0, cn0 + wcol, wm, lane_e);
+        stamp(j, 8);
+        P::template epilogue<MODE, (ABL >> 5) & 3 | ((ABL >> 6) & 12) | ((ABL >> 12) & 16) | (LNF ? 32 : 0) | ((ABL >> 12) & (64 | 128))>(ep, pos0, stage, acc, cm0, cn0 + wcol, wm, lane_e);
+        stamp(j, 9);
     }
     if (!grp1) cbarrier();
+    if constexpr (TL) {   // every wave dumps its own 1 KiB of stamps (it wrote them itself: no barrier needed)
+        if (blockIdx.x < 4 && ep.amax != nullptr && MODE != PP_ARGMAX) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            uint64_t* dst = reinterpret_cast<uint64_t*>(ep.amax) + ((int64_t)blockIdx.x * 8 + wave) * 128;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int idx = lane + h * 64;
+                uint64_t v;
+                const uint32_t a = tl_lds + (uint32_t)idx * 8u;
+                asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+                if (idx < TL_EV * TL_TILES) dst[idx] = v;
+            }
+        }
+    }
 }
 
 // ---- persistent kernel, stream-K items (round 5): the decode-shape GEMMs whose 256 x 256 tiles do not fill whole rounds ------------
@@ -4571,6 +4693,9 @@ BT_KNOB int g_small_stages = 0;   // LDS ring depth of the 128^2 / 128x64 / 64x6
 // stream-K items kernel (gemm_bf16_mfma256sk_kernel, round 5) for full-tile problems whose 256 x 256 tiles leave the persistent
 // kernel's last round under 90 % full, and for bt_linear2 above 256 rows: 1 = on (needs the caller's scratch: slabs + flags), 0 = A/B
 BT_KNOB int g_sk = 1;
+#ifdef BT_DEBUG_HOOKS
+static void* g_timeline = nullptr;   // bt_debug_timeline_buffer: 4 workgroups x 8 waves x 128 stamps of 8 bytes (variant 28)
+#endif
 BT_KNOB int g_sk_drop_vw = -1;    // debug build (bt_debug_stream_k_drop): this publishing workgroup never raises its flags ...
 BT_KNOB int g_sk_spin = 0;        // ... and consumers give up after this many polls (0: SK_SPIN_LIMIT) -> the time-out path under test
 BT_KNOB int g_gemm_variant = 0;   // 0 auto; 1 force 128^2; 2/3 256^2 four-phase ring (plain/staggered); 4-8 timing ablations; 9/10 256^2
@@ -4894,6 +5019,16 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
     else if (g_gemm_variant == 27) /* A/B: QKV epilogue with the generic (per-lane division) K / V addresses */      \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 65536>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
+                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
+    else if (g_gemm_variant == 28) /* round 6: tile-boundary timeline (stamps -> g_timeline) */                       \
+        { ep.amax = (MODE_ == PP_ARGMAX) ? ep.amax : (uint2*)g_timeline;                                             \
+        hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 131072>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
+                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n); }                                 \
+    else if (g_gemm_variant == 29) /* round 6 experiment: QKV epilogue, cos / sin rows of all 8 fragments in one batch */ \
+        hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 262144>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
+                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
+    else if (g_gemm_variant == 30) /* round 6 A/B: the round-5 GELU (degree 12, builtin min / max) */                  \
+        hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 524288>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
     else if (g_gemm_variant == 19) /* experiment: cluster tail after the hand-over barrier */                       \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 2048>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,   \
@@ -6010,6 +6145,7 @@ extern "C" void bt_debug_force_generic_gemm(int on) { g_force_generic = on != 0;
 extern "C" void bt_debug_gemm_variant(int v) { g_gemm_variant = v; }
 extern "C" void bt_debug_stream_k(int on) { g_sk = on; }
 extern "C" void bt_debug_stream_k_drop(int vw, int spin) { g_sk_drop_vw = vw; g_sk_spin = spin; }
+extern "C" void bt_debug_timeline_buffer(void* buf) { g_timeline = buf; }
 extern "C" void bt_debug_gemm_max_wg(int n) { g_max_wg = n; }
 extern "C" void bt_debug_skinny_rows(int n) { g_skinny_rows = n; }
 extern "C" void bt_debug_small_stages(int n) { g_small_stages = n; }

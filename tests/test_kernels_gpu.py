@@ -688,7 +688,7 @@ def _poison_scratch(scratch):
 
 
 def test_stream_k_handoff_timeout_is_reported_not_swallowed(dbg_lib):
-    """VERDICT r5 weak #1 / ADVICE r5: a consumer of the stream-K hand-off whose producer never raises its flag (debug hook: workgroup 5
+    """VERDICT r5 weak #1 / ADVICE r5: a consumer of the stream-K hand-off whose producer never raises its flag (debug hook: workgroup 4
     skips its publish, consumers give up after 2000 polls instead of 2^20) must NOT add the unwritten slab and carry on silently: the
     sticky word of the scratch is set, survives the next launch's flag clearing (a good launch in between does not erase the unread
     time-out), bt_stream_k_status turns it into BT_DEV_ERR_HANDOFF_TIMEOUT, and after the reset the same scratch works again."""
@@ -701,7 +701,7 @@ def test_stream_k_handoff_timeout_is_reported_not_swallowed(dbg_lib):
     scratch = _poison_scratch(ops.stream_k_scratch(DEV))
     good = ops.linear2(x1, w1, b1, x2, w2, b2, scratch=scratch).clone()
     ops.stream_k_check(scratch)                                  # nothing to report
-    lib().bt_debug_stream_k_drop(5, 2000)
+    lib().bt_debug_stream_k_drop(4, 2000)                     # (even virtual ids hold a tile's FIRST chunks here: the publishers)
     try:
         bad = ops.linear2(x1, w1, b1, x2, w2, b2, scratch=scratch).clone()
         torch.cuda.synchronize()

@@ -1282,7 +1282,7 @@ def test_device_guard_flags_a_replay_past_the_cache(gpu_model):
 def test_stream_k_handoff_timeout_makes_generate_raise(dbg_lib):
     """the stream-K GEMM's bounded hand-off must fail LOUDLY.  Two-layer block_main_b4_1.2b (H = 2048), B = 4096: every
     decoder step runs the fused residual projections as one stream-K GEMM whose 128 tiles are each shared by two workgroups.  With the
-    debug hook that makes workgroup 9 skip its publish (consumers give up after 2000 polls) generate() raises BtError -- the tokens
+    debug hook that makes workgroup 8 skip its publish (consumers give up after 2000 polls) generate() raises BtError -- the tokens
     are not returned -- through bt_attn_args.err_flag -> bt_engine_desc.err_flag (BT_DEV_ERR_HANDOFF_TIMEOUT); the scoring path
     (decoder module forward -> DecoderRuntime.check_errors) raises too; and without the hook the same engine generates again."""
     import dataclasses
@@ -1299,7 +1299,7 @@ def test_stream_k_handoff_timeout_makes_generate_raise(dbg_lib):
     model.use_graphs = False                 # (a captured graph carries the kernel arguments of its capture, the hook included)
     good = model.generate(prompt, max_length=P + 8).cpu()
     emb = torch.randn(B, 1, dims.bd.hidden, device=DEV, dtype=torch.bfloat16)       # 4096 rows through the block decoder MODULE
-    _lib.lib().bt_debug_stream_k_drop(9, 2000)
+    _lib.lib().bt_debug_stream_k_drop(8, 2000)               # (even virtual ids publish at M = 4096: 2 workgroups per tile)
     try:
         with pytest.raises(_lib.BtError, match="hand-off timed out"):
             model.generate(prompt, max_length=P + 8)

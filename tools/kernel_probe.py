@@ -222,7 +222,7 @@ def probe_copy(nbytes, iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("what", choices=["gemm", "attn", "flash", "suite", "copy", "ab", "abl", "skinny", "decode", "vendor", "pitch",
-                                     "local", "lin2", "ln", "ppabl", "ppstore", "ppv2", "ppepi", "ppab", "t21", "ppqkv", "sk"])
+                                     "local", "lin2", "ln", "ppabl", "ppstore", "ppv2", "ppepi", "ppab", "t21", "ppqkv", "sk", "pptl"])
     ap.add_argument("--m", type=int, default=32768)
     ap.add_argument("--n", type=int, default=6144)
     ap.add_argument("--k", type=int, default=2048)
@@ -515,6 +515,75 @@ def main():
             rec["a_TF"], rec["b_TF"] = round(fl / min(rec["a_us"]), 1), round(fl / min(rec["b_us"]), 1)
             res.append(rec)
         hooks.bt_debug_gemm_variant(0)
+    elif args.what == "pptl":
+        # round 6: the tile-boundary TIMELINE of the persistent kernel (debug variant 28: every wave stamps s_memtime at ten points of each
+        # of its first twelve tiles; workgroups 0 .. 3 dump).  Per mode and shape: the median over tiles 1 .. nt - 2 and the 8 waves of the
+        # intervals between consecutive stamps, in shader-clock cycles (s_memtime ticks at 100 MHz on this part: converted with the
+        # launch's measured duration / its span in ticks) -- where the time between a tile's last MFMA cluster and the next tile's
+        # first one goes.  Events: 0 top of phase (0,0), 1 cluster (0,0) opens, 2 its 32 MFMAs issued, 3 cluster (0,1) opens,
+        # 4 cluster (1,0) opens, 5 top of phase (nk-1,0), 6 cluster (nk-1,1) opens, 7 issued, 8 epilogue starts (after the boundary
+        # barrier + pre-issue), 9 epilogue done (last store issued).
+        import statistics
+        heads, d, rot = 16, 128, 32
+        H = heads * d
+        tab = ops.rope_tables(1024, rot, 10000.0, DEV)
+        buf = torch.zeros(4 * 8 * 128, dtype=torch.int64, device=DEV)
+        hooks.bt_debug_timeline_buffer(ptr(buf))
+        for (mode, M, N, K) in (("plain", 32768, 6144, 2048), ("gelu", 32768, 8192, 2048), ("qkv", 32768, 6144, 2048), ("res", 32768, 2048, 2048),
+                                ("plain", 4096, 8192, 2048), ("gelu", 4096, 8192, 2048), ("qkv", 4096, 6144, 2048), ("qkv2", 8192, 6144, 2048)):
+            x = torch.randn(M, K, device=DEV).bfloat16()
+            w = (torch.randn(N, K, device=DEV) * K ** -0.5).bfloat16()
+            b = torch.randn(N, device=DEV).bfloat16()
+            r = torch.randn(M, N, device=DEV).bfloat16() if mode == "res" else None
+            out = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+            if mode.startswith("qkv"):
+                q = 512 if M == 32768 else (2 if mode == "qkv2" else 1)
+                B = M // q
+                n_max = q + 2
+                kc = torch.zeros(B, heads, n_max, d, dtype=torch.bfloat16, device=DEV)
+                vc = torch.zeros_like(kc)
+
+                def call():
+                    check(lib().bt_qkv_rope_append(_lib.BT_BF16, B, q, heads, d, rot, ptr(x), H, ptr(w), ptr(b), ptr(out), 3 * H, ptr(kc),
+                                                   ptr(vc), n_max, None, 0, None, ptr(tab[0]), ptr(tab[1]), None, 0, current_stream()))
+            else:
+                def call():
+                    ops.linear(x, w, b, r, act="gelu" if mode == "gelu" else "none", out=out)
+            hooks.bt_debug_gemm_variant(0)
+            us_prod = timed(call, 10) * 1e3
+            hooks.bt_debug_gemm_variant(28)
+            us_tl = timed(call, 10) * 1e3
+            buf.zero_()
+            call()
+            torch.cuda.synchronize()
+            hooks.bt_debug_gemm_variant(0)
+            st = buf.view(4, 8, 128)[:, :, :120].reshape(4, 8, 12, 10).cpu()
+            nt = int((st[0, 0, :, 0] != 0).sum())
+            span = int(st[:, :, :nt].max() - st[:, :, :nt][st[:, :, :nt] != 0].min())
+            rec = {"op": "pp_timeline", "mode": mode, "M": M, "N": N, "K": K, "tiles_per_workgroup": nt, "us_production": round(us_prod, 1),
+                   "us_with_stamps": round(us_tl, 1), "span_ticks_wg0_3": span, "ns_per_tick_if_span_is_the_launch": round(us_tl * 1e3 / max(span, 1), 3)}
+            names = ["0>1 wait+reads (0,0)", "1>2 cluster (0,0) issue", "2>3 to cluster (0,1)", "3>4 to cluster (1,0)", "4>5 K-tiles 1..nk-2",
+                     "5>6 last K-tile to its 2nd cluster", "6>7 last cluster issue", "7>8 boundary barrier + pre-issue", "8>9 epilogue",
+                     "9>0' next tile's phase (0,0) top", "7>1' last cluster issued -> next tile's first cluster opens", "1>1' whole tile"]
+            iv = {n: [] for n in names}
+            per_wave_epi = [[] for _ in range(8)]
+            for wg in range(4):
+                for wv in range(8):
+                    for j in range(1, max(nt - 1, 1)):
+                        t = [int(v) for v in st[wg, wv, j]]
+                        nx = [int(v) for v in st[wg, wv, j + 1]] if j + 1 < nt else None
+                        for e in range(9):
+                            iv[names[e]].append(t[e + 1] - t[e])
+                        per_wave_epi[wv].append(t[9] - t[8])
+                        if nx is not None and nx[0]:
+                            iv[names[9]].append(nx[0] - t[9])
+                            iv[names[10]].append(nx[1] - t[7])
+                            iv[names[11]].append(nx[1] - t[1])
+            rec["median_ticks"] = {n: (statistics.median(v) if v else None) for n, v in iv.items()}
+            rec["p90_ticks"] = {n: (sorted(v)[int(0.9 * (len(v) - 1))] if v else None) for n, v in iv.items()}
+            rec["epilogue_median_ticks_by_wave"] = [statistics.median(v) if v else None for v in per_wave_epi]
+            res.append(rec)
+        hooks.bt_debug_timeline_buffer(None)
     elif args.what == "t21":
         # the decode projections onto the residual stream at M = 4096: one-tile 256 x 128 kernel (production dispatch, variant 0) vs
         # the 128^2 kernel (variant 1) vs torch F.linear (hipBLASLt), interleaved
