@@ -546,8 +546,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the in-run oracle check of the timed batch (parity_in_run)")
     ap.add_argument("--no-secondary", action="store_true",
-                    help="skip the secondary north-star workloads (prefill 128 / decode 2048; the L = 8 variant) of the default run")
-    ap.add_argument("--secondary-steps", type=int, default=3, help="timed generates per secondary workload (after one full-length warm-up)")
+                    help="skip the secondary north-star workloads (prefill 128 / decode 2048; prefill 2048 / decode 2048 at the per-GPU batch; the L = 8 variant) of the default run")
+    ap.add_argument("--secondary-steps", type=int, default=2, help="timed generates per secondary workload (after one full-length warm-up)")
     ap.add_argument("--secondary-deadline", type=float, default=330.0,
                     help="seconds after process start beyond which no further secondary step is started (the line says how many ran)")
     ap.add_argument("--no-ceilings", action="store_true", help="skip the in-run empirical ceilings (copy kernel, MFMA loop) and the clock / power sampler")
@@ -789,6 +789,17 @@ def main():
         parity_failed = parity_failed or not sec[-1].get("parity_in_run", {"ok": True})["ok"]
         log(f"secondary: {sec[-1]['value']:.0f} tok/s")
         model.release_buffers()
+        torch.cuda.empty_cache()
+        # BASELINE.json configs[3] (prefill 2048 / decode 2048) at the batch ONE rank of the 8-GPU run holds (free HBM: the global KV of
+        # 1024 block positions per sequence), with the in-run oracle check of its last block -- attention over 1023 cached positions in
+        # every layer, 511 roll-overs behind it (VERDICT r5 next #3b).  ~29 s per generate: one warm-up + at most two timed.
+        B3 = args.batch if args.batch > 0 else auto_batch(dims, 2048, 2048, device, itemsize)
+        log(f"secondary: prefill 2048 / decode 2048 at the per-GPU batch {B3} ...")
+        sec.append(secondary_workload(model, dims, args.config, 2048, 2048, B3, device, args.seed + 3, itemsize,
+                                      steps=min(args.secondary_steps, 2), deadline=deadline + 90.0, parity=not args.no_parity))
+        parity_failed = parity_failed or not sec[-1].get("parity_in_run", {"ok": True})["ok"]
+        log(f"secondary: {sec[-1]['value']:.0f} tok/s")
+        model.release_buffers()
         del model
         torch.cuda.empty_cache()
         d8 = named_dims("block_main_b8_1.2b")
@@ -797,7 +808,7 @@ def main():
         m8.use_graphs = not args.no_graphs
         B8 = args.batch if args.batch > 0 else auto_batch(d8, 2048, 128, device, itemsize)
         sec.append(secondary_workload(m8, d8, "block_main_b8_1.2b", 2048, 128, B8, device, args.seed + 2, itemsize,
-                                      steps=args.secondary_steps, deadline=deadline + 60.0, parity=not args.no_parity))
+                                      steps=args.secondary_steps, deadline=deadline + 150.0, parity=not args.no_parity))
         parity_failed = parity_failed or not sec[-1].get("parity_in_run", {"ok": True})["ok"]
         log(f"secondary: {sec[-1]['value']:.0f} tok/s")
         m8.release_buffers()

@@ -2440,6 +2440,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
     // dump them to ep.amax (unused outside the ARGMAX mode) at the end.  Correct results; tools/kernel_probe.py pptl reads the buffer.
     constexpr bool TL = (ABL & 131072) != 0;
     constexpr int TL_EV = 10, TL_TILES = 12;
+    // ABL bit 1048576 (variant 31 / 32 with the timeline): the round-5 tile boundary -- group 1's extra barrier in FRONT of its refill, i.e.
+    // the two groups' epilogues one after the other (A/B reference of the round-6 boundary, bit-identical results)
+    constexpr bool SERIAL_EPI = (ABL & 1048576) != 0;
     __shared__ __attribute__((aligned(16))) char smem[PP_SMEM + (TL ? 8192 : 0)];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2799,9 +2802,16 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
         if (MODE == PP_ARGMAX && ep.out == nullptr) prev_full = false;   // 8 partial stores per wave instead of >= PP_STORES
         if (j + 1 < nt) {
             // tile boundary: W1 / A1 of the next tile's K-tile 1 go out ahead of this tile's stores.  Their slots were last read in
-            // the final phase: one barrier after those reads were issued, the margin every other refill of the ring has
-            // (group 0's barrier here pairs with group 1's second barrier of the final phase and vice versa).
-            cbarrier();
+            // the final phase: one barrier after those reads were issued, the margin every other refill of the ring has.
+            // Round 6 (profiles/r6_pp_timeline.jsonl): the two wave groups run one barrier apart, so group 0's barrier here pairs
+            // with group 1's SECOND barrier of its final phase -- and group 1's own boundary barrier used to pair with group 0's first
+            // barrier of the NEXT tile, which group 0 reaches only after its epilogue; group 0 then waited at its second barrier for
+            // group 1's epilogue: the two epilogues ran one after the other (per tile 2 x 3.9 k cycles plain, 2 x 8.9 k QKV, 2 x 13 k
+            // GELU with the matrix pipe idle).  Group 1 needs no barrier in front of its refill -- every wave that passed group 1's
+            // second barrier of the final phase has issued its final reads, and group 0's were issued a barrier earlier -- so its
+            // extra barrier (the count must match group 0's: the stagger) moves BEHIND its epilogue: both groups now run their
+            // epilogues at the same time, group 1's starting when its last MFMA cluster is issued.
+            if (!grp1 || SERIAL_EPI) cbarrier();
             issue2(I2{}, I3{}, false);
             advance();
             pre_issued = true;
@@ -2813,6 +2823,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
         stamp(j, 8);
         P::template epilogue<MODE, (ABL >> 5) & 3 | ((ABL >> 6) & 12) | ((ABL >> 12) & 16) | (LNF ? 32 : 0) | ((ABL >> 12) & (64 | 128))>(ep, pos0, stage, acc, cm0, cn0 + wcol, wm, lane_e);
         stamp(j, 9);
+        if (j + 1 < nt && grp1 && !SERIAL_EPI) cbarrier();
     }
     if (!grp1) cbarrier();
     if constexpr (TL) {   // every wave dumps its own 1 KiB of stamps (it wrote them itself: no barrier needed)
@@ -3170,9 +3181,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256sk_kernel(const bf16* __
         const bool consume = last && !publish && cw.cs != 0;   // the chain began inside its tile: add the neighbour's partial first
         prev_full = last && !publish;                      // a normal epilogue follows: >= PP_STORES stores per wave
         if (MODE == PP_ARGMAX && ep.out == nullptr) prev_full = false;
-        if (j + 1 < nt) {
-            // item boundary: W1 / A1 of the next item's K-tile 1 go out ahead of whatever this item stores (see the v2 kernel)
-            cbarrier();
+        const bool more = j + 1 < nt;
+        if (more) {
+            // item boundary: W1 / A1 of the next item's K-tile 1 go out ahead of whatever this item stores (see the v2 kernel).  Round 6:
+            // group 1's extra barrier sits BEHIND whatever it does at the boundary (epilogue, publish, consume), so that the two wave
+            // groups do it at the same time instead of one after the other -- see the v2 kernel's tile boundary
+            if (!grp1) cbarrier();
             issue2(I2{}, I3{}, false);
             advance();
             pre_issued = true;
@@ -3180,8 +3194,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256sk_kernel(const bf16* __
             prev_full = false;
         }
         const int cm0 = cw.m0, cn0 = cw.n0;
-        if (j + 1 < nt) cw.next(lo, C, tiles_m, tiles_n);
-        if (!last) continue;                               // the next item continues this tile in the same accumulators
+        if (more) cw.next(lo, C, tiles_m, tiles_n);
+        if (!last) {                                       // the next item continues this tile in the same accumulators
+            if (more && grp1) cbarrier();
+            continue;
+        }
         if (publish) {
             // this wave's 128 x 64 fp32 block -> slab of the consumer (the next virtual workgroup), write-through, then its flag
             float* slab = sk.slabs + ((int64_t)(vw + 1) * 8 + wave) * (32 * 64 * 4);
@@ -3198,9 +3215,10 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256sk_kernel(const bf16* __
                 }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every store of this wave has left the CU (and the loads issued before them)
 #ifdef BT_DEBUG_HOOKS
-            if (vw == sk.dbg_drop_vw) continue;                // test hook: a producer that never arrives
+            if (vw != sk.dbg_drop_vw)                          // test hook: a producer that never arrives
 #endif
             sk_flag_store(sk.flags + (int64_t)(vw + 1) * 8 + wave, 1u);
+            if (more && grp1) cbarrier();
             continue;
         }
         if (consume) {
@@ -3256,6 +3274,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256sk_kernel(const bf16* __
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         P::template epilogue<MODE>(ep, pos0, stage, acc, cm0, cn0 + wcol, wm, lane_e);
+        if (more && grp1) cbarrier();
     }
     if (!grp1) cbarrier();
 }
@@ -5027,6 +5046,13 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
     else if (g_gemm_variant == 29) /* round 6 experiment: QKV epilogue, cos / sin rows of all 8 fragments in one batch */ \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 262144>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
+    else if (g_gemm_variant == 31) /* round 6 A/B: the round-5 tile boundary (epilogues of the two wave groups serialised) */ \
+        hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 1048576>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
+                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
+    else if (g_gemm_variant == 32) /* ... with the timeline stamps */                                                \
+        { ep.amax = (MODE_ == PP_ARGMAX) ? ep.amax : (uint2*)g_timeline;                                             \
+        hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 1048576 + 131072>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
+                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n); }                                 \
     else if (g_gemm_variant == 30) /* round 6 A/B: the round-5 GELU (degree 12, builtin min / max) */                  \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 524288>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \

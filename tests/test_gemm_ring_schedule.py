@@ -323,7 +323,10 @@ def _pp2_stream(grp, wave0, nk, nt, full, stores, pd, has_bias, bad=None, dmac=F
                 g += 1
         prev_full = full[j]
         if j + 1 < nt:
-            if bad != "no_boundary_barrier":
+            # round 6: group 0's extra barrier in FRONT of the boundary refill, group 1's BEHIND its epilogue / publish (the two groups'
+            # epilogues run side by side instead of one after the other); bad = "g1_barrier_first" is the round-5 order (also hazard-free:
+            # the debug build keeps it as the A/B reference), "no_boundary_barrier" drops group 0's
+            if (grp == 0 and bad != "no_boundary_barrier") or (grp == 1 and bad == "g1_barrier_first"):
                 ev.append(("bar",))
             dma2()
             pre_issued = True
@@ -333,6 +336,8 @@ def _pp2_stream(grp, wave0, nk, nt, full, stores, pd, has_bias, bad=None, dmac=F
             ev.append(("vm", ("st", j)))
         if j in drain:                            # stream-K publish: s_waitcnt vmcnt(0) behind the slab stores, then the flag
             ev.append(("wait", 0))
+        if j + 1 < nt and grp == 1 and bad != "g1_barrier_first":
+            ev.append(("bar",))
     if grp == 0:
         ev.append(("bar",))
     return ev
@@ -407,6 +412,9 @@ def test_persistent_v2_model_detects_errors():
         pp_model(8, 3, [True] * 3, [PP_STORES] * 3, stream=functools.partial(_pp2_stream, bad="late_store_wait"))
     with pytest.raises(AssertionError):                   # boundary refill without its barrier: barrier counts / WAR break
         pp_model(8, 3, [True] * 3, [PP_STORES] * 3, stream=functools.partial(_pp2_stream, bad="no_boundary_barrier"))
+    # the round-5 boundary (group 1's barrier in front of its refill: variant 31 of the debug build) is hazard-free too
+    for nk in (4, 5, 8, 32):
+        pp_model(nk, 3, [True] * 3, [PP_STORES] * 3, stream=functools.partial(_pp2_stream, bad="g1_barrier_first"))
 
 
 def _pp2_ktile_walk(nk, nt, full):

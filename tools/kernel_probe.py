@@ -529,6 +529,8 @@ def main():
         tab = ops.rope_tables(1024, rot, 10000.0, DEV)
         buf = torch.zeros(4 * 8 * 128, dtype=torch.int64, device=DEV)
         hooks.bt_debug_timeline_buffer(ptr(buf))
+        # --variant 32: the round-5 tile boundary (the two wave groups' epilogues one after the other); default 28: the round-6 boundary
+        tl_variant = 32 if args.variant == 32 else 28
         for (mode, M, N, K) in (("plain", 32768, 6144, 2048), ("gelu", 32768, 8192, 2048), ("qkv", 32768, 6144, 2048), ("res", 32768, 2048, 2048),
                                 ("plain", 4096, 8192, 2048), ("gelu", 4096, 8192, 2048), ("qkv", 4096, 6144, 2048), ("qkv2", 8192, 6144, 2048)):
             x = torch.randn(M, K, device=DEV).bfloat16()
@@ -551,16 +553,17 @@ def main():
                     ops.linear(x, w, b, r, act="gelu" if mode == "gelu" else "none", out=out)
             hooks.bt_debug_gemm_variant(0)
             us_prod = timed(call, 10) * 1e3
-            hooks.bt_debug_gemm_variant(28)
+            hooks.bt_debug_gemm_variant(tl_variant)
             us_tl = timed(call, 10) * 1e3
             buf.zero_()
             call()
             torch.cuda.synchronize()
             hooks.bt_debug_gemm_variant(0)
             st = buf.view(4, 8, 128)[:, :, :120].reshape(4, 8, 12, 10).cpu()
-            nt = int((st[0, 0, :, 0] != 0).sum())
+            # tiles of workgroups 0 .. 3 (the first of every round); slots beyond hold whatever an earlier launch left in that LDS
+            nt = min(12, -(-(-(-M // 256) * -(-N // 256)) // 256))
             span = int(st[:, :, :nt].max() - st[:, :, :nt][st[:, :, :nt] != 0].min())
-            rec = {"op": "pp_timeline", "mode": mode, "M": M, "N": N, "K": K, "tiles_per_workgroup": nt, "us_production": round(us_prod, 1),
+            rec = {"op": "pp_timeline", "boundary": "round 5 (serial epilogues)" if tl_variant == 32 else "round 6", "mode": mode, "M": M, "N": N, "K": K, "tiles_per_workgroup": nt, "us_production": round(us_prod, 1),
                    "us_with_stamps": round(us_tl, 1), "span_ticks_wg0_3": span, "ns_per_tick_if_span_is_the_launch": round(us_tl * 1e3 / max(span, 1), 3)}
             names = ["0>1 wait+reads (0,0)", "1>2 cluster (0,0) issue", "2>3 to cluster (0,1)", "3>4 to cluster (1,0)", "4>5 K-tiles 1..nk-2",
                      "5>6 last K-tile to its 2nd cluster", "6>7 last cluster issue", "7>8 boundary barrier + pre-issue", "8>9 epilogue",
@@ -569,7 +572,7 @@ def main():
             per_wave_epi = [[] for _ in range(8)]
             for wg in range(4):
                 for wv in range(8):
-                    for j in range(1, max(nt - 1, 1)):
+                    for j in range(1 if nt > 2 else 0, max(nt - 1, 1)):
                         t = [int(v) for v in st[wg, wv, j]]
                         nx = [int(v) for v in st[wg, wv, j + 1]] if j + 1 < nt else None
                         for e in range(9):
@@ -582,6 +585,19 @@ def main():
             rec["median_ticks"] = {n: (statistics.median(v) if v else None) for n, v in iv.items()}
             rec["p90_ticks"] = {n: (sorted(v)[int(0.9 * (len(v) - 1))] if v else None) for n, v in iv.items()}
             rec["epilogue_median_ticks_by_wave"] = [statistics.median(v) if v else None for v in per_wave_epi]
+            for grp in (0, 1):     # the two wave groups see the boundary differently (who waits for whom)
+                g = {n: [] for n in (names[7], names[8], names[0], names[10])}
+                for wg in range(4):
+                    for wv in range(4 * grp, 4 * grp + 4):
+                        for j in range(1 if nt > 2 else 0, max(nt - 1, 1)):
+                            t = [int(v) for v in st[wg, wv, j]]
+                            g[names[7]].append(t[8] - t[7])
+                            g[names[8]].append(t[9] - t[8])
+                            if j + 1 < nt:
+                                nx = [int(v) for v in st[wg, wv, j + 1]]
+                                g[names[0]].append(nx[1] - nx[0])
+                                g[names[10]].append(nx[1] - t[7])
+                rec[f"group{grp}_median_ticks"] = {n: (statistics.median(v) if v else None) for n, v in g.items()}
             res.append(rec)
         hooks.bt_debug_timeline_buffer(None)
     elif args.what == "t21":
