@@ -182,9 +182,12 @@ _DEBUG_SIGS = {
     "bt_debug_stream_k": (None, [c_int]),
     "bt_debug_stream_k_drop": (None, [c_int, c_int]),
     "bt_debug_timeline_buffer": (None, [c_void_p]),
+    "bt_debug_serial_epilogues": (None, [c_int]),
     "bt_debug_no_two_branch": (None, [c_int]),
     "bt_debug_ln_streaming": (None, [c_int]),
     "bt_debug_tr_probe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "bt_debug_grid_barrier_probe": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "bt_debug_phase_probe": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
 }
 
 # every symbol include/bt_hip.h declares (tests check the library exports all of them)

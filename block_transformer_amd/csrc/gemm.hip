@@ -2938,7 +2938,7 @@ struct SkWalk {          // wave-uniform: the items of this workgroup's run [lo,
     __device__ inline bool chain_last() const { return c == ce - 1; }
 };
 
-template <int MODE>
+template <int MODE, bool SERIAL_EPI = false>   // SERIAL_EPI: the round-5 item boundary (debug-build A/B reference, bt_debug_serial_epilogues)
 __global__ __launch_bounds__(512) void gemm_bf16_mfma256sk_kernel(const bf16* __restrict__ A, int64_t lda,
                                                                  const bf16* __restrict__ W, int64_t ldw, const EpiArgs ep,
                                                                  int tiles_m, int tiles_n, const SkArgs sk) {
@@ -3186,7 +3186,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256sk_kernel(const bf16* __
             // item boundary: W1 / A1 of the next item's K-tile 1 go out ahead of whatever this item stores (see the v2 kernel).  Round 6:
             // group 1's extra barrier sits BEHIND whatever it does at the boundary (epilogue, publish, consume), so that the two wave
             // groups do it at the same time instead of one after the other -- see the v2 kernel's tile boundary
-            if (!grp1) cbarrier();
+            if (!grp1 || SERIAL_EPI) cbarrier();
             issue2(I2{}, I3{}, false);
             advance();
             pre_issued = true;
@@ -3196,7 +3196,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256sk_kernel(const bf16* __
         const int cm0 = cw.m0, cn0 = cw.n0;
         if (more) cw.next(lo, C, tiles_m, tiles_n);
         if (!last) {                                       // the next item continues this tile in the same accumulators
-            if (more && grp1) cbarrier();
+            if (more && grp1 && !SERIAL_EPI) cbarrier();
             continue;
         }
         if (publish) {
@@ -3218,7 +3218,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256sk_kernel(const bf16* __
             if (vw != sk.dbg_drop_vw)                          // test hook: a producer that never arrives
 #endif
             sk_flag_store(sk.flags + (int64_t)(vw + 1) * 8 + wave, 1u);
-            if (more && grp1) cbarrier();
+            if (more && grp1 && !SERIAL_EPI) cbarrier();
             continue;
         }
         if (consume) {
@@ -3274,7 +3274,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256sk_kernel(const bf16* __
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         P::template epilogue<MODE>(ep, pos0, stage, acc, cm0, cn0 + wcol, wm, lane_e);
-        if (more && grp1) cbarrier();
+        if (more && grp1 && !SERIAL_EPI) cbarrier();
     }
     if (!grp1) cbarrier();
 }
@@ -4715,6 +4715,7 @@ BT_KNOB int g_sk = 1;
 #ifdef BT_DEBUG_HOOKS
 static void* g_timeline = nullptr;   // bt_debug_timeline_buffer: 4 workgroups x 8 waves x 128 stamps of 8 bytes (variant 28)
 #endif
+BT_KNOB bool g_serial_epi = false;   // debug build (bt_debug_serial_epilogues): the round-5 tile / item boundary of the persistent and stream-K kernels
 BT_KNOB int g_sk_drop_vw = -1;    // debug build (bt_debug_stream_k_drop): this publishing workgroup never raises its flags ...
 BT_KNOB int g_sk_spin = 0;        // ... and consumers give up after this many polls (0: SK_SPIN_LIMIT) -> the time-out path under test
 BT_KNOB int g_gemm_variant = 0;   // 0 auto; 1 force 128^2; 2/3 256^2 four-phase ring (plain/staggered); 4-8 timing ablations; 9/10 256^2
@@ -4926,9 +4927,21 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                 sk.dbg_spin = (uint32_t)g_sk_spin;
                 if (!sk_clean) BT_TRY(bt::sk_clear_flags(scratch, scratch_bytes, s));
                 const int tiles_m = (int)(M / BM2), tiles_n = (int)(N / BN2);
+#ifdef BT_DEBUG_HOOKS
+#define BT_LAUNCH_SK(MODE_)                                                                                                  \
+    do {                                                                                                                     \
+        if (g_serial_epi)                                                                                                    \
+            hipLaunchKernelGGL((gemm_bf16_mfma256sk_kernel<MODE_, true>), dim3(G), dim3(512), 0, s, (const bf16*)A, lda, (const bf16*)W, K, \
+                               ep, tiles_m, tiles_n, sk);                                                                    \
+        else                                                                                                                 \
+            hipLaunchKernelGGL((gemm_bf16_mfma256sk_kernel<MODE_>), dim3(G), dim3(512), 0, s, (const bf16*)A, lda, (const bf16*)W, K, ep, \
+                               tiles_m, tiles_n, sk);                                                                        \
+    } while (0)
+#else
 #define BT_LAUNCH_SK(MODE_)                                                                                                  \
     hipLaunchKernelGGL((gemm_bf16_mfma256sk_kernel<MODE_>), dim3(G), dim3(512), 0, s, (const bf16*)A, lda, (const bf16*)W, K, ep, \
                        tiles_m, tiles_n, sk)
+#endif
                 if (ep.q.enabled) BT_LAUNCH_SK(PP_QKV);
                 else if (act == BT_ACT_GELU) BT_LAUNCH_SK(PP_GELU);
                 else if (residual) BT_LAUNCH_SK(PP_RES);
@@ -5046,10 +5059,10 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
     else if (g_gemm_variant == 29) /* round 6 experiment: QKV epilogue, cos / sin rows of all 8 fragments in one batch */ \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 262144>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
-    else if (g_gemm_variant == 31) /* round 6 A/B: the round-5 tile boundary (epilogues of the two wave groups serialised) */ \
+    else if (g_gemm_variant == 94 || (g_gemm_variant == 0 && g_serial_epi)) /* round 6 A/B: the round-5 tile boundary (the two wave groups' epilogues serialised); bt_debug_serial_epilogues */ \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 1048576>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
-    else if (g_gemm_variant == 32) /* ... with the timeline stamps */                                                \
+    else if (g_gemm_variant == 95) /* ... with the timeline stamps */                                                \
         { ep.amax = (MODE_ == PP_ARGMAX) ? ep.amax : (uint2*)g_timeline;                                             \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 1048576 + 131072>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n); }                                 \
@@ -6172,6 +6185,7 @@ extern "C" void bt_debug_gemm_variant(int v) { g_gemm_variant = v; }
 extern "C" void bt_debug_stream_k(int on) { g_sk = on; }
 extern "C" void bt_debug_stream_k_drop(int vw, int spin) { g_sk_drop_vw = vw; g_sk_spin = spin; }
 extern "C" void bt_debug_timeline_buffer(void* buf) { g_timeline = buf; }
+extern "C" void bt_debug_serial_epilogues(int on) { g_serial_epi = on != 0; }
 extern "C" void bt_debug_gemm_max_wg(int n) { g_max_wg = n; }
 extern "C" void bt_debug_skinny_rows(int n) { g_skinny_rows = n; }
 extern "C" void bt_debug_small_stages(int n) { g_small_stages = n; }

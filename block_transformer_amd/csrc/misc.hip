@@ -628,6 +628,99 @@ extern "C" int bt_ceiling_mfma(const void* data, int64_t data_bytes, void* out, 
 }
 
 #ifdef BT_DEBUG_HOOKS
+// ---- round 6 probe: what would a grid-wide barrier cost a persistent <= 4-row decoder LAYER? -------------------------
+// One launch of `workgroups` resident workgroups x 256 threads runs `rounds` barrier rounds; between two barriers every workgroup
+// streams `bytes_per_wg` bytes of `stream_src` (16 B per lane, non-temporal; 0 = nothing) and publishes one 128-byte record that the
+// next round re-reads -- the shape of "GEMV phase -> hand its rows to every workgroup -> next phase".  mode 0: ONE device-scope counter
+// (monotonic, relaxed sc1 polls + s_sleep, release fence before the arrive, acquire fence after); mode 1: XCD-hierarchical -- a counter
+// per XCD (workgroup i sits on XCD i % 8 in a one-workgroup-per-CU launch), the last arriver of an XCD arrives at the top counter, the
+// last of those bumps the top generation, every XCD leader then bumps its XCD's generation and the other workgroups poll that word
+// (their own L2).  state: >= 64 uint32 words per XCD slot + 64 for the top, zeroed by the caller; ticks = s_memrealtime (100 MHz) of
+// workgroup 0 around the loop.
+__global__ __launch_bounds__(256) void grid_barrier_probe_kernel(uint32_t* state, uint32_t* records, const uint4* stream_src, int64_t bytes_per_wg,
+                                                                 int rounds, int mode, uint64_t* ticks, float* sink) {
+    const int G = gridDim.x, bid = blockIdx.x, tid = threadIdx.x;
+    const int xcd = bid & 7, n_x = (G >> 3) + ((G & 7) > xcd ? 1 : 0);
+    uint32_t* top_cnt = state;              // [0] counter, [32] generation
+    uint32_t* x_cnt = state + 64 * (1 + xcd);
+    float acc = 0.f;
+    uint64_t t0 = 0;
+    if (bid == 0 && tid == 0) t0 = __builtin_amdgcn_s_memrealtime();
+    for (int r = 0; r < rounds; ++r) {
+        // phase work: stream this workgroup's slice, re-read the previous round's record of the "next" workgroup, publish its own
+        const int64_t n16 = bytes_per_wg / 16;
+        const uint4* src = stream_src + (int64_t)bid * n16;
+        for (int64_t i = tid; i < n16; i += 256) {
+            typedef unsigned int pu32x4_t __attribute__((ext_vector_type(4)));
+            const pu32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const pu32x4_t*>(src + i));
+            acc += __uint_as_float(v.x ^ v.y ^ v.z ^ v.w);
+        }
+        if (tid < 32) {
+            const uint32_t seen = __hip_atomic_load(records + (int64_t)((bid + 1) % G) * 32 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            acc += (float)seen;
+            __hip_atomic_store(records + (int64_t)bid * 32 + tid, (uint32_t)(r + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const uint32_t gen = (uint32_t)(r + 1);
+            if (mode == 0) {
+                __hip_atomic_fetch_add(top_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                while (__hip_atomic_load(top_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen * (uint32_t)G) __builtin_amdgcn_s_sleep(2);
+            } else {
+                const uint32_t old = __hip_atomic_fetch_add(x_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == gen * (uint32_t)n_x - 1u) {             // last arriver of this XCD: arrive at the top, wait for its generation
+                    const uint32_t told = __hip_atomic_fetch_add(top_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (told == gen * 8u - 1u) __hip_atomic_store(top_cnt + 32, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    while (__hip_atomic_load(top_cnt + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) __builtin_amdgcn_s_sleep(1);
+                    __hip_atomic_store(x_cnt + 32, gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    while (__hip_atomic_load(x_cnt + 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < gen) __builtin_amdgcn_s_sleep(1);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+    }
+    if (bid == 0 && tid == 0) {
+        ticks[0] = __builtin_amdgcn_s_memrealtime() - t0;
+    }
+    if (acc == 12345.678f) sink[bid] = acc;
+}
+
+extern "C" int bt_debug_grid_barrier_probe(void* state, void* records, const void* stream_src, int64_t bytes_per_wg, int32_t workgroups,
+                                           int32_t rounds, int32_t mode, void* ticks, void* sink, bt_stream stream) {
+    BT_CHECK_ARG(state && records && ticks && sink && workgroups >= 8 && rounds > 0 && bytes_per_wg % 16 == 0, "bt_debug_grid_barrier_probe: bad argument");
+    hipLaunchKernelGGL(grid_barrier_probe_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (uint32_t*)state, (uint32_t*)records,
+                       (const uint4*)stream_src, bytes_per_wg, rounds, mode, (uint64_t*)ticks, (float*)sink);
+    BT_LAUNCH_CHECK("grid barrier probe launch");
+    return BT_OK;
+}
+// the launch-per-phase counterpart: one phase (the same streaming + record work, no barrier) per launch; the caller captures a chain of them
+__global__ __launch_bounds__(256) void phase_probe_kernel(uint32_t* records, const uint4* stream_src, int64_t bytes_per_wg, int r, float* sink) {
+    const int G = gridDim.x, bid = blockIdx.x, tid = threadIdx.x;
+    float acc = 0.f;
+    const int64_t n16 = bytes_per_wg / 16;
+    const uint4* src = stream_src + (int64_t)bid * n16;
+    for (int64_t i = tid; i < n16; i += 256) {
+        typedef unsigned int pu32x4_t __attribute__((ext_vector_type(4)));
+        const pu32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const pu32x4_t*>(src + i));
+        acc += __uint_as_float(v.x ^ v.y ^ v.z ^ v.w);
+    }
+    if (tid < 32) {
+        acc += (float)records[(int64_t)((bid + 1) % G) * 32 + tid];
+        records[(int64_t)bid * 32 + tid] = (uint32_t)(r + 1);
+    }
+    if (acc == 12345.678f) sink[bid] = acc;
+}
+extern "C" int bt_debug_phase_probe(void* records, const void* stream_src, int64_t bytes_per_wg, int32_t workgroups, int32_t r, void* sink,
+                                    bt_stream stream) {
+    hipLaunchKernelGGL(phase_probe_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (uint32_t*)records, (const uint4*)stream_src,
+                       bytes_per_wg, r, (float*)sink);
+    BT_LAUNCH_CHECK("phase probe launch");
+    return BT_OK;
+}
+
 extern "C" int bt_debug_tr_probe(const void* in, const void* addr, void* out, bt_stream stream) {
     hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const short*)in, (const int*)addr,
                        (short*)out);

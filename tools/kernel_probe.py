@@ -529,8 +529,8 @@ def main():
         tab = ops.rope_tables(1024, rot, 10000.0, DEV)
         buf = torch.zeros(4 * 8 * 128, dtype=torch.int64, device=DEV)
         hooks.bt_debug_timeline_buffer(ptr(buf))
-        # --variant 32: the round-5 tile boundary (the two wave groups' epilogues one after the other); default 28: the round-6 boundary
-        tl_variant = 32 if args.variant == 32 else 28
+        # --variant 95: the round-5 tile boundary (the two wave groups' epilogues one after the other); default 28: the round-6 boundary
+        tl_variant = 95 if args.variant == 95 else 28
         for (mode, M, N, K) in (("plain", 32768, 6144, 2048), ("gelu", 32768, 8192, 2048), ("qkv", 32768, 6144, 2048), ("res", 32768, 2048, 2048),
                                 ("plain", 4096, 8192, 2048), ("gelu", 4096, 8192, 2048), ("qkv", 4096, 6144, 2048), ("qkv2", 8192, 6144, 2048)):
             x = torch.randn(M, K, device=DEV).bfloat16()
@@ -563,7 +563,7 @@ def main():
             # tiles of workgroups 0 .. 3 (the first of every round); slots beyond hold whatever an earlier launch left in that LDS
             nt = min(12, -(-(-(-M // 256) * -(-N // 256)) // 256))
             span = int(st[:, :, :nt].max() - st[:, :, :nt][st[:, :, :nt] != 0].min())
-            rec = {"op": "pp_timeline", "boundary": "round 5 (serial epilogues)" if tl_variant == 32 else "round 6", "mode": mode, "M": M, "N": N, "K": K, "tiles_per_workgroup": nt, "us_production": round(us_prod, 1),
+            rec = {"op": "pp_timeline", "boundary": "round 5 (serial epilogues)" if tl_variant == 95 else "round 6", "mode": mode, "M": M, "N": N, "K": K, "tiles_per_workgroup": nt, "us_production": round(us_prod, 1),
                    "us_with_stamps": round(us_tl, 1), "span_ticks_wg0_3": span, "ns_per_tick_if_span_is_the_launch": round(us_tl * 1e3 / max(span, 1), 3)}
             names = ["0>1 wait+reads (0,0)", "1>2 cluster (0,0) issue", "2>3 to cluster (0,1)", "3>4 to cluster (1,0)", "4>5 K-tiles 1..nk-2",
                      "5>6 last K-tile to its 2nd cluster", "6>7 last cluster issue", "7>8 boundary barrier + pre-issue", "8>9 epilogue",

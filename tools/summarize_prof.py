@@ -53,6 +53,32 @@ def stats(args):
             print(f"| `{_short(name, 70)}` | {g} | {c} | {s:.2f} | {a:.2f} |")
 
 
+def gaps(args):
+    """Idle time between consecutive kernels of a trace (end of one -> start of the next, same queue order): what the dependent launch
+    boundaries inside the captured block step cost.  Gaps above --max-gap-us are host-side (graph launch, sync) and are reported apart."""
+    cur = _db(args.path)
+    rows = cur.execute("select name, start, end from kernels order by start").fetchall()
+    if args.skip_first:
+        rows = rows[int(len(rows) * args.skip_first):]
+    g, by_pred = [], {}
+    host = 0
+    for (n0, s0, e0), (n1, s1, e1) in zip(rows, rows[1:]):
+        d = (s1 - e0) / 1e3
+        if d > args.max_gap_us:
+            host += 1
+            continue
+        g.append(d)
+        by_pred.setdefault(_short(n0, 60), []).append(d)
+    g.sort()
+    tot_k = sum(e - s for _, s, e in rows) / 1e3
+    out = {"kernels": len(rows), "device_side_boundaries": len(g), "host_side_gaps": host, "sum_kernel_us": round(tot_k, 1),
+           "sum_gap_us": round(sum(g), 1), "gap_share_of_busy_span": round(sum(g) / (tot_k + sum(g)), 4),
+           "gap_us": {"median": round(g[len(g) // 2], 3), "mean": round(sum(g) / len(g), 3), "p10": round(g[len(g) // 10], 3),
+                      "p90": round(g[len(g) * 9 // 10], 3)},
+           "median_gap_us_after_kernel": {k: round(sorted(v)[len(v) // 2], 3) for k, v in sorted(by_pred.items(), key=lambda kv: -len(kv[1]))[:10]}}
+    print(json.dumps(out, indent=1))
+
+
 def _pmc(path, kernel):
     cur = _db(path)
     rows = cur.execute("select counter_name, avg(value), avg(duration), count(*) from counters_collection "
@@ -103,6 +129,11 @@ def main():
     a.add_argument("--top", type=int, default=14)
     a.add_argument("--by-grid", default="gemm_bf16")
     a.set_defaults(fn=stats)
+    a = sub.add_parser("gaps")
+    a.add_argument("path")
+    a.add_argument("--max-gap-us", type=float, default=40.0)
+    a.add_argument("--skip-first", type=float, default=0.5, help="fraction of the trace to skip (warm-up, prefill of the first generate)")
+    a.set_defaults(fn=gaps)
     a = sub.add_parser("pmc")
     a.add_argument("path")
     a.add_argument("--kernel", required=True)
