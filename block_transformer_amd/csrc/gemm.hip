@@ -1625,9 +1625,22 @@ struct RowSplit {
 
 // EABL (debug timing ablations, wrong results): 1 = no global stores, 2 = no LDS transposes (the packed registers are stored as is);
 // 16 (correct results, A/B): QKV mode with the generic per-lane K / V addresses
+// EABL 256 (timeline variant): s_memtime stamps at LDS byte address tl + 8 * event (tl = 0: none) -- events 10 .. 12 inside the epilogue
+template <int EABL>
+__device__ inline void epi_stamp(uint32_t tl, int ev) {
+    if constexpr ((EABL & 256) != 0) {
+        if (tl != 0) {
+            uint64_t tm;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm) : : "memory");
+            const uint32_t a = tl + (uint32_t)ev * 8u;
+            asm volatile("ds_write_b64 %0, %1" : : "v"(a), "v"(tm) : "memory");
+        }
+    }
+}
+
 template <int MODE, int EABL = 0>
 __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x4_t (&acc)[8][4], int cm0, int n_wave, int wm,
-                                   int lane) {
+                                   int lane, uint32_t tl = 0) {
     const int M = e.M, N = e.N;
     constexpr bool qkv = MODE == PP_QKV;
     if constexpr ((EABL & 32) != 0) {
@@ -1661,7 +1674,7 @@ __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x
             }
         }
     }
-    // ---- sweep A ----  (two batches of 4 fragments: 32 transient registers, two exposed load latencies)
+    // ---- sweep A ----
     if (qkv) {
         const int D = e.q.head_dim;
         bool rot[2];
@@ -1689,9 +1702,11 @@ __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x
 #pragma unroll
                 for (int ai = 0; ai < 8; ++ai) rpos[ai] = e.q.pos_table[rpos[ai]];
             }
-            if constexpr ((EABL & 64) != 0) {
-                // round-6 experiment (variant 29): the cos / sin rows of all 8 fragments in flight together -- one exposed load latency per
-                // rotated column group instead of two (64 transient registers: the K-loop's fragment registers are dead here)
+            if constexpr ((EABL & 64) == 0) {
+                // round 6: the cos / sin rows of all 8 fragments in flight together -- one exposed load latency per rotated column group
+                // instead of two (64 transient registers: the K-loop's fragment registers are dead here): +1.2 ... 1.7 % on the prefill
+                // and both decode QKV shapes, bit-identical (profiles/r6_ppqkv_rope_one_batch_new_boundary.jsonl; EABL 64 = variant 29
+                // of the debug build keeps the round-5 two-batch form as the A/B reference)
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
                     if (!rot[pr]) continue;
@@ -1766,6 +1781,7 @@ __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x
         }
     }
     asm volatile("" ::: "memory");
+    epi_stamp<EABL>(tl, 10);     // sweep A done (RoPE applied / residual loads issued)
     // ---- sweep B ----
     const uint32_t patch_w = lds_addr(stage) + (lane & 15) * EPI_PITCH + (lane >> 4) * 8;
     const uint32_t patch_r = lds_addr(stage) + (lane >> 3) * EPI_PITCH + (lane & 7) * 16;
@@ -1822,8 +1838,10 @@ __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x
             }
         }
     }
+    epi_stamp<EABL>(tl, 11);     // store addressing set up
 #pragma unroll
     for (int ai = 0; ai < 8; ++ai) {
+        if (ai == 4) epi_stamp<EABL>(tl, 12);     // half of the fragments converted / transposed / stored
         const int row_l = (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16;
         uint2 o[4];
 #pragma unroll
@@ -2003,8 +2021,8 @@ struct Mma16 {
     }
     template <int MODE, int EABL = 0>
     __device__ static inline void epilogue(const EpiArgs& e, int pos0, char* stage, Acc (&acc)[8][4], int cm0, int n_wave,
-                                           int wm, int lane) {
-        pp_epilogue<MODE, EABL>(e, pos0, stage, acc, cm0, n_wave, wm, lane);
+                                           int wm, int lane, uint32_t tl = 0) {
+        pp_epilogue<MODE, EABL>(e, pos0, stage, acc, cm0, n_wave, wm, lane, tl);
     }
 };
 
@@ -2439,7 +2457,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
     // twelve tiles into 8 KiB of LDS behind the kernel's own (inline asm: the compiler must not see LDS traffic), and workgroups 0 .. 3
     // dump them to ep.amax (unused outside the ARGMAX mode) at the end.  Correct results; tools/kernel_probe.py pptl reads the buffer.
     constexpr bool TL = (ABL & 131072) != 0;
-    constexpr int TL_EV = 10, TL_TILES = 12;
+    constexpr int TL_EV = 13, TL_TILES = 9;
     // ABL bit 1048576 (variant 31 / 32 with the timeline): the round-5 tile boundary -- group 1's extra barrier in FRONT of its refill, i.e.
     // the two groups' epilogues one after the other (A/B reference of the round-6 boundary, bit-identical results)
     constexpr bool SERIAL_EPI = (ABL & 1048576) != 0;
@@ -2463,6 +2481,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
             }
         }
     };
+    if constexpr (TL) {     // slot 117: kernel entry (118: exit, 119: s_memrealtime at entry -- 100 MHz, comparable across workgroups)
+        uint64_t tm, rt;
+        asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm), "=s"(rt) : : "memory");
+        asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:16" : : "v"(tl_lds + 117u * 8u), "v"(tm), "v"(rt) : "memory");
+    }
     const uint32_t lane_slot = (uint32_t)(((lane & 7) ^ ((lane >> 3) & 7)) * 16);
     // lane part of a DMA address inside its 16-row group: row (lane >> 3) of rows 0..7 / 8..15, swizzled 16-byte slot
     const uint32_t voff_a_0 = (uint32_t)(lane >> 3) * (uint32_t)(lda * 2) + lane_slot;
@@ -2622,13 +2645,22 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
                 wait_vmcnt<(p ? PP2_WAIT_P1 : PP2_WAIT_P0)>();
             }
         }
-        cbarrier();
+        const char* buf = smem + (ST >= 0 ? ST * 4 * HALF_BYTES : (g & 2) * 2 * HALF_BYTES);
+        const bool do_reads = !(ABL & 2) || g == 0;
+        // Round 6: phase (0, 0) of every tile but the workgroup's first, group 0: accumulator init + fragment reads go IN FRONT of the
+        // phase's first barrier.  That barrier pairs with group 1's barrier behind its epilogue, i.e. group 0 used to sit there until
+        // group 1's epilogue was done and only then start ~1.5 k cycles of init + 24 ds_reads with the matrix pipe idle.  Legal: this
+        // wave's own share of K-tile 0 is covered by the wait above; group 1's share (and wave 0's wait for the bias row) were waited
+        // for before group 1's second barrier of the previous tile's final phase = the barrier group 0 passed at the tile boundary.
+        // (pre_issued is true exactly at t == 0 of such a tile.)  ABL 2097152 (variant 96): the round-5 order, A/B reference.
+        bool early = false;
+        if constexpr (PM == 0 && p == 0 && ST < 0 && (ABL & 2097152) == 0 && !SERIAL_EPI) early = !grp1 && t == 0 && pre_issued;
+        // (one copy of the phase body, the BARRIER moves: two call sites of the reads made hipcc keep both live and spill)
+        if (!early) cbarrier();
         if constexpr (TAIL) {
             if (ST >= 0 || tail_pending) run_tail(std::integral_constant<int, 1 - p>{});
             tail_pending = true;
         }
-        const char* buf = smem + (ST >= 0 ? ST * 4 * HALF_BYTES : (g & 2) * 2 * HALF_BYTES);
-        const bool do_reads = !(ABL & 2) || g == 0;
         if (ABL & 16384) __builtin_amdgcn_s_setprio(2);   // experiment (variant 25): the off-turn (reads + DMA issue) at raised priority
         if constexpr ((ABL & 4096) != 0 && ST >= 0) {
             // experiment (variant 23): the four DMA instructions spread among the fragment reads instead of behind them
@@ -2666,6 +2698,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
                     for (int i = 0; i < P::MI; ++i) af[i][ks] = P::read_a(buf, wm, i, ks, lane);
                 }
             }
+            if (early) cbarrier();       // the phase's first barrier, behind the reads (group 0, phase (0, 0) of a later tile)
             if constexpr (ST >= 0) {     // the cursor stands one K-tile ahead: the other ring stage
                 issue1_fast(I2{}, std::integral_constant<int, 1 - ST>{});
                 if constexpr (!DMAC) {
@@ -2811,6 +2844,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
             // second barrier of the final phase has issued its final reads, and group 0's were issued a barrier earlier -- so its
             // extra barrier (the count must match group 0's: the stagger) moves BEHIND its epilogue: both groups now run their
             // epilogues at the same time, group 1's starting when its last MFMA cluster is issued.
+            // (group 0 reads the next tile's phase (0, 0) in front of that phase's first barrier, see phase(): every group-0 wave's own
+            //  share of those half-tiles must have landed before a barrier all of them pass -- this one.  Same immediate and same point
+            //  in the wave's timeline as the top-of-phase wait of any steady-state phase: right behind its MFMA cluster, six instructions
+            //  -- A1 of K-tile 0, A0 / W0 of K-tile 1 -- younger than what it needs.)
+            if (!grp1 && !SERIAL_EPI && (ABL & 2097152) == 0) wait_vmcnt<PP2_WAIT_P0>();
             if (!grp1 || SERIAL_EPI) cbarrier();
             issue2(I2{}, I3{}, false);
             advance();
@@ -2821,22 +2859,29 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         stamp(j, 8);
-        P::template epilogue<MODE, (ABL >> 5) & 3 | ((ABL >> 6) & 12) | ((ABL >> 12) & 16) | (LNF ? 32 : 0) | ((ABL >> 12) & (64 | 128))>(ep, pos0, stage, acc, cm0, cn0 + wcol, wm, lane_e);
+        P::template epilogue<MODE, (ABL >> 5) & 3 | ((ABL >> 6) & 12) | ((ABL >> 12) & 16) | (LNF ? 32 : 0) | ((ABL >> 12) & (64 | 128)) | ((ABL >> 9) & 256)>(
+            ep, pos0, stage, acc, cm0, cn0 + wcol, wm, lane_e, (TL && j < TL_TILES) ? tl_lds + (uint32_t)(j * TL_EV) * 8u : 0u);
         stamp(j, 9);
         if (j + 1 < nt && grp1 && !SERIAL_EPI) cbarrier();
     }
     if (!grp1) cbarrier();
     if constexpr (TL) {   // every wave dumps its own 1 KiB of stamps (it wrote them itself: no barrier needed)
-        if (blockIdx.x < 4 && ep.amax != nullptr && MODE != PP_ARGMAX) {
+        {
+            uint64_t tm, rt;
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm), "=s"(rt) : : "memory");   // (stores acknowledged)
+            asm volatile("ds_write_b64 %0, %1\n\tds_write_b64 %0, %2 offset:16" : : "v"(tl_lds + 118u * 8u), "v"(tm), "v"(rt) : "memory");
+        }
+        if ((blockIdx.x < 4 || blockIdx.x >= gridDim.x - 4) && ep.amax != nullptr && MODE != PP_ARGMAX) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            uint64_t* dst = reinterpret_cast<uint64_t*>(ep.amax) + ((int64_t)blockIdx.x * 8 + wave) * 128;
+            const int slot = blockIdx.x < 4 ? (int)blockIdx.x : 4 + (int)(blockIdx.x - (gridDim.x - 4));   // first four and last four workgroups
+            uint64_t* dst = reinterpret_cast<uint64_t*>(ep.amax) + ((int64_t)slot * 8 + wave) * 128;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const int idx = lane + h * 64;
                 uint64_t v;
                 const uint32_t a = tl_lds + (uint32_t)idx * 8u;
                 asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
-                if (idx < TL_EV * TL_TILES) dst[idx] = v;
+                if (idx < TL_EV * TL_TILES + 4) dst[idx] = v;
             }
         }
     }
@@ -3089,8 +3134,11 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256sk_kernel(const bf16* __
                 wait_vmcnt<(p ? PP2_WAIT_P1 : PP2_WAIT_P0)>();
             }
         }
-        cbarrier();
         const char* buf = smem + (ST >= 0 ? ST * 4 * HALF_BYTES : (g & 2) * 2 * HALF_BYTES);
+        // phase (0, 0) of every item but the first, group 0: init + fragment reads in front of the phase's first barrier (see the v2 kernel)
+        bool early = false;
+        if constexpr (PM == 0 && p == 0 && ST < 0 && !SERIAL_EPI) early = !grp1 && t == 0 && pre_issued;
+        if (!early) cbarrier();
         if constexpr (p == 0) {
             if constexpr (PM == 0) {
                 if (t == 0 && c_init)
@@ -3103,6 +3151,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256sk_kernel(const bf16* __
 #pragma unroll
                 for (int i = 0; i < P::MI; ++i) af[i][ks] = P::read_a(buf, wm, i, ks, lane);
             }
+            if (early) cbarrier();
             if constexpr (ST >= 0) {     // the cursor stands one K-tile ahead: the other ring stage
                 issue1_fast(I2{}, std::integral_constant<int, 1 - ST>{});
                 issue1_fast(I3{}, std::integral_constant<int, 1 - ST>{});
@@ -3186,6 +3235,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256sk_kernel(const bf16* __
             // item boundary: W1 / A1 of the next item's K-tile 1 go out ahead of whatever this item stores (see the v2 kernel).  Round 6:
             // group 1's extra barrier sits BEHIND whatever it does at the boundary (epilogue, publish, consume), so that the two wave
             // groups do it at the same time instead of one after the other -- see the v2 kernel's tile boundary
+            if (!grp1 && !SERIAL_EPI) wait_vmcnt<PP2_WAIT_P0>();   // own share of the next item's phase (0, 0): read in front of its first barrier
             if (!grp1 || SERIAL_EPI) cbarrier();
             issue2(I2{}, I3{}, false);
             advance();
@@ -5056,11 +5106,14 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
         { ep.amax = (MODE_ == PP_ARGMAX) ? ep.amax : (uint2*)g_timeline;                                             \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 131072>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n); }                                 \
-    else if (g_gemm_variant == 29) /* round 6 experiment: QKV epilogue, cos / sin rows of all 8 fragments in one batch */ \
+    else if (g_gemm_variant == 29) /* round 6 A/B: QKV epilogue with the round-5 RoPE loads (two batches of four fragments) */ \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 262144>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
     else if (g_gemm_variant == 94 || (g_gemm_variant == 0 && g_serial_epi)) /* round 6 A/B: the round-5 tile boundary (the two wave groups' epilogues serialised); bt_debug_serial_epilogues */ \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 1048576>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
+                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
+    else if (g_gemm_variant == 96) /* round 6 A/B: group 0's phase-(0,0) init + reads behind the first barrier (round-5 order) */ \
+        hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 2097152>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
     else if (g_gemm_variant == 95) /* ... with the timeline stamps */                                                \
         { ep.amax = (MODE_ == PP_ARGMAX) ? ep.amax : (uint2*)g_timeline;                                             \

@@ -517,7 +517,7 @@ def main():
         hooks.bt_debug_gemm_variant(0)
     elif args.what == "pptl":
         # round 6: the tile-boundary TIMELINE of the persistent kernel (debug variant 28: every wave stamps s_memtime at ten points of each
-        # of its first twelve tiles; workgroups 0 .. 3 dump).  Per mode and shape: the median over tiles 1 .. nt - 2 and the 8 waves of the
+        # of its first nine tiles; workgroups 0 .. 3 dump).  Per mode and shape: the median over tiles 1 .. nt - 2 and the 8 waves of the
         # intervals between consecutive stamps, in shader-clock cycles (s_memtime ticks at 100 MHz on this part: converted with the
         # launch's measured duration / its span in ticks) -- where the time between a tile's last MFMA cluster and the next tile's
         # first one goes.  Events: 0 top of phase (0,0), 1 cluster (0,0) opens, 2 its 32 MFMAs issued, 3 cluster (0,1) opens,
@@ -527,7 +527,7 @@ def main():
         heads, d, rot = 16, 128, 32
         H = heads * d
         tab = ops.rope_tables(1024, rot, 10000.0, DEV)
-        buf = torch.zeros(4 * 8 * 128, dtype=torch.int64, device=DEV)
+        buf = torch.zeros(8 * 8 * 128, dtype=torch.int64, device=DEV)      # first four + last four workgroups x 8 waves x 128 stamps
         hooks.bt_debug_timeline_buffer(ptr(buf))
         # --variant 95: the round-5 tile boundary (the two wave groups' epilogues one after the other); default 28: the round-6 boundary
         tl_variant = 95 if args.variant == 95 else 28
@@ -559,16 +559,32 @@ def main():
             call()
             torch.cuda.synchronize()
             hooks.bt_debug_gemm_variant(0)
-            st = buf.view(4, 8, 128)[:, :, :120].reshape(4, 8, 12, 10).cpu()
+            raw = buf.view(8, 8, 128).cpu()
+            st = raw[:4, :, :117].reshape(4, 8, 9, 13)
             # tiles of workgroups 0 .. 3 (the first of every round); slots beyond hold whatever an earlier launch left in that LDS
-            nt = min(12, -(-(-(-M // 256) * -(-N // 256)) // 256))
+            nt = min(9, -(-(-(-M // 256) * -(-N // 256)) // 256))
             span = int(st[:, :, :nt].max() - st[:, :, :nt][st[:, :, :nt] != 0].min())
             rec = {"op": "pp_timeline", "boundary": "round 5 (serial epilogues)" if tl_variant == 95 else "round 6", "mode": mode, "M": M, "N": N, "K": K, "tiles_per_workgroup": nt, "us_production": round(us_prod, 1),
                    "us_with_stamps": round(us_tl, 1), "span_ticks_wg0_3": span, "ns_per_tick_if_span_is_the_launch": round(us_tl * 1e3 / max(span, 1), 3)}
+            # kernel entry / exit (slots 117 / 118: s_memtime; 119 / 120: s_memrealtime, 100 MHz) of the first and last four workgroups
+            nt_all = -(-(-(-M // 256) * -(-N // 256)) // 256)
+            ent, ext, rt0, rt1 = raw[:, :, 117], raw[:, :, 118], raw[:, :, 119], raw[:, :, 120]
+            rec["kernel_cycles_median"] = float((ext - ent).float().median())
+            rec["fill_cycles_entry_to_first_phase_median"] = float((raw[:4, :, 0] - ent[:4]).float().median())
+            if nt_all <= 9:
+                last_e9 = raw[:4, :, (nt_all - 1) * 13 + 9]
+                rec["tail_cycles_last_epilogue_end_to_exit_median"] = float((ext[:4] - last_e9).float().median())
+                rec["last_epilogue_cycles_median"] = float((last_e9 - raw[:4, :, (nt_all - 1) * 13 + 8]).float().median())
+            rec["realtime_us"] = {"first_entry_to_last_exit": float(rt1.max() - rt0.min()) * 0.01,
+                                  "entry_skew_first4_vs_last4": float(rt0[4:].float().mean() - rt0[:4].float().mean()) * 0.01,
+                                  "exit_skew_first4_vs_last4": float(rt1[4:].float().mean() - rt1[:4].float().mean()) * 0.01,
+                                  "per_workgroup_resident": float((rt1 - rt0).float().median()) * 0.01}
             names = ["0>1 wait+reads (0,0)", "1>2 cluster (0,0) issue", "2>3 to cluster (0,1)", "3>4 to cluster (1,0)", "4>5 K-tiles 1..nk-2",
                      "5>6 last K-tile to its 2nd cluster", "6>7 last cluster issue", "7>8 boundary barrier + pre-issue", "8>9 epilogue",
                      "9>0' next tile's phase (0,0) top", "7>1' last cluster issued -> next tile's first cluster opens", "1>1' whole tile"]
             iv = {n: [] for n in names}
+            # inside the epilogue (events 10 .. 12): sweep A = RoPE / residual loads, set-up of the store addressing, fragments 0-3, 4-7
+            epi_parts = {"8>10 epilogue sweep A": (8, 10), "10>11 store set-up": (10, 11), "11>12 fragments 0-3": (11, 12), "12>9 fragments 4-7": (12, 9)}
             per_wave_epi = [[] for _ in range(8)]
             for wg in range(4):
                 for wv in range(8):
@@ -578,6 +594,8 @@ def main():
                         for e in range(9):
                             iv[names[e]].append(t[e + 1] - t[e])
                         per_wave_epi[wv].append(t[9] - t[8])
+                        for n, (a, b) in epi_parts.items():
+                            iv.setdefault(n, []).append(t[b] - t[a])
                         if nx is not None and nx[0]:
                             iv[names[9]].append(nx[0] - t[9])
                             iv[names[10]].append(nx[1] - t[7])
