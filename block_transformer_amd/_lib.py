@@ -183,6 +183,7 @@ _DEBUG_SIGS = {
     "bt_debug_stream_k_drop": (None, [c_int, c_int]),
     "bt_debug_timeline_buffer": (None, [c_void_p]),
     "bt_debug_serial_epilogues": (None, [c_int]),
+    "bt_debug_sk_diag_buffer": (None, [c_void_p]),
     "bt_debug_no_two_branch": (None, [c_int]),
     "bt_debug_ln_streaming": (None, [c_int]),
     "bt_debug_tr_probe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -360,7 +360,7 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
         }
     }
     // a consumer of a stream-K hand-off that gave up waiting -> BT_DEV_ERR_HANDOFF_TIMEOUT in the caller's sticky error word
-    if (sk_ws && attn->err_flag) BT_TRY(sk_status(scratch, sk_bytes, attn->err_flag, (hipStream_t)stream));
+    if (sk_ws && attn->err_flag) BT_TRY(sk_status(scratch, sk_bytes, attn->err_flag, (hipStream_t)stream, (uint32_t)M | ((uint32_t)q_len << 24)));
     // final_layer_norm of the rows the caller consumes
     const int count = q_len - first_out_row;
     if (first_out_row == 0) {

@@ -2647,16 +2647,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
         }
         const char* buf = smem + (ST >= 0 ? ST * 4 * HALF_BYTES : (g & 2) * 2 * HALF_BYTES);
         const bool do_reads = !(ABL & 2) || g == 0;
-        // Round 6: phase (0, 0) of every tile but the workgroup's first, group 0: accumulator init + fragment reads go IN FRONT of the
-        // phase's first barrier.  That barrier pairs with group 1's barrier behind its epilogue, i.e. group 0 used to sit there until
-        // group 1's epilogue was done and only then start ~1.5 k cycles of init + 24 ds_reads with the matrix pipe idle.  Legal: this
-        // wave's own share of K-tile 0 is covered by the wait above; group 1's share (and wave 0's wait for the bias row) were waited
-        // for before group 1's second barrier of the previous tile's final phase = the barrier group 0 passed at the tile boundary.
-        // (pre_issued is true exactly at t == 0 of such a tile.)  ABL 2097152 (variant 96): the round-5 order, A/B reference.
-        bool early = false;
-        if constexpr (PM == 0 && p == 0 && ST < 0 && (ABL & 2097152) == 0 && !SERIAL_EPI) early = !grp1 && t == 0 && pre_issued;
-        // (one copy of the phase body, the BARRIER moves: two call sites of the reads made hipcc keep both live and spill)
-        if (!early) cbarrier();
+        cbarrier();
         if constexpr (TAIL) {
             if (ST >= 0 || tail_pending) run_tail(std::integral_constant<int, 1 - p>{});
             tail_pending = true;
@@ -2698,7 +2689,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
                     for (int i = 0; i < P::MI; ++i) af[i][ks] = P::read_a(buf, wm, i, ks, lane);
                 }
             }
-            if (early) cbarrier();       // the phase's first barrier, behind the reads (group 0, phase (0, 0) of a later tile)
             if constexpr (ST >= 0) {     // the cursor stands one K-tile ahead: the other ring stage
                 issue1_fast(I2{}, std::integral_constant<int, 1 - ST>{});
                 if constexpr (!DMAC) {
@@ -2844,11 +2834,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
             // second barrier of the final phase has issued its final reads, and group 0's were issued a barrier earlier -- so its
             // extra barrier (the count must match group 0's: the stagger) moves BEHIND its epilogue: both groups now run their
             // epilogues at the same time, group 1's starting when its last MFMA cluster is issued.
-            // (group 0 reads the next tile's phase (0, 0) in front of that phase's first barrier, see phase(): every group-0 wave's own
-            //  share of those half-tiles must have landed before a barrier all of them pass -- this one.  Same immediate and same point
-            //  in the wave's timeline as the top-of-phase wait of any steady-state phase: right behind its MFMA cluster, six instructions
-            //  -- A1 of K-tile 0, A0 / W0 of K-tile 1 -- younger than what it needs.)
-            if (!grp1 && !SERIAL_EPI && (ABL & 2097152) == 0) wait_vmcnt<PP2_WAIT_P0>();
             if (!grp1 || SERIAL_EPI) cbarrier();
             issue2(I2{}, I3{}, false);
             advance();
@@ -2928,6 +2913,7 @@ struct SkArgs {
                          // (SK_TIMEOUT_MAGIC once any consumer gave up; cleared by sk_reset only, never by the per-launch sk_clear_flags)
     int dbg_drop_vw;     // debug build: the publishing workgroup with this virtual id never raises its flags (-1: none) -> its consumer
     uint32_t dbg_spin;   //              times out after dbg_spin polls (0: SK_SPIN_LIMIT); the product build ignores both
+    uint32_t* dbg_diag;  // debug build (bt_debug_sk_diag_buffer): [0] = count, then 8 words per recorded time-out; never cleared by the library
 };
 constexpr int SK_SLAB_FLOATS = 8 * 32 * 64 * 4;          // 256 KiB per workgroup
 constexpr uint32_t SK_SPIN_LIMIT = 1u << 20;              // polls (x ~1 us) before a consumer gives up and flags the launch
@@ -3135,10 +3121,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256sk_kernel(const bf16* __
             }
         }
         const char* buf = smem + (ST >= 0 ? ST * 4 * HALF_BYTES : (g & 2) * 2 * HALF_BYTES);
-        // phase (0, 0) of every item but the first, group 0: init + fragment reads in front of the phase's first barrier (see the v2 kernel)
-        bool early = false;
-        if constexpr (PM == 0 && p == 0 && ST < 0 && !SERIAL_EPI) early = !grp1 && t == 0 && pre_issued;
-        if (!early) cbarrier();
+        cbarrier();
         if constexpr (p == 0) {
             if constexpr (PM == 0) {
                 if (t == 0 && c_init)
@@ -3151,7 +3134,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256sk_kernel(const bf16* __
 #pragma unroll
                 for (int i = 0; i < P::MI; ++i) af[i][ks] = P::read_a(buf, wm, i, ks, lane);
             }
-            if (early) cbarrier();
             if constexpr (ST >= 0) {     // the cursor stands one K-tile ahead: the other ring stage
                 issue1_fast(I2{}, std::integral_constant<int, 1 - ST>{});
                 issue1_fast(I3{}, std::integral_constant<int, 1 - ST>{});
@@ -3235,7 +3217,6 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256sk_kernel(const bf16* __
             // item boundary: W1 / A1 of the next item's K-tile 1 go out ahead of whatever this item stores (see the v2 kernel).  Round 6:
             // group 1's extra barrier sits BEHIND whatever it does at the boundary (epilogue, publish, consume), so that the two wave
             // groups do it at the same time instead of one after the other -- see the v2 kernel's tile boundary
-            if (!grp1 && !SERIAL_EPI) wait_vmcnt<PP2_WAIT_P0>();   // own share of the next item's phase (0, 0): read in front of its first barrier
             if (!grp1 || SERIAL_EPI) cbarrier();
             issue2(I2{}, I3{}, false);
             advance();
@@ -3292,6 +3273,19 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256sk_kernel(const bf16* __
                 // bt_stream_k_status turn it into BT_DEV_ERR_HANDOFF_TIMEOUT and the host discards the pass.  The flag word stays as
                 // it is -- a producer that arrives late leaves it at 1, and whoever runs next on this scratch starts from sk_reset.
                 sk_flag_store(sk.flags + (int64_t)G * 8, SK_TIMEOUT_MAGIC);
+                sk_flag_store(sk.flags + (int64_t)G * 8 + 1, (uint32_t)vw);            // who gave up (last writer wins): diagnostics only
+                sk_flag_store(sk.flags + (int64_t)G * 8 + 2, (uint32_t)wave | ((uint32_t)MODE << 8) | ((uint32_t)nt << 16));
+                sk_flag_store(sk.flags + (int64_t)G * 8 + 3, (uint32_t)tiles_m | ((uint32_t)tiles_n << 16));
+#ifdef BT_DEBUG_HOOKS
+                if (sk.dbg_diag != nullptr && lane == 0) {
+                    const uint32_t slot = atomicAdd(sk.dbg_diag, 1u);
+                    if (slot < 64) {
+                        uint32_t* d = sk.dbg_diag + 8 + slot * 8;
+                        d[0] = (uint32_t)vw; d[1] = (uint32_t)wave; d[2] = (uint32_t)MODE; d[3] = (uint32_t)nt;
+                        d[4] = (uint32_t)ep.M; d[5] = (uint32_t)ep.N; d[6] = (uint32_t)sk.nk; d[7] = (uint32_t)sk.C;
+                    }
+                }
+#endif
             } else {
             const float* slab = sk.slabs + ((int64_t)vw * 8 + wave) * (32 * 64 * 4);
             const __amdgpu_buffer_rsrc_t srs = tile_rsrc(reinterpret_cast<const char*>(slab));
@@ -4765,6 +4759,9 @@ BT_KNOB int g_sk = 1;
 #ifdef BT_DEBUG_HOOKS
 static void* g_timeline = nullptr;   // bt_debug_timeline_buffer: 4 workgroups x 8 waves x 128 stamps of 8 bytes (variant 28)
 #endif
+#ifdef BT_DEBUG_HOOKS
+static uint32_t* g_sk_diag = nullptr;
+#endif
 BT_KNOB bool g_serial_epi = false;   // debug build (bt_debug_serial_epilogues): the round-5 tile / item boundary of the persistent and stream-K kernels
 BT_KNOB int g_sk_drop_vw = -1;    // debug build (bt_debug_stream_k_drop): this publishing workgroup never raises its flags ...
 BT_KNOB int g_sk_spin = 0;        // ... and consumers give up after this many polls (0: SK_SPIN_LIMIT) -> the time-out path under test
@@ -4820,9 +4817,13 @@ static SkPlan sk_plan(int64_t M, int64_t N, int64_t K1, int64_t K2, int G) {
     }
     return p;
 }
-static int64_t sk_ws_bytes(int G) { return (int64_t)G * SK_SLAB_FLOATS * 4 + ((int64_t)G * 8 + 8) * 4; }
+// [G slabs][G * 8 flag words][32 words = one 128-byte line of its own for the sticky time-out word]: the region ends on a line boundary, so
+// the word never shares a cache line with whatever lies behind the scratch (round 6: in the token decoder's workspace that is the
+// activation area of the 2 B-row pass -- written by other XCDs' GEMM epilogues, i.e. a line some L2 may still hold from before the reset)
+constexpr int SK_TAIL_WORDS = 32;
+static int64_t sk_ws_bytes(int G) { return (int64_t)G * SK_SLAB_FLOATS * 4 + ((int64_t)G * 8 + SK_TAIL_WORDS) * 4; }
 namespace bt {
-// scratch layout of the stream-K kernel: [G slabs of 256 KiB][G * 8 flag words][sticky time-out word + 7 spare]; bt_decoder_forward
+// scratch layout of the stream-K kernel: [G slabs of 256 KiB][G * 8 flag words][sticky time-out word + 31 spare = its own 128-byte line]; bt_decoder_forward
 // sizes its scratch for it (engine.hip), zeroes flags + sticky word once per pass with sk_reset() and reports the sticky word at the end
 // of the pass with sk_status(); the kernels leave the flag words zero
 int64_t sk_scratch_bytes() { return sk_ws_bytes(num_cus()); }
@@ -4831,31 +4832,51 @@ bool sk_linear2_ok(int64_t M, int64_t N, int64_t K1, int64_t K2, int64_t scratch
     const int G = num_cus();
     return g_sk != 0 && M > 256 && scratch_bytes >= sk_ws_bytes(G) && sk_plan(M, N, K1, K2, G).ok;
 }
-// per launch (callers without sk_clean): the G * 8 hand-off flags only -- an unread time-out (the sticky word behind them) survives
-int sk_clear_flags(void* scratch, int64_t scratch_bytes, hipStream_t s) {
+// Clearing is a KERNEL of this library, not hipMemsetAsync (round 6): inside replayed hipGraphs the words behind the 8 KiB of flags were
+// found holding stale bytes at the end of a pass whose first node was a memset over them (profiles/r6_handoff_false_positive.md); a
+// one-workgroup kernel is something the library controls in eager and captured launches alike.
+__global__ __launch_bounds__(256) void sk_zero_kernel(uint32_t* words, int n) {
+    for (int i = threadIdx.x; i < n; i += 256) __hip_atomic_store(words + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static int sk_zero(void* scratch, int64_t scratch_bytes, hipStream_t s, int words) {
     const int G = num_cus();
     if (!scratch || scratch_bytes < sk_ws_bytes(G)) return BT_OK;
-    hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(scratch) + (int64_t)G * SK_SLAB_FLOATS * 4, 0, (size_t)G * 8 * 4, s);
-    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(stream-K flags)");
+    hipLaunchKernelGGL(sk_zero_kernel, dim3(1), dim3(256), 0, s,
+                       reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(scratch) + (int64_t)G * SK_SLAB_FLOATS * 4), words);
+    BT_LAUNCH_CHECK("stream-K flag clear launch");
     return BT_OK;
 }
+// per launch (callers without sk_clean): the G * 8 hand-off flags only -- an unread time-out (the sticky word behind them) survives
+int sk_clear_flags(void* scratch, int64_t scratch_bytes, hipStream_t s) { return sk_zero(scratch, scratch_bytes, s, num_cus() * 8); }
 // flags AND the sticky word: a fresh scratch (undefined bytes), the start of a bt_decoder_forward pass (which reports the word itself
 // at its end), or the caller's acknowledgement of a reported time-out
-int sk_reset(void* scratch, int64_t scratch_bytes, hipStream_t s) {
-    const int G = num_cus();
-    if (!scratch || scratch_bytes < sk_ws_bytes(G)) return BT_OK;
-    hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(scratch) + (int64_t)G * SK_SLAB_FLOATS * 4, 0, ((size_t)G * 8 + 8) * 4, s);
-    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(stream-K flags + sticky word)");
-    return BT_OK;
+int sk_reset(void* scratch, int64_t scratch_bytes, hipStream_t s) { return sk_zero(scratch, scratch_bytes, s, num_cus() * 8 + SK_TAIL_WORDS); }
+__global__ void sk_status_kernel(const uint32_t* sticky, int32_t* err_flag, uint32_t* diag, uint32_t tag) {
+    // agent-scope acquire + an agent-scope load: the word is written by the clearing kernel (some XCD) and by the GEMMs' sc1 stores, and
+    // must not be served from a line this XCD's L2 happens to hold from an earlier pass
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const uint32_t v = __hip_atomic_load(sticky, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (exactly the value a consumer that gave up stores: bytes nobody cleared are not a time-out)
+    if (v == SK_TIMEOUT_MAGIC) atomicOr(err_flag, (int32_t)BT_DEV_ERR_HANDOFF_TIMEOUT);
+    if (v != 0 && diag != nullptr) {     // debug build: what the word held and which pass saw it (tag = rows | q_len << 24 of the pass)
+        const uint32_t slot = atomicAdd(diag + 1, 1u);
+        if (slot < 8) {
+            uint32_t* d = diag + 8 + 64 * 8 + slot * 8;
+            d[0] = tag; d[1] = sticky[0]; d[2] = sticky[1]; d[3] = sticky[2]; d[4] = sticky[3]; d[5] = sticky[-1];
+            d[6] = (uint32_t)reinterpret_cast<uint64_t>(sticky); d[7] = (uint32_t)(reinterpret_cast<uint64_t>(sticky) >> 32);
+        }
+    }
 }
-__global__ void sk_status_kernel(const uint32_t* sticky, int32_t* err_flag) {
-    if (*sticky != 0) atomicOr(err_flag, (int32_t)BT_DEV_ERR_HANDOFF_TIMEOUT);
-}
-int sk_status(const void* scratch, int64_t scratch_bytes, int32_t* err_flag, hipStream_t s) {
+int sk_status(const void* scratch, int64_t scratch_bytes, int32_t* err_flag, hipStream_t s, uint32_t tag) {
     const int G = num_cus();
     if (!scratch || !err_flag || scratch_bytes < sk_ws_bytes(G)) return BT_OK;
     const uint32_t* sticky = reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(scratch) + (int64_t)G * SK_SLAB_FLOATS * 4) + (int64_t)G * 8;
-    hipLaunchKernelGGL(sk_status_kernel, dim3(1), dim3(1), 0, s, sticky, err_flag);
+#ifdef BT_DEBUG_HOOKS
+    uint32_t* diag = g_sk_diag;
+#else
+    uint32_t* diag = nullptr;
+#endif
+    hipLaunchKernelGGL(sk_status_kernel, dim3(1), dim3(1), 0, s, sticky, err_flag, diag, tag);
     BT_LAUNCH_CHECK("stream-K status launch");
     return BT_OK;
 }
@@ -4867,7 +4888,7 @@ extern "C" int bt_stream_k_reset(void* scratch, int64_t scratch_bytes, bt_stream
 }
 extern "C" int bt_stream_k_status(const void* scratch, int64_t scratch_bytes, int32_t* err_flag, bt_stream stream) {
     BT_CHECK_ARG(scratch_bytes >= 0 && (scratch || scratch_bytes == 0) && err_flag, "bt_stream_k_status: null pointer");
-    return bt::sk_status(scratch, scratch_bytes, err_flag, (hipStream_t)stream);
+    return bt::sk_status(scratch, scratch_bytes, err_flag, (hipStream_t)stream, 0u);
 }
 
 // amax (bt_logits_argmax): when the persistent kernel takes the problem, run its PP_ARGMAX epilogue (per-slab argmax partials
@@ -4975,6 +4996,9 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                 sk.flags = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(scratch) + (int64_t)G * SK_SLAB_FLOATS * 4);
                 sk.dbg_drop_vw = g_sk_drop_vw;
                 sk.dbg_spin = (uint32_t)g_sk_spin;
+#ifdef BT_DEBUG_HOOKS
+                sk.dbg_diag = g_sk_diag;
+#endif
                 if (!sk_clean) BT_TRY(bt::sk_clear_flags(scratch, scratch_bytes, s));
                 const int tiles_m = (int)(M / BM2), tiles_n = (int)(N / BN2);
 #ifdef BT_DEBUG_HOOKS
@@ -5111,9 +5135,6 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
     else if (g_gemm_variant == 94 || (g_gemm_variant == 0 && g_serial_epi)) /* round 6 A/B: the round-5 tile boundary (the two wave groups' epilogues serialised); bt_debug_serial_epilogues */ \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 1048576>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
-                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
-    else if (g_gemm_variant == 96) /* round 6 A/B: group 0's phase-(0,0) init + reads behind the first barrier (round-5 order) */ \
-        hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 2097152>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
     else if (g_gemm_variant == 95) /* ... with the timeline stamps */                                                \
         { ep.amax = (MODE_ == PP_ARGMAX) ? ep.amax : (uint2*)g_timeline;                                             \
@@ -6239,6 +6260,7 @@ extern "C" void bt_debug_stream_k(int on) { g_sk = on; }
 extern "C" void bt_debug_stream_k_drop(int vw, int spin) { g_sk_drop_vw = vw; g_sk_spin = spin; }
 extern "C" void bt_debug_timeline_buffer(void* buf) { g_timeline = buf; }
 extern "C" void bt_debug_serial_epilogues(int on) { g_serial_epi = on != 0; }
+extern "C" void bt_debug_sk_diag_buffer(void* buf) { g_sk_diag = (uint32_t*)buf; }
 extern "C" void bt_debug_gemm_max_wg(int n) { g_max_wg = n; }
 extern "C" void bt_debug_skinny_rows(int n) { g_skinny_rows = n; }
 extern "C" void bt_debug_small_stages(int n) { g_small_stages = n; }

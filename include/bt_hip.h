@@ -182,7 +182,7 @@ int64_t bt_stream_k_scratch_bytes(void);
  * necessarily beside another process's kernels.  A consumer that gives up does NOT add the (unwritten) slab: it sets a sticky
  * word inside `scratch`, and the results of that launch are incomplete.  The sticky word survives the per-launch clearing of the
  * flag words; it is how a caller of bt_linear_ws / bt_linear2_ws / bt_qkv_rope_append learns about it:
- *   bt_stream_k_reset   zero the flag words AND the sticky word (once after allocating `scratch`, whose bytes are otherwise
+ *   bt_stream_k_reset   zero the flag words AND the sticky word -- a one-workgroup kernel, not a memset (once after allocating `scratch`, whose bytes are otherwise
  *                       undefined, and to acknowledge a reported time-out);
  *   bt_stream_k_status  enqueue a one-thread kernel that ORs BT_DEV_ERR_HANDOFF_TIMEOUT into *err_flag (device int32) when the
  *                       sticky word of `scratch` is set; the host reads *err_flag whenever it synchronises anyway.

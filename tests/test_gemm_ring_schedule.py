@@ -291,21 +291,12 @@ def _pp2_stream(grp, wave0, nk, nt, full, stores, pd, has_bias, bad=None, dmac=F
                         n = PP2_WAIT[p] + (PP_STORES if (pm == 0 and prev_full) else 0)
                     if n is not None:
                         ev.append(("wait", n))
-                # round 6: group 0 reads phase (0, 0) of every tile but its first IN FRONT of the phase's first barrier (which pairs with
-                # group 1's barrier behind its epilogue); bad = "g1_barrier_first" = the round-5 boundary keeps the reads behind it
-                early = grp == 0 and p == 0 and t == 0 and pre_issued and bad != "g1_barrier_first"
-                x = g >> 1
-
-                def reads():
-                    if p == 0 and t == 0 and has_bias:
-                        ev.append(("read", ("bias", j)))
-                    for sidx in ([4 * x, 4 * x + 1, 4 * x + 2] if p == 0 else [4 * x + 3]):
-                        ev.append(("read", ("ld", sidx)))
-                if early:
-                    reads()
                 ev.append(("bar",))
-                if not early:
-                    reads()
+                if p == 0 and t == 0 and has_bias:
+                    ev.append(("read", ("bias", j)))
+                x = g >> 1
+                for sidx in ([4 * x, 4 * x + 1, 4 * x + 2] if p == 0 else [4 * x + 3]):
+                    ev.append(("read", ("ld", sidx)))
                 late = False
                 if p == 0 and t == 0 and pre_issued:
                     pre_issued = False
@@ -335,8 +326,6 @@ def _pp2_stream(grp, wave0, nk, nt, full, stores, pd, has_bias, bad=None, dmac=F
             # round 6: group 0's extra barrier in FRONT of the boundary refill, group 1's BEHIND its epilogue / publish (the two groups'
             # epilogues run side by side instead of one after the other); bad = "g1_barrier_first" is the round-5 order (also hazard-free:
             # the debug build keeps it as the A/B reference), "no_boundary_barrier" drops group 0's
-            if grp == 0 and bad not in ("g1_barrier_first", "no_early_wait"):
-                ev.append(("wait", PP2_WAIT[0]))   # own share of the next tile's phase (0, 0), read in front of that phase's first barrier
             if (grp == 0 and bad != "no_boundary_barrier") or (grp == 1 and bad == "g1_barrier_first"):
                 ev.append(("bar",))
             dma2()
@@ -423,8 +412,6 @@ def test_persistent_v2_model_detects_errors():
         pp_model(8, 3, [True] * 3, [PP_STORES] * 3, stream=functools.partial(_pp2_stream, bad="late_store_wait"))
     with pytest.raises(AssertionError):                   # boundary refill without its barrier: barrier counts / WAR break
         pp_model(8, 3, [True] * 3, [PP_STORES] * 3, stream=functools.partial(_pp2_stream, bad="no_boundary_barrier"))
-    with pytest.raises(AssertionError, match="RAW"):      # early reads of phase (0, 0) without the wait in front of the boundary barrier
-        pp_model(8, 3, [True] * 3, [PP_STORES] * 3, stream=functools.partial(_pp2_stream, bad="no_early_wait"))
     # the round-5 boundary (group 1's barrier in front of its refill: variant 94 of the debug build) is hazard-free too
     for nk in (4, 5, 8, 32):
         pp_model(nk, 3, [True] * 3, [PP_STORES] * 3, stream=functools.partial(_pp2_stream, bad="g1_barrier_first"))

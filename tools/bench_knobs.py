@@ -18,4 +18,31 @@ for kv in sys.argv[1:sep]:
     k, v = kv.split("=")
     getattr(lib(), "bt_debug_" + k)(int(v))
 sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[sep + 1:]
-runpy.run_path(sys.argv[0], run_name="__main__")
+diag = None
+if os.environ.get("BT_SK_DIAG") == "1":      # never-cleared record of stream-K hand-off time-outs (debug build), printed if the run dies
+    diag = torch.zeros(8 + 64 * 8 + 64, dtype=torch.int32, device="cuda")
+    lib().bt_debug_sk_diag_buffer(diag.data_ptr())
+try:
+    runpy.run_path(sys.argv[0], run_name="__main__")
+finally:
+    if diag is not None:
+        n = int(diag[0].item())
+        print(f"[bench_knobs] stream-K time-outs recorded on the device: {n}", file=sys.stderr)
+        for r in diag[8:8 + 8 * min(n, 16)].view(-1, 8).tolist():
+            print("[bench_knobs]   vw %d wave %d mode %d items/wg %d M %d N %d nk %d C %d" % tuple(r), file=sys.stderr)
+        m = int(diag[1].item())
+        print(f"[bench_knobs] passes whose sticky word was non-zero at their end: {m}", file=sys.stderr)
+        for r in diag[8 + 512:8 + 512 + 8 * min(m, 8)].view(-1, 8).tolist():
+            addr = (r[6] & 0xffffffff) | ((r[7] & 0xffffffff) << 32)
+            print("[bench_knobs]   pass rows %d q_len %d: sticky word at %#x holds %s, word before %s" % (r[0] & 0xffffff, (r[0] >> 24) & 0xff, addr,
+                  [hex(v & 0xffffffff) for v in r[1:5]], hex(r[5] & 0xffffffff)), file=sys.stderr)
+            import gc
+            for obj in gc.get_objects():       # which live CUDA tensor (storage) contains that address?
+                try:
+                    if isinstance(obj, torch.Tensor) and obj.is_cuda:
+                        st = obj.untyped_storage()
+                        if st.data_ptr() <= addr < st.data_ptr() + st.nbytes():
+                            print("[bench_knobs]      inside storage %#x + %d bytes (offset %d, %d bytes before its end), tensor shape %s dtype %s" % (
+                                st.data_ptr(), st.nbytes(), addr - st.data_ptr(), st.data_ptr() + st.nbytes() - addr, tuple(obj.shape), obj.dtype), file=sys.stderr)
+                except Exception:
+                    pass
