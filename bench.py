@@ -698,9 +698,9 @@ def main():
         result["kernel_family_launches"] = fam_n
         dominant = max(fam_ms, key=fam_ms.get)
         # committed PMC passes, newest round first (each record names the kernel, the shape and the git revision it was
-        # taken on: profiles/r5_pmc_traffic.json is written by tools/gpu_runs/r5_run6.sh)
+        # taken on: profiles/r6_pmc_traffic.json is written by tools/gpu_runs/r6_run12.sh)
         pmc, pmc_file = {}, None
-        for cand in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "pmc_traffic.json"):
+        for cand in ("r6_pmc_traffic.json", "r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "pmc_traffic.json"):
             pmc_path = os.path.join(ROOT, "profiles", cand)
             if os.path.exists(pmc_path):
                 pmc, pmc_file = json.load(open(pmc_path)), cand

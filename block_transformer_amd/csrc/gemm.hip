@@ -1842,6 +1842,12 @@ __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x
 #pragma unroll
     for (int ai = 0; ai < 8; ++ai) {
         if (ai == 4) epi_stamp<EABL>(tl, 12);     // half of the fragments converted / transposed / stored
+        // EABL 512 (round-6 experiment, variant 97): the two waves of a SIMD (one of each group) take turns at raised priority, fragment by
+        // fragment -- with equal priority the older wave (group 0) wins the VALU, finishes its epilogue first and waits for group 1's
+        if constexpr ((EABL & 512) != 0) {
+            if ((ai & 1) == wm) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         const int row_l = (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16;
         uint2 o[4];
 #pragma unroll
@@ -1946,6 +1952,7 @@ __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x
             }
         }
     }
+    if constexpr ((EABL & 512) != 0) __builtin_amdgcn_s_setprio(0);
 }
 
 // ---- MFMA shape policies of the persistent kernel -----------------------------------------------------------------------
@@ -2844,7 +2851,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         stamp(j, 8);
-        P::template epilogue<MODE, (ABL >> 5) & 3 | ((ABL >> 6) & 12) | ((ABL >> 12) & 16) | (LNF ? 32 : 0) | ((ABL >> 12) & (64 | 128)) | ((ABL >> 9) & 256)>(
+        P::template epilogue<MODE, ((ABL >> 5) & 3) | ((ABL >> 6) & 12) | ((ABL >> 12) & 16) | (LNF ? 32 : 0) | ((ABL >> 12) & (64 | 128)) | ((ABL >> 9) & 256) | ((ABL >> 13) & 512)>(
             ep, pos0, stage, acc, cm0, cn0 + wcol, wm, lane_e, (TL && j < TL_TILES) ? tl_lds + (uint32_t)(j * TL_EV) * 8u : 0u);
         stamp(j, 9);
         if (j + 1 < nt && grp1 && !SERIAL_EPI) cbarrier();
@@ -5135,6 +5142,9 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
     else if (g_gemm_variant == 94 || (g_gemm_variant == 0 && g_serial_epi)) /* round 6 A/B: the round-5 tile boundary (the two wave groups' epilogues serialised); bt_debug_serial_epilogues */ \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 1048576>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
+                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
+    else if (g_gemm_variant == 97) /* round 6 experiment: the two waves of a SIMD alternate at raised priority through the epilogue */ \
+        hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 4194304>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
     else if (g_gemm_variant == 95) /* ... with the timeline stamps */                                                \
         { ep.amax = (MODE_ == PP_ARGMAX) ? ep.amax : (uint2*)g_timeline;                                             \
