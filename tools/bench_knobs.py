@@ -18,6 +18,15 @@ for kv in sys.argv[1:sep]:
     k, v = kv.split("=")
     getattr(lib(), "bt_debug_" + k)(int(v))
 sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[sep + 1:]
+if os.environ.get("BT_ENGINE") == "pipelined":   # experiment: two half-batch shards on two streams (tools/experiments/pipelined_engine.py)
+    from block_transformer_amd.model.block_transformer import BlockTransformer
+    from tools.experiments.pipelined_engine import PipelinedEngine
+    _init = BlockTransformer.__init__
+
+    def _patched(self, *a, **kw):
+        _init(self, *a, **kw)
+        self.engine_factory = PipelinedEngine
+    BlockTransformer.__init__ = _patched
 diag = None
 if os.environ.get("BT_SK_DIAG") == "1":      # never-cleared record of stream-K hand-off time-outs (debug build), printed if the run dies
     diag = torch.zeros(8 + 64 * 8 + 64, dtype=torch.int32, device="cuda")
