@@ -188,6 +188,7 @@ _DEBUG_SIGS = {
     "bt_debug_ln_streaming": (None, [c_int]),
     "bt_debug_tr_probe": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "bt_debug_grid_barrier_probe": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p]),
+    "bt_debug_memset": (c_int, [c_void_p, c_int32, c_int64, c_void_p]),
     "bt_debug_phase_probe": (c_int, [c_void_p, c_void_p, c_int64, c_int32, c_int32, c_void_p, c_void_p]),
 }
 

@@ -144,10 +144,7 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
         // reduction leaves its counters at zero again; the clear makes a pass independent of whatever ran before it)
         int* counters = reinterpret_cast<int*>(sk + sk_bytes - MID_COUNTER_BYTES);
         const int64_t slab_room = sk_bytes - MID_COUNTER_BYTES;
-        {
-            hipError_t me = hipMemsetAsync(counters, 0, MID_COUNTER_BYTES, hs);
-            if (me != hipSuccess) return bt::hip_fail(me, "hipMemsetAsync(mid-batch counters)");
-        }
+        BT_TRY(zero_words(counters, (int)(MID_COUNTER_BYTES / 4), hs));   // (a kernel, not a memset node: profiles/r6_handoff_false_positive.md)
         const bt_layer_weights& l0 = w->layers_host[0];
         BT_TRY(bt_layernorm(dtype, M, H, x, H, l0.ln1_w, l0.ln1_b, ln1, H, l0.ln2_w, l0.ln2_b, ln2, H, dims->ln_eps, stream));
         for (int l = 0; l < dims->layers; ++l) {

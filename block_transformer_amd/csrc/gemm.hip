@@ -4801,7 +4801,21 @@ struct SkPlan {
     bool ok;
     int nk, C, q, G;
 };
+static SkPlan sk_plan_search(int64_t M, int64_t N, int64_t K1, int64_t K2, int G);
+// The search is O(T * nkt / 4) host work and the engine asks for the same few shapes up to three times per layer of every eager pass
+// (ADVICE r5): a small per-thread memo of the last shapes (pure function of its arguments: no dispatch state, nothing shared)
 static SkPlan sk_plan(int64_t M, int64_t N, int64_t K1, int64_t K2, int G) {
+    struct Key { int64_t M, N, K1, K2; int G; SkPlan p; bool used; };
+    static thread_local Key memo[8] = {};
+    static thread_local int next = 0;
+    for (const Key& k : memo)
+        if (k.used && k.M == M && k.N == N && k.K1 == K1 && k.K2 == K2 && k.G == G) return k.p;
+    const SkPlan p = sk_plan_search(M, N, K1, K2, G);
+    memo[next] = Key{M, N, K1, K2, G, p, true};
+    next = (next + 1) & 7;
+    return p;
+}
+static SkPlan sk_plan_search(int64_t M, int64_t N, int64_t K1, int64_t K2, int G) {
     SkPlan p{false, 0, 0, 0, G};
     if (G < 8 || G % 8 != 0 || M % BM2 != 0 || N % BN2 != 0 || K1 % BK != 0 || K2 % BK != 0 || K1 <= 0) return p;
     const int64_t T = (M / BM2) * (N / BN2);
@@ -4851,6 +4865,12 @@ static int sk_zero(void* scratch, int64_t scratch_bytes, hipStream_t s, int word
     hipLaunchKernelGGL(sk_zero_kernel, dim3(1), dim3(256), 0, s,
                        reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(scratch) + (int64_t)G * SK_SLAB_FLOATS * 4), words);
     BT_LAUNCH_CHECK("stream-K flag clear launch");
+    return BT_OK;
+}
+// the same kernel for the mid-batch path's tile counters (engine.hip): no memset node is left in a captured block step
+int zero_words(void* p, int words, hipStream_t s) {
+    hipLaunchKernelGGL(sk_zero_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<uint32_t*>(p), words);
+    BT_LAUNCH_CHECK("zero_words launch");
     return BT_OK;
 }
 // per launch (callers without sk_clean): the G * 8 hand-off flags only -- an unread time-out (the sticky word behind them) survives

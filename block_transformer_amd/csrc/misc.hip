@@ -721,6 +721,13 @@ extern "C" int bt_debug_phase_probe(void* records, const void* stream_src, int64
     return BT_OK;
 }
 
+// round 6 probe (profiles/r6_handoff_false_positive.md): a bare hipMemsetAsync of `bytes` at `p`, to be captured into a hipGraph by the caller
+extern "C" int bt_debug_memset(void* p, int32_t value, int64_t bytes, bt_stream stream) {
+    hipError_t e = hipMemsetAsync(p, value, (size_t)bytes, (hipStream_t)stream);
+    if (e != hipSuccess) return bt::hip_fail(e, "hipMemsetAsync(probe)");
+    return BT_OK;
+}
+
 extern "C" int bt_debug_tr_probe(const void* in, const void* addr, void* out, bt_stream stream) {
     hipLaunchKernelGGL(tr_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const short*)in, (const int*)addr,
                        (short*)out);
