@@ -161,6 +161,7 @@ _DEBUG_SIGS = {
     "bt_debug_mid_tall": (None, [c_int]),
     "bt_debug_mid_tall_wgs": (None, [c_int]),
     "bt_debug_mid_tall_wt": (None, [c_int]),
+    "bt_debug_mid_tall_fuse": (None, [c_int]),
     "bt_debug_mid_wt": (None, [c_int]),
     "bt_debug_mid_rows_max": (None, [c_int]),
     "bt_debug_mid_tall_wgs_res": (None, [c_int]),

@@ -231,6 +231,7 @@ int mid_res_ln(hipStream_t s, int64_t M, int64_t N, int64_t K1, const void* x1, 
 int64_t sk_scratch_bytes();
 bool sk_linear2_ok(int64_t M, int64_t N, int64_t K1, int64_t K2, int64_t scratch_bytes);
 int sk_clear_flags(void* scratch, int64_t scratch_bytes, hipStream_t s);                              // hand-off flags only (per launch)
+int tall_status(const int* counters, int32_t* err_flag, hipStream_t s, uint32_t tag = 0);          // fused mid-batch launch: sticky time-out word -> err_flag
 int zero_words(void* p, int words, hipStream_t s);                                                    // one-workgroup clearing kernel (no memset nodes in captured graphs)
 int sk_reset(void* scratch, int64_t scratch_bytes, hipStream_t s);                                    // flags + sticky time-out word
 int sk_status(const void* scratch, int64_t scratch_bytes, int32_t* err_flag, hipStream_t s, uint32_t tag = 0);          // sticky word -> BT_DEV_ERR_HANDOFF_TIMEOUT

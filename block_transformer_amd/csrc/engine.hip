@@ -176,6 +176,8 @@ extern "C" int bt_decoder_forward(int dtype, const bt_decoder_dims* dims, const 
                               more ? nx.ln1_w : nullptr, more ? nx.ln1_b : nullptr, ln1, more ? nx.ln2_w : nullptr,
                               more ? nx.ln2_b : nullptr, ln2, H, dims->ln_eps, scratch, slab_room));
         }
+        // the fused QKV + h->4h launch's hand-off (97 .. 256 rows) reports a give-up like the stream-K GEMMs do
+        if (attn->err_flag) BT_TRY(tall_status(counters, attn->err_flag, hs, (uint32_t)M | ((uint32_t)q_len << 24)));
     }
     // stream-K hand-off flags of the large-M GEMMs (the fused residual projections; QKV shapes whose tile count the persistent kernel
     // refuses): flags + the sticky time-out word zeroed once per pass, the kernels leave the flags zero -> the layers below pass

@@ -1923,7 +1923,8 @@ __device__ inline void pp_epilogue(const EpiArgs& e, int pos0, char* stage, f32x
                     continue;
                 } else if (kv_mode != 0) {
                     const uint32_t r0 = (uint32_t)(row_l + h * 8);          // first tile row of this store (scalar)
-                    if (part_u == 0) {                                       // q columns: rows of the qkv buffer
+                    if (part_u == 0 || (EABL & 1024) != 0) {                 // q columns: rows of the qkv buffer  (EABL 1024, variant 98: timing
+                                                                             //  experiment, WRONG results -- k / v go there too)
                         __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{v.x, v.y, v.z, v.w}, out_rsrc, out_voff, r0 * (uint32_t)e.ldo * 2u, 0);
                     } else if (kv_mode == 3) {
                         const uint32_t r = r0 + (uint32_t)(lane >> 3);
@@ -2851,7 +2852,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256pp2_kernel(const bf16* _
         int lane_e = lane;
         asm volatile("" : "+v"(lane_e));
         stamp(j, 8);
-        P::template epilogue<MODE, ((ABL >> 5) & 3) | ((ABL >> 6) & 12) | ((ABL >> 12) & 16) | (LNF ? 32 : 0) | ((ABL >> 12) & (64 | 128)) | ((ABL >> 9) & 256) | ((ABL >> 13) & 512)>(
+        P::template epilogue<MODE, ((ABL >> 5) & 3) | ((ABL >> 6) & 12) | ((ABL >> 12) & 16) | (LNF ? 32 : 0) | ((ABL >> 12) & (64 | 128)) | ((ABL >> 9) & 256) | ((ABL >> 13) & 512) | ((ABL >> 13) & 1024)>(
             ep, pos0, stage, acc, cm0, cn0 + wcol, wm, lane_e, (TL && j < TL_TILES) ? tl_lds + (uint32_t)(j * TL_EV) * 8u : 0u);
         stamp(j, 9);
         if (j + 1 < nt && grp1 && !SERIAL_EPI) cbarrier();
@@ -3593,11 +3594,108 @@ __device__ inline void ts_wait_tiles(int tiles) {
     else wait_vmcnt_n<0>();
 }
 
+// ---- round 6: the QKV + h->4h launch of the 97 .. 512-row path with its epilogues FUSED (no reduce launch behind it) -----------------------
+// Up to 256 rows a column tile's K range is cut in two (224 workgroups for the 1.2B layer); the workgroup with the FIRST K-tiles publishes
+// its fp32 tile exactly as the slab kernel stores it (write-through) and raises one flag word per tile, the workgroup with the LAST
+// K-tiles (a few more of them, so that it never waits) adds that tile to its accumulators and runs the epilogue the reduce launch used to:
+// bias, RoPE on the first 32 dims of q / k (rot == 32: the partner column of e < 16 is e + 16 = the wave's other column fragment, same
+// lane, same register), q -> qkv buffer, (k, v) -> cache rows pos0 + t, GELU for the h->4h side, bf16 stores.  257 .. 512 rows: one K
+// range per tile (two row tiles), the epilogue runs on the accumulators directly.  The hand-off is the stream-K kernel's recipe with one
+// flag per TILE (workgroup barrier on either side): write-through slab stores, s_waitcnt vmcnt(0), barrier, relaxed agent-scope flag store;
+// bounded relaxed polls + s_sleep, barrier, agent-scope acquire, plain loads.  A consumer that gives up does not add the tile and stores
+// SK_TIMEOUT_MAGIC into flags[TF_STICKY] (bt_decoder_forward reports it as BT_DEV_ERR_HANDOFF_TIMEOUT).
+struct TallFuse {
+    EpiArgs ep[2];       // side 0: QKV (ep.q.enabled), side 1: h->4h (ep.act == GELU)
+    uint32_t* flags;     // one word per (side, tile), zero at launch and left zero; the caller's mid-batch counter words
+    int first_nk;        // K-tiles of the publishing workgroup when a tile's K range is cut in two (the rest go to the finishing one)
+};
+constexpr int TF_STICKY = 1023;      // word of the 4 KiB counter region that holds the sticky time-out value
+
+__device__ inline void tall_fused_epilogue(const EpiArgs& e, f32x4_t (&acc)[8][2], int m0, int nw, int wm, int lane) {
+    const int M = e.M;
+    const bool qkv = e.q.enabled != 0;
+    const int cl = (lane >> 4) * 4;                       // the lane's 4 consecutive columns inside a 16-column fragment
+    float bv[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    if (e.bias) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const uint2 b = *reinterpret_cast<const uint2*>(e.bias + nw + nb * 16 + cl);
+            bv[nb][0] = __uint_as_float(b.x << 16); bv[nb][1] = __uint_as_float(b.x & 0xffff0000u);
+            bv[nb][2] = __uint_as_float(b.y << 16); bv[nb][3] = __uint_as_float(b.y & 0xffff0000u);
+        }
+    }
+    // the wave's 32 columns lie inside one head's q, k or v part (head_dim % 32 == 0)
+    int head = 0, part = 0, el0 = 0, pos0 = 0, q_len = 1;
+    bool rot = false;
+    if (qkv) {
+        const int D = e.q.head_dim;
+        head = nw / (3 * D);
+        const int within = nw - head * 3 * D;
+        part = within / D;
+        el0 = within - part * D;
+        rot = part < 2 && el0 == 0;
+        pos0 = __builtin_amdgcn_readfirstlane(e.q.pos0_dev ? *e.q.pos0_dev : e.q.pos0_host);
+        q_len = e.q.q_len;
+    }
+    int rb[8], rt[8];                                      // (sequence, position inside the call) of the lane's row of every fragment
+    float4 cs[8], sn[8];
+#pragma unroll
+    for (int ai = 0; ai < 8; ++ai) {
+        int m = m0 + (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16 + (lane & 15);
+        m = m < M ? m : M - 1;
+        if (q_len == 1) { rb[ai] = m; rt[ai] = 0; }
+        else if (q_len == 2) { rb[ai] = m >> 1; rt[ai] = m & 1; }
+        else { rb[ai] = m / q_len; rt[ai] = m - rb[ai] * q_len; }
+    }
+    if (rot) {
+#pragma unroll
+        for (int ai = 0; ai < 8; ++ai) {
+            const int rpos = e.q.pos_table ? e.q.pos_table[pos0 + rt[ai]] : pos0 + rt[ai];
+            cs[ai] = *reinterpret_cast<const float4*>(e.q.cos_tab + (int64_t)rpos * 16 + cl);
+            sn[ai] = *reinterpret_cast<const float4*>(e.q.sin_tab + (int64_t)rpos * 16 + cl);
+        }
+    }
+#pragma unroll
+    for (int ai = 0; ai < 8; ++ai) {
+        const int m = m0 + (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16 + (lane & 15);
+        float v[2][4];
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[nb][r] = acc[ai][nb][r] + bv[nb][r];
+        if (rot) {
+            const float c[4] = {cs[ai].x, cs[ai].y, cs[ai].z, cs[ai].w}, sv[4] = {sn[ai].x, sn[ai].y, sn[ai].z, sn[ai].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x1 = v[0][r], x2 = v[1][r];
+                v[0][r] = x1 * c[r] - x2 * sv[r];
+                v[1][r] = x2 * c[r] + x1 * sv[r];
+            }
+        }
+        if (e.act == BT_ACT_GELU) {
+            gelu4(v[0]);
+            gelu4(v[1]);
+        }
+        if (m < M) {
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const uint2 o = uint2{pack_bf16x2(v[nb][0], v[nb][1]), pack_bf16x2(v[nb][2], v[nb][3])};
+                bf16* dst;
+                if (!qkv || part == 0) dst = e.out + (int64_t)m * e.ldo + nw + nb * 16 + cl;
+                else
+                    dst = (part == 1 ? e.q.kc : e.q.vc) +
+                          (((int64_t)rb[ai] * e.q.heads + head) * e.q.n_max + pos0 + rt[ai]) * e.q.head_dim + el0 + nb * 16 + cl;
+                *reinterpret_cast<uint2*>(dst) = o;
+            }
+        }
+    }
+}
+
 // WT: the slab stores are write-through (sc1).  With plain stores the 29-34 MB of slabs sit dirty in the eight L2s until the end-of-kernel
 // release writes them back -- after the last workgroup, on the critical path of the reduce launch that follows; written through they
 // drain while the other workgroups still compute (guide "publish-large" / "splitk-seam": 64 KB fp32 slabs per workgroup at M = 256).
-template <bool WT>
-__global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const TallArgs a, int M, int wg_side1) {
+template <bool WT, bool FUSE = false>
+__global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const TallArgs a, int M, int wg_side1, const TallFuse tf = TallFuse{}) {
     static_assert(TS_WD >= 2 && TS_WD <= 5, "ts_wait_tiles covers up to four W tiles in flight behind the awaited one");
     __shared__ __attribute__((aligned(16))) char smem[TS_SMEM];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -3616,7 +3714,13 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
     const int m0 = tm * 256;
     const bool second = slice >= g.s1;
     const int sidx = second ? slice - g.s1 : slice, scnt = second ? g.s2 : g.s1, nk_all = second ? g.nk2 : g.nk1;
-    const int kb = sidx * nk_all / scnt, ke = (sidx + 1) * nk_all / scnt;   // (slices x K-tiles << 2^31)
+    int kb = sidx * nk_all / scnt, ke = (sidx + 1) * nk_all / scnt;   // (slices x K-tiles << 2^31)
+    if constexpr (FUSE) {     // two K ranges: [0, first_nk) is published, [first_nk, nk_all) finishes the tile (host: S <= 2, one operand pair)
+        if (S == 2) {
+            kb = slice == 0 ? 0 : tf.first_nk;
+            ke = slice == 0 ? tf.first_nk : nk_all;
+        }
+    }
     const int nk = ke - kb;
     const bf16* A = second ? g.A2 : g.A;
     const bf16* W = second ? g.W2 : g.W;
@@ -3732,6 +3836,60 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
         __builtin_amdgcn_s_setprio(0);
     }
     if (!grp1) cbarrier();
+    if constexpr (FUSE) {
+        const EpiArgs& ep = tf.ep[side];
+        uint32_t* flag = tf.flags + (side ? (wg_side1 / S) : 0) + tile;          // one word per (side, tile)
+        if (S == 2 && slice == 1) {
+            // finishing workgroup: wait for the partner's tile (wave 0 polls, everybody passes the barrier behind it), add it
+            uint32_t seen = 1;
+            if (wave == 0) {
+                seen = 0;
+                for (uint32_t spins = 0; spins < SK_SPIN_LIMIT; ++spins) {
+                    seen = sk_flag_load(flag);
+                    if (seen != 0) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                if (seen == 0) sk_flag_store(tf.flags + TF_STICKY, SK_TIMEOUT_MAGIC);   // gave up: the tile stays incomplete, the pass is flagged
+                else sk_flag_store(flag, 0u);                                         // ready for the next launch
+            }
+            cbarrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            // (every wave looks at the sticky word instead of sharing wave 0's verdict through LDS: it is only ever non-zero after a give-up)
+            const bool gave_up = sk_flag_load(tf.flags + TF_STICKY) == SK_TIMEOUT_MAGIC;
+            if (!gave_up) {
+                const __amdgpu_buffer_rsrc_t prs = tile_rsrc(reinterpret_cast<const char*>(g.partial + n0 + wn * 32));
+                const uint32_t pvoff = ((uint32_t)(lane & 15) * (uint32_t)N + (uint32_t)(lane >> 4) * 4u) * 4u;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    u32x4_t pv[4][2];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        int row0 = m0 + h * 128 + wm * 64 + i * 16;
+                        row0 = row0 + (lane & 15) < M ? row0 : 0;           // rows beyond the stack: any valid address (their sums are never stored)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb)
+                            pv[i][nb] = __builtin_amdgcn_raw_buffer_load_b128(prs, pvoff, ((uint32_t)row0 * (uint32_t)N + (uint32_t)nb * 16u) * 4u, 0);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) {
+                            acc[h * 4 + i][nb][0] += __uint_as_float(pv[i][nb].x);
+                            acc[h * 4 + i][nb][1] += __uint_as_float(pv[i][nb].y);
+                            acc[h * 4 + i][nb][2] += __uint_as_float(pv[i][nb].z);
+                            acc[h * 4 + i][nb][3] += __uint_as_float(pv[i][nb].w);
+                        }
+                }
+            }
+            tall_fused_epilogue(ep, acc, m0, n0 + wn * 32, wm, lane);
+            return;
+        }
+        if (S == 1) {
+            tall_fused_epilogue(ep, acc, m0, n0 + wn * 32, wm, lane);
+            return;
+        }
+        // S == 2, slice 0: publish below (slab region of slice 0), then the flag
+    }
     // ---- slab stores: accumulator fragment = row (lane & 15), columns nb * 16 + (lane >> 4) * 4 .. + 3 ----
     const __amdgpu_buffer_rsrc_t srs = tile_rsrc(reinterpret_cast<const char*>(g.partial + ((int64_t)slice * M) * N + n0 + wn * 32));
     const uint32_t svoff = ((uint32_t)(lane & 15) * (uint32_t)N + (uint32_t)(lane >> 4) * 4u) * 4u;
@@ -3744,9 +3902,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
                 const f32x4_t v = acc[ai][nb];
                 __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]),
                                                                __float_as_uint(v[3])},
-                                                       srs, svoff, ((uint32_t)row0 * (uint32_t)N + (uint32_t)nb * 16u) * 4u, WT ? 16 : 0);
+                                                       srs, svoff, ((uint32_t)row0 * (uint32_t)N + (uint32_t)nb * 16u) * 4u, (WT || FUSE) ? 16 : 0);
             }
         }
+    }
+    if constexpr (FUSE) {     // publisher: every wave's stores have left the CU, then ONE flag for the tile
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        cbarrier();
+        if (wave == 0) sk_flag_store(tf.flags + (side ? (wg_side1 / S) : 0) + tile, 1u);
     }
 }
 
@@ -4752,6 +4915,10 @@ BT_KNOB int g_mid_rows_max = 512;  // ... and take stacks of up to this many row
 BT_KNOB int g_mid_tall_wgs = 256; // ... with about this many workgroups per launch (A/B)
 BT_KNOB int g_mid_tall_wgs_res = 256; // ... (the launch with two operand pairs: the residual projections)
 BT_KNOB bool g_mid_tall_wt = true; // ... and write-through slab stores (false: plain stores, A/B)
+BT_KNOB int g_mid_tall_fuse = 1;  // round 6: the QKV + h->4h launch of that path with FUSED epilogues, no reduce launch.  1: where a tile has one K range
+                                  // (257 .. 512 rows: B = 384 / 512 +3.6 %); 2 (debug A/B): also up to 256 rows, with the hand-off between a tile's two
+                                  // K ranges -- measured -3 % (B = 256) / -10 % (B = 128): the reduce launch it removes also carried the token
+                                  // decoder's local attention, which becomes a launch of its own (profiles/r6_ab_mid_fused_epilogues.jsonl); 0: off
 // <= 2 rows, local window: the attention computed inside the residual-stream GEMV.  Built and A/B-measured in round 4
 // (profiles/r4_ab_few_attn.jsonl, same box, interleaved): B = 1 1695 vs 1725 tok/s, B = 2 2950 vs 2921 -- a wash: the per-workgroup
 // attention arithmetic (latency chains of ~28 cross-lane ops per item, redundantly in 512 workgroups) costs what the dependent
@@ -4867,6 +5034,8 @@ static int sk_zero(void* scratch, int64_t scratch_bytes, hipStream_t s, int word
     BT_LAUNCH_CHECK("stream-K flag clear launch");
     return BT_OK;
 }
+// the fused 256 x 128 launch's sticky time-out word (TF_STICKY of the mid-batch counter words) -> BT_DEV_ERR_HANDOFF_TIMEOUT
+int tall_status(const int* counters, int32_t* err_flag, hipStream_t s, uint32_t tag);
 // the same kernel for the mid-batch path's tile counters (engine.hip): no memset node is left in a captured block step
 int zero_words(void* p, int words, hipStream_t s) {
     hipLaunchKernelGGL(sk_zero_kernel, dim3(1), dim3(256), 0, s, reinterpret_cast<uint32_t*>(p), words);
@@ -4905,6 +5074,17 @@ int sk_status(const void* scratch, int64_t scratch_bytes, int32_t* err_flag, hip
 #endif
     hipLaunchKernelGGL(sk_status_kernel, dim3(1), dim3(1), 0, s, sticky, err_flag, diag, tag);
     BT_LAUNCH_CHECK("stream-K status launch");
+    return BT_OK;
+}
+int tall_status(const int* counters, int32_t* err_flag, hipStream_t s, uint32_t tag) {
+    if (!counters || !err_flag) return BT_OK;
+#ifdef BT_DEBUG_HOOKS
+    uint32_t* diag = g_sk_diag;
+#else
+    uint32_t* diag = nullptr;
+#endif
+    hipLaunchKernelGGL(sk_status_kernel, dim3(1), dim3(1), 0, s, reinterpret_cast<const uint32_t*>(counters) + TF_STICKY, err_flag, diag, tag);
+    BT_LAUNCH_CHECK("mid-batch hand-off status launch");
     return BT_OK;
 }
 }  // namespace bt
@@ -5162,6 +5342,9 @@ static int linear_impl(int dtype, int64_t M, int64_t N, int64_t K, const void* A
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
     else if (g_gemm_variant == 94 || (g_gemm_variant == 0 && g_serial_epi)) /* round 6 A/B: the round-5 tile boundary (the two wave groups' epilogues serialised); bt_debug_serial_epilogues */ \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 1048576>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
+                           lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
+    else if (g_gemm_variant == 98) /* round 6 timing experiment (wrong results): QKV mode with k / v stored into the qkv buffer */ \
+        hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 8388608>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
                            lda, (const bf16*)W, K, ep, (int)K, tiles_m, tiles_n);                                   \
     else if (g_gemm_variant == 97) /* round 6 experiment: the two waves of a SIMD alternate at raised priority through the epilogue */ \
         hipLaunchKernelGGL((gemm_bf16_mfma256pp2_kernel<MODE_, 4194304>), dim3(n_wg), dim3(512), 0, s, (const bf16*)A,  \
@@ -6002,13 +6185,18 @@ bool mid_tall_layer_ok(int64_t H, int64_t I, const void* qkv_w, const void* h4_w
            tall_operand_ok(h_w, I, I) && tall_operand_ok(dense_w, H, H);
 }
 
-static int tall_launch(hipStream_t s, int64_t M, const TallSide& g0, const TallSide* g1) {
+static int tall_launch(hipStream_t s, int64_t M, const TallSide& g0, const TallSide* g1, const TallFuse* fuse = nullptr) {
     TallArgs ta{};
     ta.g[0] = g0;
     ta.g[1] = g1 ? *g1 : g0;
     const int tiles_m = (int)ceil_div(M, 256);
     const int wg0 = tiles_m * (g0.N / 128) * (g0.s1 + g0.s2);
     const int wg1 = g1 ? tiles_m * (g1->N / 128) * (g1->s1 + g1->s2) : 0;
+    if (fuse) {
+        hipLaunchKernelGGL((gemm_bf16_mfma256x128_slab_kernel<true, true>), dim3(wg0 + wg1), dim3(512), 0, s, ta, (int)M, wg0, *fuse);
+        BT_LAUNCH_CHECK("mid-batch 256 x 128 fused GEMM launch");
+        return BT_OK;
+    }
     if (g_mid_tall_wt)
         hipLaunchKernelGGL(gemm_bf16_mfma256x128_slab_kernel<true>, dim3(wg0 + wg1), dim3(512), 0, s, ta, (int)M, wg0);
     else
@@ -6183,6 +6371,23 @@ int mid_qkv_gelu(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, c
         g0.nk1 = (int)(K / 64); g0.s1 = slices;
         g1.A = (const bf16*)x2; g1.W = (const bf16*)h4_w; g1.lda = H; g1.ldw = K; g1.partial = p2; g1.N = (int)N2;
         g1.nk1 = (int)(K / 64); g1.s1 = slices;
+        // round 6: epilogues fused into this launch (hand-off between the two K ranges of a tile, or none above 256 rows): no reduce
+        // launch; the attention of either decoder follows as its own launch (the caller sees attn_done == false)
+        const int nk = (int)(K / 64);
+        const int64_t n_tiles = ceil_div(M, 256) * ((N1 + N2) / 128);
+        if (g_mid_tall_fuse && counters && (slices == 1 || (slices == 2 && g_mid_tall_fuse >= 2 && nk >= 8)) && n_tiles < TF_STICKY && head_dim % 32 == 0 &&
+            ld_qkv % 4 == 0 && I % 4 == 0 && (reinterpret_cast<uintptr_t>(qkv) & 7u) == 0 && (reinterpret_cast<uintptr_t>(h4) & 7u) == 0 &&
+            (reinterpret_cast<uintptr_t>(kc) & 7u) == 0 && (reinterpret_cast<uintptr_t>(vc) & 7u) == 0 &&
+            (!qkv_b || (reinterpret_cast<uintptr_t>(qkv_b) & 7u) == 0) && (!h4_b || (reinterpret_cast<uintptr_t>(h4_b) & 7u) == 0)) {
+            TallFuse tf{};
+            tf.ep[0] = e1;
+            tf.ep[1] = e2;
+            tf.flags = reinterpret_cast<uint32_t*>(counters);
+            tf.first_nk = std::max(1, nk / 2 - 2);         // the finishing workgroup runs ~4 K-tiles longer: the partner's tile is there when it looks
+            BT_TRY(tall_launch(s, M, g0, &g1, &tf));
+            *done = true;
+            return BT_OK;
+        }
         BT_TRY(tall_launch(s, M, g0, &g1));
     } else {
         ProfScope ps(BT_PROF_LINEAR_MFMA, s);
@@ -6298,6 +6503,7 @@ extern "C" void bt_debug_mid_rows(int on) { g_mid_rows = on != 0; }
 extern "C" void bt_debug_mid_tall(int mode) { g_mid_tall = mode; }
 extern "C" void bt_debug_mid_tall_wgs(int wgs) { g_mid_tall_wgs = wgs > 0 ? wgs : 256; }
 extern "C" void bt_debug_mid_tall_wt(int on) { g_mid_tall_wt = on != 0; }
+extern "C" void bt_debug_mid_tall_fuse(int mode) { g_mid_tall_fuse = mode; }
 extern "C" void bt_debug_mid_wt(int on) { g_mid_wt = on != 0; }
 extern "C" void bt_debug_mid_rows_max(int rows) { g_mid_rows_max = rows; }
 extern "C" void bt_debug_mid_tall_wgs_res(int wgs) { g_mid_tall_wgs_res = wgs > 0 ? wgs : 256; }

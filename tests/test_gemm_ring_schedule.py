@@ -605,7 +605,8 @@ def test_one_tile_256x128_model_detects_a_missing_drain():
 # group 1 (TS_WD K-tiles deep): each group has its own vmcnt queue ----------------------------------------------------------------
 TS_WD = int(re.search(r"constexpr int TS_WD = (\d+);", SRC).group(1))
 _SLAB = SRC[SRC.index("void gemm_bf16_mfma256x128_slab_kernel("):]
-_SLAB = re.sub(r"\s+", "", re.sub(r"//[^\n]*", "", _SLAB[:_SLAB.index("// ---- slab stores")]))
+# (the K-loop ends where the round-6 fused form -- hand-off + epilogue, its own workgroup barriers -- or the slab stores begin)
+_SLAB = re.sub(r"\s+", "", re.sub(r"//[^\n]*", "", _SLAB[:min(_SLAB.index("// ---- slab stores"), _SLAB.index("const EpiArgs& ep = tf.ep[side];"))]))
 # the lines the streams below restate (comments and whitespace removed)
 for piece in ("if(!grp1){issue_a(I0{},0);issue_a(I1{},0);if(nk>1)issue_a(I0{},1);}else{for(intkt=0;kt<TS_WD&&kt<nk;++kt)issue_w(kt);}",
               "if(grp1){ts_wait_tiles(min(TS_WD,nk)-1);cbarrier();}",
@@ -614,7 +615,7 @@ for piece in ("if(!grp1){issue_a(I0{},0);issue_a(I1{},0);if(nk>1)issue_a(I0{},1)
               "if(!grp1)ts_wait_tiles(t+1<nk?2:0);cbarrier();",
               "if(!grp1&&t+2<nk)issue_a(I0{},t+2);if(grp1){if(t+TS_WD<nk)issue_w(t+TS_WD);ts_wait_tiles(min(t+TS_WD,nk-1)-(t+1));"
               "asmvolatile(\"s_waitcntlgkmcnt(0)\":::\"memory\");}cbarrier();",
-              "if(!grp1)cbarrier();"):
+              "if(!grp1)cbarrier();ifconstexpr(FUSE){"):
     assert piece in _SLAB, piece
 assert _SLAB.count("cbarrier();") == 6 and _SLAB.count("ts_wait_tiles(") == 4
 assert "if(tiles>=4)wait_vmcnt_n<16>();elseif(tiles==3)wait_vmcnt_n<12>();elseif(tiles==2)wait_vmcnt_n<8>();elseif(tiles==1)wait_vmcnt_n<4>();elsewait_vmcnt_n<0>();" \

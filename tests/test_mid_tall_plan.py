@@ -20,7 +20,7 @@ for line in ("const int total = std::max(1, (nk2 > 0 ? g_mid_tall_wgs_res : g_mi
              "int a = (int)((int64_t)total * nk1 / (nk1 + nk2));",
              "a = std::max(1, std::min(a, std::max(1, nk1 / 4)));",
              "int b = std::max(1, std::min(total - a, std::max(1, nk2 / 4)));",
-             "const int kb = sidx * nk_all / scnt, ke = (sidx + 1) * nk_all / scnt;",
+             "int kb = sidx * nk_all / scnt, ke = (sidx + 1) * nk_all / scnt;",
              "const int slice = id % S, tile = id / S;",
              "const int tm = tile / tiles_n, tn = tile - tm * tiles_n;",
              "const bool second = slice >= g.s1;"):

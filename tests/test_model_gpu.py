@@ -1824,6 +1824,52 @@ def test_mid_rows_decoder_stack_vs_fp32_oracle(M, dbg_lib):
         assert (got - want).abs().max().item() <= 3e-2 * want.abs().max().item() + 1e-2
 
 
+@pytest.mark.parametrize("M", [97, 128, 200, 256, 257, 300, 512])
+@pytest.mark.parametrize("fuse", [0, 1, 2])
+def test_mid_rows_fused_epilogue_launch_vs_oracle_and_reduce_launch(M, fuse, dbg_lib):
+    """Round 6: the QKV + h->4h launch of the 97 .. 512-row path with its epilogues fused (bias, RoPE, K/V append, GELU in the GEMM's own
+    accumulator layout; no reduce launch).  fuse = 1 is the product (fusion where a tile has ONE K range: 257 .. 512 rows), 2 adds the
+    hand-off between a tile's two K ranges up to 256 rows (measured slower, debug A/B only: one flag per tile, write-through slab, bounded
+    polls), 0 the round-5 slab + reduce launches.  Decode step (q = 1 against a 40-row cache): hidden states and the appended K / V rows vs
+    the fp32 oracle, and every setting against fuse = 0 within one bf16 rounding of the same fp32 sums; repeated to catch a flag word
+    left non-zero; the sticky time-out word stays clear (no BtError from the module forward)."""
+    model, dims, o = _mid_stack()
+    H = dims.bd.hidden
+    g = torch.Generator().manual_seed(1000 + M)
+    past_len = 40
+    xp = (torch.randn(M, past_len, H, generator=g) * 0.5).bfloat16()
+    xs = (torch.randn(M, 1, H, generator=g) * 0.5).bfloat16()
+    ones = torch.ones(M, past_len + 1, dtype=torch.long)
+
+    def run():
+        pre = model.block_decoder(inputs_embeds=xp.to(DEV), block_attention_mask=ones[:, :past_len].to(DEV))
+        step = model.block_decoder(inputs_embeds=xs.to(DEV), block_attention_mask=ones.to(DEV), past_key_values=pre.past_key_values)
+        k, v = step.past_key_values[1]
+        return step.hidden_states[:, 0].float().cpu(), k[:, :, past_len].float().cpu(), v[:, :, past_len].float().cpu()
+
+    try:
+        dbg_lib.bt_debug_mid_tall_fuse(0)
+        hid0, k0, v0 = run()
+        dbg_lib.bt_debug_mid_tall_fuse(fuse)
+        hid, k_new, v_new = run()
+        hid_b, k_b, v_b = run()
+    finally:
+        dbg_lib.bt_debug_mid_tall_fuse(1)
+    assert torch.equal(hid, hid_b) and torch.equal(k_new, k_b) and torch.equal(v_new, v_b), "not repeatable (a hand-off flag left set?)"
+    ref_pre, past = o.block_decoder(xp.float(), ones[:, :past_len])
+    ref, kv = o.block_decoder(xs.float(), ones, past)
+    ref = ref[:, 0]
+    scale = ref.abs().max().item()
+    assert (hid - ref).abs().max().item() <= 3e-2 * scale + 1e-2, (hid - ref).abs().max().item()
+    k_ref, v_ref = kv[1][0][:, :, past_len], kv[1][1][:, :, past_len]
+    assert (k_new - k_ref).abs().max().item() <= 3e-2 * k_ref.abs().max().item() + 1e-2
+    assert (v_new - v_ref).abs().max().item() <= 3e-2 * v_ref.abs().max().item() + 1e-2
+    # same fp32 sums, same formulas as the reduce launch: at most one bf16 ulp apart (multiply-add contraction may differ)
+    assert (k_new - k0).abs().max().item() <= 2.0 ** -7 * k_ref.abs().max().item()
+    assert (v_new - v0).abs().max().item() <= 2.0 ** -7 * v_ref.abs().max().item()
+    assert (hid - hid0).abs().max().item() <= 3e-2 * scale + 1e-2
+
+
 @pytest.mark.parametrize("M,mode", [(97, 1), (129, 1), (192, 1), (250, 1), (256, 1), (257, 1), (300, 1), (510, 1), (512, 1), (96, 2)])
 def test_mid_rows_tall_tiles_match_the_64x64_slab_kernels(M, mode, dbg_lib):
     """97 .. 256 rows (round 5): the slab GEMMs of a layer run on 256 x 128 tiles with a K RANGE per workgroup
