@@ -3608,10 +3608,13 @@ struct TallFuse {
     EpiArgs ep[2];       // side 0: QKV (ep.q.enabled), side 1: h->4h (ep.act == GELU)
     uint32_t* flags;     // one word per (side, tile), zero at launch and left zero; the caller's mid-batch counter words
     int first_nk;        // K-tiles of the publishing workgroup when a tile's K range is cut in two (the rest go to the finishing one)
+    int half_mode;       // 129 .. 256 rows: a workgroup owns ONE 128-row half of a column tile over the whole K (grid = 2 x tiles, the two
+                         // halves of a tile 8 block ids apart = on one XCD, so the W tile they both stream is fetched into that L2 once);
+                         // phase 1 of every K-tile (the A1 half) is empty: no A1 loads, no reads, no MFMAs -- one K range, no hand-off
 };
 constexpr int TF_STICKY = 1023;      // word of the 4 KiB counter region that holds the sticky time-out value
 
-__device__ inline void tall_fused_epilogue(const EpiArgs& e, f32x4_t (&acc)[8][2], int m0, int nw, int wm, int lane) {
+__device__ inline void tall_fused_epilogue(const EpiArgs& e, f32x4_t (&acc)[8][2], int m0, int nw, int wm, int lane, bool half_only = false) {
     const int M = e.M;
     const bool qkv = e.q.enabled != 0;
     const int cl = (lane >> 4) * 4;                       // the lane's 4 consecutive columns inside a 16-column fragment
@@ -3657,6 +3660,7 @@ __device__ inline void tall_fused_epilogue(const EpiArgs& e, f32x4_t (&acc)[8][2
     }
 #pragma unroll
     for (int ai = 0; ai < 8; ++ai) {
+        if (half_only && ai >= 4) break;                  // (a workgroup that owns one 128-row half has no A1 accumulators)
         const int m = m0 + (ai >> 2) * 128 + wm * 64 + (ai & 3) * 16 + (lane & 15);
         float v[2][4];
 #pragma unroll
@@ -3704,14 +3708,24 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
     const bool grp1 = wave >= 4;
     const int wq = wave & 3;                 // this wave's quarter of the tile its group streams
     // side, column tile and slice: workgroup-uniform index into the kernel-argument array (scalar loads at a computed offset)
-    const int side = (int)blockIdx.x >= wg_side1 ? 1 : 0;
+    bool half_mode = false;
+    int lin = (int)blockIdx.x, half = 0;
+    if constexpr (FUSE) {
+        half_mode = tf.half_mode != 0;
+        if (half_mode) {     // block b = 8 q + x: half = q & 1, column tile (q >> 1) * 8 + x -- the two halves of a tile share x = the XCD
+            const int q = (int)blockIdx.x >> 3, x = (int)blockIdx.x & 7;
+            half = q & 1;
+            lin = (q >> 1) * 8 + x;
+        }
+    }
+    const int side = lin >= wg_side1 ? 1 : 0;
     const TallSide& g = a.g[side];
-    const int id = (int)blockIdx.x - side * wg_side1;
+    const int id = lin - side * wg_side1;
     const int S = g.s1 + g.s2;
     const int slice = id % S, tile = id / S;   // consecutive ids (= XCDs) take different slices: an XCD's L2 holds S / 8 of the A columns
     const int tiles_n = g.N >> 7;
     const int tm = tile / tiles_n, tn = tile - tm * tiles_n;   // 257 .. 512 rows: two row tiles
-    const int m0 = tm * 256;
+    const int m0 = tm * 256 + half * 128;
     const bool second = slice >= g.s1;
     const int sidx = second ? slice - g.s1 : slice, scnt = second ? g.s2 : g.s1, nk_all = second ? g.nk2 : g.nk1;
     int kb = sidx * nk_all / scnt, ke = (sidx + 1) * nk_all / scnt;   // (slices x K-tiles << 2^31)
@@ -3765,7 +3779,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
     // prologue: group 0 -> A0(0), A1(0), A0(1); group 1 -> W(0 .. TS_WD - 1)
     if (!grp1) {
         issue_a(I0{}, 0);
-        issue_a(I1{}, 0);
+        if (!half_mode) issue_a(I1{}, 0);
         if (nk > 1) issue_a(I0{}, 1);
     } else {
         for (int kt = 0; kt < TS_WD && kt < nk; ++kt) issue_w(kt);
@@ -3788,7 +3802,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
         const char* wbuf = smem + 2 * TS_A_STAGE + r_slot * HALF_BYTES;
         r_slot = r_slot + 1 == TS_WD ? 0 : r_slot + 1;
         // ---- phase 0: A0, W ----
-        if (!grp1) ts_wait_tiles(t + 1 < nk ? 2 : 1);        // A0(t) landed; A1(t) and A0(t + 1) may be in flight
+        if (!grp1) ts_wait_tiles((t + 1 < nk ? 2 : 1) - (half_mode ? 1 : 0));   // A0(t) landed; A1(t) and A0(t + 1) may be in flight (half mode: no A1)
         cbarrier();
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -3797,7 +3811,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
 #pragma unroll
             for (int i = 0; i < 4; ++i) af[i][ks] = read_frag(abuf, wm * 64 + i * 16, ks, lane);
         }
-        if (!grp1 && t + 1 < nk) issue_a(I1{}, t + 1);
+        if (!grp1 && t + 1 < nk && !half_mode) issue_a(I1{}, t + 1);
         if (grp1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // A0 / W reads done before their slots may be refilled
         cbarrier();
         __builtin_amdgcn_sched_barrier(0);
@@ -3811,12 +3825,14 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
                     acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][ks], af[i][ks], acc[i][nb], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
         // ---- phase 1: A1 ----
-        if (!grp1) ts_wait_tiles(t + 1 < nk ? 2 : 0);        // A1(t) landed; A0(t + 1) and A1(t + 1) may be in flight
+        if (!grp1 && !half_mode) ts_wait_tiles(t + 1 < nk ? 2 : 0);        // A1(t) landed; A0(t + 1) and A1(t + 1) may be in flight
         cbarrier();
+        if (!half_mode) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i][ks] = read_frag(abuf + HALF_BYTES, wm * 64 + i * 16, ks, lane);
+                for (int i = 0; i < 4; ++i) af[i][ks] = read_frag(abuf + HALF_BYTES, wm * 64 + i * 16, ks, lane);
+        }
         if (!grp1 && t + 2 < nk) issue_a(I0{}, t + 2);
         if (grp1) {
             if (t + TS_WD < nk) issue_w(t + TS_WD);
@@ -3825,15 +3841,17 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
         }
         cbarrier();
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+        if (!half_mode) {
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-                    acc[4 + i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][ks], af[i][ks], acc[4 + i][nb], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+                    for (int nb = 0; nb < 2; ++nb)
+                        acc[4 + i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][ks], af[i][ks], acc[4 + i][nb], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        }
     }
     if (!grp1) cbarrier();
     if constexpr (FUSE) {
@@ -3885,7 +3903,7 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
             return;
         }
         if (S == 1) {
-            tall_fused_epilogue(ep, acc, m0, n0 + wn * 32, wm, lane);
+            tall_fused_epilogue(ep, acc, m0, n0 + wn * 32, wm, lane, half_mode);
             return;
         }
         // S == 2, slice 0: publish below (slab region of slice 0), then the flag
@@ -6193,7 +6211,8 @@ static int tall_launch(hipStream_t s, int64_t M, const TallSide& g0, const TallS
     const int wg0 = tiles_m * (g0.N / 128) * (g0.s1 + g0.s2);
     const int wg1 = g1 ? tiles_m * (g1->N / 128) * (g1->s1 + g1->s2) : 0;
     if (fuse) {
-        hipLaunchKernelGGL((gemm_bf16_mfma256x128_slab_kernel<true, true>), dim3(wg0 + wg1), dim3(512), 0, s, ta, (int)M, wg0, *fuse);
+        const int grid = fuse->half_mode ? 2 * (wg0 + wg1) : wg0 + wg1;
+        hipLaunchKernelGGL((gemm_bf16_mfma256x128_slab_kernel<true, true>), dim3(grid), dim3(512), 0, s, ta, (int)M, wg0, *fuse);
         BT_LAUNCH_CHECK("mid-batch 256 x 128 fused GEMM launch");
         return BT_OK;
     }
@@ -6375,7 +6394,10 @@ int mid_qkv_gelu(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, c
         // launch; the attention of either decoder follows as its own launch (the caller sees attn_done == false)
         const int nk = (int)(K / 64);
         const int64_t n_tiles = ceil_div(M, 256) * ((N1 + N2) / 128);
-        if (g_mid_tall_fuse && counters && (slices == 1 || (slices == 2 && g_mid_tall_fuse >= 2 && nk >= 8)) && n_tiles < TF_STICKY && head_dim % 32 == 0 &&
+        // 129 .. 256 rows (one row tile, two K ranges in the slab form): with fused epilogues each workgroup takes ONE 128-row half of a
+        // column tile over the whole K instead -- same 224 workgroups, no hand-off (g_mid_tall_fuse == 3: off, A/B)
+        const bool halves = slices == 2 && M > 128 && M <= 256 && n_tiles % 8 == 0 && g_mid_tall_fuse != 3 && g_mid_tall_fuse != 2;
+        if (g_mid_tall_fuse && counters && (slices == 1 || halves || (slices == 2 && g_mid_tall_fuse == 2 && nk >= 8)) && n_tiles < TF_STICKY && head_dim % 32 == 0 &&
             ld_qkv % 4 == 0 && I % 4 == 0 && (reinterpret_cast<uintptr_t>(qkv) & 7u) == 0 && (reinterpret_cast<uintptr_t>(h4) & 7u) == 0 &&
             (reinterpret_cast<uintptr_t>(kc) & 7u) == 0 && (reinterpret_cast<uintptr_t>(vc) & 7u) == 0 &&
             (!qkv_b || (reinterpret_cast<uintptr_t>(qkv_b) & 7u) == 0) && (!h4_b || (reinterpret_cast<uintptr_t>(h4_b) & 7u) == 0)) {
@@ -6384,6 +6406,10 @@ int mid_qkv_gelu(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, c
             tf.ep[1] = e2;
             tf.flags = reinterpret_cast<uint32_t*>(counters);
             tf.first_nk = std::max(1, nk / 2 - 2);         // the finishing workgroup runs ~4 K-tiles longer: the partner's tile is there when it looks
+            if (halves) {
+                tf.half_mode = 1;
+                g0.s1 = g1.s1 = 1;                          // one K range per (tile, half)
+            }
             BT_TRY(tall_launch(s, M, g0, &g1, &tf));
             *done = true;
             return BT_OK;

@@ -608,11 +608,11 @@ _SLAB = SRC[SRC.index("void gemm_bf16_mfma256x128_slab_kernel("):]
 # (the K-loop ends where the round-6 fused form -- hand-off + epilogue, its own workgroup barriers -- or the slab stores begin)
 _SLAB = re.sub(r"\s+", "", re.sub(r"//[^\n]*", "", _SLAB[:min(_SLAB.index("// ---- slab stores"), _SLAB.index("const EpiArgs& ep = tf.ep[side];"))]))
 # the lines the streams below restate (comments and whitespace removed)
-for piece in ("if(!grp1){issue_a(I0{},0);issue_a(I1{},0);if(nk>1)issue_a(I0{},1);}else{for(intkt=0;kt<TS_WD&&kt<nk;++kt)issue_w(kt);}",
+for piece in ("if(!grp1){issue_a(I0{},0);if(!half_mode)issue_a(I1{},0);if(nk>1)issue_a(I0{},1);}else{for(intkt=0;kt<TS_WD&&kt<nk;++kt)issue_w(kt);}",
               "if(grp1){ts_wait_tiles(min(TS_WD,nk)-1);cbarrier();}",
-              "if(!grp1)ts_wait_tiles(t+1<nk?2:1);cbarrier();",
-              "if(!grp1&&t+1<nk)issue_a(I1{},t+1);if(grp1)asmvolatile(\"s_waitcntlgkmcnt(0)\":::\"memory\");cbarrier();",
-              "if(!grp1)ts_wait_tiles(t+1<nk?2:0);cbarrier();",
+              "if(!grp1)ts_wait_tiles((t+1<nk?2:1)-(half_mode?1:0));cbarrier();",
+              "if(!grp1&&t+1<nk&&!half_mode)issue_a(I1{},t+1);if(grp1)asmvolatile(\"s_waitcntlgkmcnt(0)\":::\"memory\");cbarrier();",
+              "if(!grp1&&!half_mode)ts_wait_tiles(t+1<nk?2:0);cbarrier();",
               "if(!grp1&&t+2<nk)issue_a(I0{},t+2);if(grp1){if(t+TS_WD<nk)issue_w(t+TS_WD);ts_wait_tiles(min(t+TS_WD,nk-1)-(t+1));"
               "asmvolatile(\"s_waitcntlgkmcnt(0)\":::\"memory\");}cbarrier();",
               "if(!grp1)cbarrier();ifconstexpr(FUSE){"):
@@ -622,8 +622,9 @@ assert "if(tiles>=4)wait_vmcnt_n<16>();elseif(tiles==3)wait_vmcnt_n<12>();elseif
     in re.sub(r"\s+", "", SRC[SRC.index("__device__ inline void ts_wait_tiles(int tiles)"):][:400])
 
 
-def _slab_stream(grp, nk, bad=None):
-    """program order of one wave; a tile (A half-tile or W) is four DMA instructions of the issuing wave"""
+def _slab_stream(grp, nk, bad=None, half=False):
+    """program order of one wave; a tile (A half-tile or W) is four DMA instructions of the issuing wave.  half: the round-6 fused form for
+    129 .. 256 rows -- a workgroup owns one 128-row half of a column tile: no A1 loads / reads, phase 1 only refills"""
     ev = []
 
     def dma(tag):
@@ -635,7 +636,8 @@ def _slab_stream(grp, nk, bad=None):
 
     if grp == 0:
         dma(("a0", 0))
-        dma(("a1", 0))
+        if not half:
+            dma(("a1", 0))
         if nk > 1:
             dma(("a0", 1))
     else:
@@ -645,17 +647,18 @@ def _slab_stream(grp, nk, bad=None):
         ev.append(("bar",))
     for t in range(nk):
         if grp == 0:
-            wait_tiles(2 if t + 1 < nk else 1)
+            wait_tiles((2 if t + 1 < nk else 1) - (1 if half else 0) + (1 if bad == "half_a0_late" else 0))
         ev.append(("bar",))
         ev.append(("read", ("w", t)))
         ev.append(("read", ("a0", t)))
-        if grp == 0 and t + 1 < nk:
+        if grp == 0 and t + 1 < nk and not half:
             dma(("a1", t + 1))
         ev.append(("bar",))
-        if grp == 0:
+        if grp == 0 and not half:
             wait_tiles((2 if t + 1 < nk else 0) + (1 if bad == "a1_late" else 0))
         ev.append(("bar",))
-        ev.append(("read", ("a1", t)))
+        if not half:
+            ev.append(("read", ("a1", t)))
         if grp == 0 and t + 2 < nk:
             dma(("a0", t + 2))
         if grp == 1:
@@ -668,8 +671,8 @@ def _slab_stream(grp, nk, bad=None):
     return ev
 
 
-def slab_model(nk, bad=None, depth=None):
-    waves = {g: _pp_analyse(_slab_stream(g, nk, bad)) for g in (0, 1)}
+def slab_model(nk, bad=None, depth=None, half=False):
+    waves = {g: _pp_analyse(_slab_stream(g, nk, bad, half)) for g in (0, 1)}
     assert len({v[3] for v in waves.values()}) == 1, "barrier counts differ between wave groups"
     owner = {"a0": 0, "a1": 0, "w": 1}
     ring = {"a0": 2, "a1": 2, "w": depth or TS_WD}
@@ -686,6 +689,9 @@ def slab_model(nk, bad=None, depth=None):
                 assert b >= last_read[prev] + 1, f"WAR nk={nk}: {tag} issued by group {key} too early"
     # every tile is issued exactly once, by its owner, and read by both groups
     for kind in ring:
+        if half and kind == "a1":
+            assert not any(t[0] == "a1" for t in waves[0][0])
+            continue
         assert sorted(t[1] for t in waves[owner[kind]][0] if t[0] == kind) == list(range(nk))
         for g in (0, 1):
             assert sorted(t[1] for t, _ in waves[g][2] if t[0] == kind) == list(range(nk))
@@ -694,6 +700,12 @@ def slab_model(nk, bad=None, depth=None):
 @pytest.mark.parametrize("nk", [1, 2, 3, 4, 5, 6, 7, 8, 10, 11, 16, 32])
 def test_slab_kernel_schedule(nk):
     slab_model(nk)
+    slab_model(nk, half=True)          # round 6: one 128-row half per workgroup (fused epilogues, 129 .. 256 rows)
+
+
+def test_slab_kernel_half_mode_model_detects_a_loose_wait():
+    with pytest.raises(AssertionError, match="RAW"):
+        slab_model(8, bad="half_a0_late", half=True)
 
 
 def test_slab_kernel_model_detects_errors():

@@ -1824,13 +1824,14 @@ def test_mid_rows_decoder_stack_vs_fp32_oracle(M, dbg_lib):
         assert (got - want).abs().max().item() <= 3e-2 * want.abs().max().item() + 1e-2
 
 
-@pytest.mark.parametrize("M", [97, 128, 200, 256, 257, 300, 512])
-@pytest.mark.parametrize("fuse", [0, 1, 2])
+@pytest.mark.parametrize("M", [97, 128, 129, 200, 255, 256, 257, 300, 512])
+@pytest.mark.parametrize("fuse", [0, 1, 2, 3])
 def test_mid_rows_fused_epilogue_launch_vs_oracle_and_reduce_launch(M, fuse, dbg_lib):
     """Round 6: the QKV + h->4h launch of the 97 .. 512-row path with its epilogues fused (bias, RoPE, K/V append, GELU in the GEMM's own
-    accumulator layout; no reduce launch).  fuse = 1 is the product (fusion where a tile has ONE K range: 257 .. 512 rows), 2 adds the
-    hand-off between a tile's two K ranges up to 256 rows (measured slower, debug A/B only: one flag per tile, write-through slab, bounded
-    polls), 0 the round-5 slab + reduce launches.  Decode step (q = 1 against a 40-row cache): hidden states and the appended K / V rows vs
+    accumulator layout; no reduce launch).  fuse = 1 is the product: fusion where a workgroup covers the whole K -- 257 .. 512 rows (two row
+    tiles) and 129 .. 256 rows (one 128-row HALF of a column tile per workgroup, phase 1 of every K-tile empty); 3 = the former only (A/B);
+    2 = instead of halves, the hand-off between a tile's two K ranges up to 256 rows (measured slower, debug A/B only: one flag per tile,
+    write-through slab, bounded polls); 0 = the round-5 slab + reduce launches.  Decode step (q = 1 against a 40-row cache): hidden states and the appended K / V rows vs
     the fp32 oracle, and every setting against fuse = 0 within one bf16 rounding of the same fp32 sums; repeated to catch a flag word
     left non-zero; the sticky time-out word stays clear (no BtError from the module forward)."""
     model, dims, o = _mid_stack()

@@ -1,0 +1,28 @@
+#!/bin/bash
+# round 6, GPU call 19: HALF mode of the fused mid-batch launch (129..256 rows): tests (fuse 0 / 1 / 2 / 3 vs oracle), A/B at B = 160 / 192 / 256
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+O=gpurun_out
+mkdir -p $O
+rm -f $O/r6_ab_mid_half_*.json
+timeout 1500 python -m pytest tests/test_model_gpu.py -x -q -m gpu -k "mid_ or batch_sizes_around or every_reference" > $O/r6_run19_tests.log 2>&1
+echo "tests rc=$?"; tail -4 $O/r6_run19_tests.log | cut -c1-300
+for B in 160 192 256; do
+  for v in 3 1 3 1; do
+    timeout 200 python tools/bench_knobs.py mid_tall_fuse=$v -- --batch $B --steps 8 --warmup 2 --no-cpu-baseline --no-roofline --no-secondary --no-parity --no-ceilings 2>/dev/null | tail -1 > $O/r6_ab_mid_half_${v}_b${B}_$RANDOM.json
+  done
+done
+python - <<'PY'
+import json, glob
+for f in sorted(glob.glob('gpurun_out/r6_ab_mid_half_*_b*.json')):
+    try:
+        d = json.loads(open(f).read())
+        print(f.split('/')[-1], round(d['value'], 1), 'decode-phase', round(d.get('decode_phase_tokens_per_s_per_gpu', 0), 1))
+    except Exception as e:
+        print(f, 'unreadable', e)
+PY
+for B in 192 256; do
+timeout 200 python bench.py --batch $B --steps 8 --warmup 2 --no-cpu-baseline --no-roofline --no-secondary --no-ceilings 2>/dev/null | tail -1 > $O/r6_sweep_half_b$B.json
+python -c "
+import json; d=json.loads(open('$O/r6_sweep_half_b$B.json').read()); p=d.get('parity_in_run') or {}; print('B=$B product', round(d['value'],1), p.get('ok'), p.get('ctx_err'), p.get('logit_err'))"
+done
