@@ -3610,7 +3610,10 @@ struct TallFuse {
     int first_nk;        // K-tiles of the publishing workgroup when a tile's K range is cut in two (the rest go to the finishing one)
     int half_mode;       // 129 .. 256 rows: a workgroup owns ONE 128-row half of a column tile over the whole K (grid = 2 x tiles, the two
                          // halves of a tile 8 block ids apart = on one XCD, so the W tile they both stream is fetched into that L2 once);
-                         // phase 1 of every K-tile (the A1 half) is empty: no A1 loads, no reads, no MFMAs -- one K range, no hand-off
+                         // its K-loop has one phase per K-tile (no A1 half) -- one K range, no hand-off
+    uint64_t* tl;        // debug build only (bt_debug_timeline_buffer, else null): 16 s_memtime stamps per wave, [workgroup][wave][16]
+    int dbg;             // debug build only, half mode, TIMING ONLY (wrong results): 1 = W addresses repeat after 4 K-tiles (W from L2), 2 = no A
+                         // loads behind the first four, 4 = no MFMAs, 8 = nt W loads, 16 = no W loads behind the first TS_WD
 };
 constexpr int TF_STICKY = 1023;      // word of the 4 KiB counter region that holds the sticky time-out value
 
@@ -3702,6 +3705,19 @@ template <bool WT, bool FUSE = false>
 __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const TallArgs a, int M, int wg_side1, const TallFuse tf = TallFuse{}) {
     static_assert(TS_WD >= 2 && TS_WD <= 5, "ts_wait_tiles covers up to four W tiles in flight behind the awaited one");
     __shared__ __attribute__((aligned(16))) char smem[TS_SMEM];
+#ifdef BT_DEBUG_HOOKS
+    // timeline of the fused launch (tools/bench_knobs.py, BT_MID_TL=1): 0 entry, 1 prologue issued, 2 first K-tile opens, 3 / 4 / 5 a quarter /
+    // half / three quarters of the K-tiles done, 6 K-loop done, 7 epilogue starts, 8 its last store issued, 9 s_memrealtime at entry
+    uint64_t tstamp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    bool tl_on = false;
+    if constexpr (FUSE) tl_on = tf.tl != nullptr;
+#define TS_STAMP(i) do { if constexpr (FUSE) { if (tl_on) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstamp[i]) : : "memory"); } } while (0)
+#define TS_STAMP_AT(t, nk) do { if constexpr (FUSE) { if (tl_on) { if ((t) == (nk) / 4) TS_STAMP(3); else if ((t) == (nk) / 2) TS_STAMP(4); else if ((t) == (nk) * 3 / 4) TS_STAMP(5); } } } while (0)
+    if constexpr (FUSE) { if (tl_on) asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstamp[0]), "=s"(tstamp[9]) : : "memory"); }
+#else
+#define TS_STAMP(i) do {} while (0)
+#define TS_STAMP_AT(t, nk) do {} while (0)
+#endif
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 2, wn = wave & 3;
@@ -3764,6 +3780,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
         glds16_sbase_off<half * HALF_BYTES + 2048>(pa, va[half][2] + koff, ring);
         glds16_sbase_off<half * HALF_BYTES + 3072>(pa, va[half][3] + koff, ring);
     };
+#ifdef BT_DEBUG_HOOKS
+    int dbg = 0;
+    if constexpr (FUSE) dbg = tf.dbg;
+#else
+    constexpr int dbg = 0;
+#endif
     int w_slot = 0;                          // group 1: ring slot of the next W tile to issue (= its K-tile mod TS_WD)
     auto issue_w = [&](int kt) {
         const uint32_t ring = w_lds + (uint32_t)w_slot * (uint32_t)HALF_BYTES;
@@ -3776,15 +3798,49 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
-    // prologue: group 0 -> A0(0), A1(0), A0(1); group 1 -> W(0 .. TS_WD - 1)
+    auto issue_ah = [&](int kt) {            // half mode, group 0: the workgroup's 128 rows of K-tile kt -> A ring slot kt & 3 (four 16 KiB slots)
+        const uint32_t ring = a_lds + (uint32_t)(kt & 3) * (uint32_t)HALF_BYTES;
+        const uint32_t koff = (uint32_t)kt * 128u;
+        if ((dbg & 2) && kt >= 4) return;
+        glds16_sbase_off<0>(pa, va[0][0] + koff, ring);
+        glds16_sbase_off<1024>(pa, va[0][1] + koff, ring);
+        glds16_sbase_off<2048>(pa, va[0][2] + koff, ring);
+        glds16_sbase_off<3072>(pa, va[0][3] + koff, ring);
+    };
+    auto issue_wh = [&](int kt) {            // half mode, group 1: W(kt) with plain loads -- the tile's other half streams the same W tile on the same XCD
+        const uint32_t ring = w_lds + (uint32_t)w_slot * (uint32_t)HALF_BYTES;
+        const uint32_t v0 = vw + (uint32_t)((dbg & 1) ? (kt & 3) : kt) * 128u;
+        if ((dbg & 16) && kt >= TS_WD) {
+        } else if (dbg & 8) {
+            glds16_sbase_off_nt<0>(pw, v0, ring);
+            glds16_sbase_off_nt<1024>(pw, v0 + row8_w, ring);
+            glds16_sbase_off_nt<2048>(pw, v0 + 2 * row8_w, ring);
+            glds16_sbase_off_nt<3072>(pw, v0 + 3 * row8_w, ring);
+        } else {
+            glds16_sbase_off<0>(pw, v0, ring);
+            glds16_sbase_off<1024>(pw, v0 + row8_w, ring);
+            glds16_sbase_off<2048>(pw, v0 + 2 * row8_w, ring);
+            glds16_sbase_off<3072>(pw, v0 + 3 * row8_w, ring);
+        }
+        w_slot = w_slot + 1 == TS_WD ? 0 : w_slot + 1;
+    };
+    // prologue: group 0 -> A0(0), A1(0), A0(1) (half mode: A(0 .. 2)); group 1 -> W(0 .. TS_WD - 1)
     if (!grp1) {
-        issue_a(I0{}, 0);
-        if (!half_mode) issue_a(I1{}, 0);
-        if (nk > 1) issue_a(I0{}, 1);
+        if (half_mode) {
+            for (int kt = 0; kt < 3 && kt < nk; ++kt) issue_ah(kt);
+        } else {
+            issue_a(I0{}, 0);
+            issue_a(I1{}, 0);
+            if (nk > 1) issue_a(I0{}, 1);
+        }
     } else {
-        for (int kt = 0; kt < TS_WD && kt < nk; ++kt) issue_w(kt);
+        for (int kt = 0; kt < TS_WD && kt < nk; ++kt) {
+            if (half_mode) issue_wh(kt);
+            else issue_w(kt);
+        }
     }
 
+    TS_STAMP(1);
     f32x4_t acc[8][2];   // [A half * 4 + m-fragment][n-fragment]
 #pragma unroll
     for (int i = 0; i < 8; ++i)
@@ -3796,52 +3852,52 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
         ts_wait_tiles(min(TS_WD, nk) - 1);   // W(0) has landed
         cbarrier();
     }
+    TS_STAMP(2);
     int r_slot = 0;                          // ring slot of W(t)
-    for (int t = 0; t < nk; ++t) {
-        const char* abuf = smem + (t & 1) * TS_A_STAGE;
-        const char* wbuf = smem + 2 * TS_A_STAGE + r_slot * HALF_BYTES;
-        r_slot = r_slot + 1 == TS_WD ? 0 : r_slot + 1;
-        // ---- phase 0: A0, W ----
-        if (!grp1) ts_wait_tiles((t + 1 < nk ? 2 : 1) - (half_mode ? 1 : 0));   // A0(t) landed; A1(t) and A0(t + 1) may be in flight (half mode: no A1)
-        cbarrier();
+    if (!half_mode) {
+        for (int t = 0; t < nk; ++t) {
+            TS_STAMP_AT(t, nk);
+            const char* abuf = smem + (t & 1) * TS_A_STAGE;
+            const char* wbuf = smem + 2 * TS_A_STAGE + r_slot * HALF_BYTES;
+            r_slot = r_slot + 1 == TS_WD ? 0 : r_slot + 1;
+            // ---- phase 0: A0, W ----
+            if (!grp1) ts_wait_tiles(t + 1 < nk ? 2 : 1);   // A0(t) landed; A1(t) and A0(t + 1) may be in flight
+            cbarrier();
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+            for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) wf[nb][ks] = read_frag(wbuf, wn * 32 + nb * 16, ks, lane);
+                for (int nb = 0; nb < 2; ++nb) wf[nb][ks] = read_frag(wbuf, wn * 32 + nb * 16, ks, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i][ks] = read_frag(abuf, wm * 64 + i * 16, ks, lane);
-        }
-        if (!grp1 && t + 1 < nk && !half_mode) issue_a(I1{}, t + 1);
-        if (grp1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // A0 / W reads done before their slots may be refilled
-        cbarrier();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
+                for (int i = 0; i < 4; ++i) af[i][ks] = read_frag(abuf, wm * 64 + i * 16, ks, lane);
+            }
+            if (!grp1 && t + 1 < nk) issue_a(I1{}, t + 1);
+            if (grp1) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // A0 / W reads done before their slots may be refilled
+            cbarrier();
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-                    acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][ks], af[i][ks], acc[i][nb], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
-        // ---- phase 1: A1 ----
-        if (!grp1 && !half_mode) ts_wait_tiles(t + 1 < nk ? 2 : 0);        // A1(t) landed; A0(t + 1) and A1(t + 1) may be in flight
-        cbarrier();
-        if (!half_mode) {
+                    for (int nb = 0; nb < 2; ++nb)
+                        acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][ks], af[i][ks], acc[i][nb], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            // ---- phase 1: A1 ----
+            if (!grp1) ts_wait_tiles(t + 1 < nk ? 2 : 0);        // A1(t) landed; A0(t + 1) and A1(t + 1) may be in flight
+            cbarrier();
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) af[i][ks] = read_frag(abuf + HALF_BYTES, wm * 64 + i * 16, ks, lane);
-        }
-        if (!grp1 && t + 2 < nk) issue_a(I0{}, t + 2);
-        if (grp1) {
-            if (t + TS_WD < nk) issue_w(t + TS_WD);
-            ts_wait_tiles(min(t + TS_WD, nk - 1) - (t + 1));   // W(t + 1) landed (its wait for phase 0 of K-tile t + 1)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // A1 reads done before group 0 may refill the slot
-        }
-        cbarrier();
-        __builtin_amdgcn_sched_barrier(0);
-        if (!half_mode) {
+            if (!grp1 && t + 2 < nk) issue_a(I0{}, t + 2);
+            if (grp1) {
+                if (t + TS_WD < nk) issue_w(t + TS_WD);
+                ts_wait_tiles(min(t + TS_WD, nk - 1) - (t + 1));   // W(t + 1) landed (its wait for phase 0 of K-tile t + 1)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // A1 reads done before group 0 may refill the slot
+            }
+            cbarrier();
+            __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
@@ -3852,8 +3908,73 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
                         acc[4 + i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][ks], af[i][ks], acc[4 + i][nb], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
         }
+    } else {
+        // ---- half mode: ONE phase per K-tile (two barriers instead of four).  Group 1 runs one barrier behind group 0, so one group's
+        // fragment reads overlap the other's MFMAs.  A ring = four 16 KiB slots (the [A0 | A1] stages of the full form), A(t + 3)
+        // issued by group 0 behind the barrier that opens its reads of t (both groups' reads of t - 1 are complete there: group 0's fed
+        // its MFMAs of t - 1, group 1 drained lgkmcnt in front of the same barrier); W(t + TS_WD) issued by group 1 behind the barrier
+        // that closes its reads of t (group 0 passed it after issuing its MFMAs of t).  RAW: A(t) waited for by group 0 in front of
+        // the barrier that opens its reads of t, W(t + 1) by group 1 in front of the barrier that closes its reads of t (= the one
+        // group 0 opens its reads of t + 1 with).
+        // Measured at 256 rows (profiles/r6_mid_half_mode_ablations.md): this form 31.1 us per launch; the full loop's four barriers
+        // with an empty phase 1: 34.5; one barrier per K-tile with the fragments double-buffered in registers: 33.5; the refills
+        // issued piecewise inside the MFMA block: 38.6.  Timing-only ablations put the K-tile at ~1600 cycles against 512 of MFMA per
+        // SIMD: W served from L2 alone (an eighth of the HBM traffic) changes nothing, no W loads -18 %, no MFMAs -26 %, neither 1080
+        // -- the per-CU load path (32 KiB per K-tile in 1 KiB LDS-DMA pieces) and the barrier-coupled phases bound it, not HBM.
+        for (int t = 0; t < nk; ++t) {
+            TS_STAMP_AT(t, nk);
+            const char* abuf = smem + (t & 3) * HALF_BYTES;
+            const char* wbuf = smem + 2 * TS_A_STAGE + r_slot * HALF_BYTES;
+            r_slot = r_slot + 1 == TS_WD ? 0 : r_slot + 1;
+            if (!grp1) ts_wait_tiles(min(t + 2, nk - 1) - t);   // A(t) landed; A(t + 1), A(t + 2) may be in flight
+            cbarrier();
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) wf[nb][ks] = read_frag(wbuf, wn * 32 + nb * 16, ks, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[i][ks] = read_frag(abuf, wm * 64 + i * 16, ks, lane);
+            }
+            if (!grp1 && t + 3 < nk) issue_ah(t + 3);
+            if (grp1) {
+                ts_wait_tiles(max(min(t + TS_WD - 1, nk - 1) - (t + 1), 0));   // W(t + 1) landed; W(t + 2 .. t + TS_WD - 1) may be in flight
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // A / W reads done before their slots may be refilled
+            }
+            cbarrier();
+            if (grp1 && t + TS_WD < nk) issue_wh(t + TS_WD);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+            if (!(dbg & 4)) {
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb)
+                            acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nb][ks], af[i][ks], acc[i][nb], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
     }
+    TS_STAMP(6);
     if (!grp1) cbarrier();
+    TS_STAMP(7);
+#ifdef BT_DEBUG_HOOKS
+    auto tl_dump = [&]() {
+        if constexpr (FUSE) {
+            if (tl_on) {
+                TS_STAMP(8);
+                if (lane == 0) {
+                    uint64_t* o = tf.tl + ((int64_t)blockIdx.x * 8 + wave) * 16;
+#pragma unroll
+                    for (int i = 0; i < 10; ++i) o[i] = tstamp[i];
+                }
+            }
+        }
+    };
+#else
+    auto tl_dump = [&]() {};
+#endif
     if constexpr (FUSE) {
         const EpiArgs& ep = tf.ep[side];
         uint32_t* flag = tf.flags + (side ? (wg_side1 / S) : 0) + tile;          // one word per (side, tile)
@@ -3900,10 +4021,12 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
                 }
             }
             tall_fused_epilogue(ep, acc, m0, n0 + wn * 32, wm, lane);
+            tl_dump();
             return;
         }
         if (S == 1) {
             tall_fused_epilogue(ep, acc, m0, n0 + wn * 32, wm, lane, half_mode);
+            tl_dump();
             return;
         }
         // S == 2, slice 0: publish below (slab region of slice 0), then the flag
@@ -3930,6 +4053,9 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
         if (wave == 0) sk_flag_store(tf.flags + (side ? (wg_side1 / S) : 0) + tile, 1u);
     }
 }
+
+#undef TS_STAMP
+#undef TS_STAMP_AT
 
 // ---- GEMV for a handful of rows (M <= 4): the weight-streaming regime of small-batch decode ------------------------------
 // out[m, n] = epi(sum_k x[m, k] * W[n, k]).  One pass over W at HBM speed is the whole cost (N*K*2 bytes; x is a few KiB), so
@@ -4949,6 +5075,7 @@ BT_KNOB int g_small_stages = 0;   // LDS ring depth of the 128^2 / 128x64 / 64x6
 // kernel's last round under 90 % full, and for bt_linear2 above 256 rows: 1 = on (needs the caller's scratch: slabs + flags), 0 = A/B
 BT_KNOB int g_sk = 1;
 #ifdef BT_DEBUG_HOOKS
+static int g_mid_tall_dbg = 0;       // bt_debug_mid_tall_dbg: timing-only ablations of the half-mode fused launch (TallFuse::dbg)
 static void* g_timeline = nullptr;   // bt_debug_timeline_buffer: 4 workgroups x 8 waves x 128 stamps of 8 bytes (variant 28)
 #endif
 #ifdef BT_DEBUG_HOOKS
@@ -6410,6 +6537,10 @@ int mid_qkv_gelu(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, c
                 tf.half_mode = 1;
                 g0.s1 = g1.s1 = 1;                          // one K range per (tile, half)
             }
+#ifdef BT_DEBUG_HOOKS
+            tf.tl = reinterpret_cast<uint64_t*>(g_timeline);
+            tf.dbg = g_mid_tall_dbg;
+#endif
             BT_TRY(tall_launch(s, M, g0, &g1, &tf));
             *done = true;
             return BT_OK;
@@ -6530,6 +6661,7 @@ extern "C" void bt_debug_mid_tall(int mode) { g_mid_tall = mode; }
 extern "C" void bt_debug_mid_tall_wgs(int wgs) { g_mid_tall_wgs = wgs > 0 ? wgs : 256; }
 extern "C" void bt_debug_mid_tall_wt(int on) { g_mid_tall_wt = on != 0; }
 extern "C" void bt_debug_mid_tall_fuse(int mode) { g_mid_tall_fuse = mode; }
+extern "C" void bt_debug_mid_tall_dbg(int bits) { g_mid_tall_dbg = bits; }
 extern "C" void bt_debug_mid_wt(int on) { g_mid_wt = on != 0; }
 extern "C" void bt_debug_mid_rows_max(int rows) { g_mid_rows_max = rows; }
 extern "C" void bt_debug_mid_tall_wgs_res(int wgs) { g_mid_tall_wgs_res = wgs > 0 ? wgs : 256; }

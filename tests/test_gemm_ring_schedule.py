@@ -608,23 +608,30 @@ _SLAB = SRC[SRC.index("void gemm_bf16_mfma256x128_slab_kernel("):]
 # (the K-loop ends where the round-6 fused form -- hand-off + epilogue, its own workgroup barriers -- or the slab stores begin)
 _SLAB = re.sub(r"\s+", "", re.sub(r"//[^\n]*", "", _SLAB[:min(_SLAB.index("// ---- slab stores"), _SLAB.index("const EpiArgs& ep = tf.ep[side];"))]))
 # the lines the streams below restate (comments and whitespace removed)
-for piece in ("if(!grp1){issue_a(I0{},0);if(!half_mode)issue_a(I1{},0);if(nk>1)issue_a(I0{},1);}else{for(intkt=0;kt<TS_WD&&kt<nk;++kt)issue_w(kt);}",
+for piece in ("if(!grp1){if(half_mode){for(intkt=0;kt<3&&kt<nk;++kt)issue_ah(kt);}else{issue_a(I0{},0);issue_a(I1{},0);if(nk>1)issue_a(I0{},1);}}"
+              "else{for(intkt=0;kt<TS_WD&&kt<nk;++kt){if(half_mode)issue_wh(kt);elseissue_w(kt);}}",
               "if(grp1){ts_wait_tiles(min(TS_WD,nk)-1);cbarrier();}",
-              "if(!grp1)ts_wait_tiles((t+1<nk?2:1)-(half_mode?1:0));cbarrier();",
-              "if(!grp1&&t+1<nk&&!half_mode)issue_a(I1{},t+1);if(grp1)asmvolatile(\"s_waitcntlgkmcnt(0)\":::\"memory\");cbarrier();",
-              "if(!grp1&&!half_mode)ts_wait_tiles(t+1<nk?2:0);cbarrier();",
+              "if(!grp1)ts_wait_tiles(t+1<nk?2:1);cbarrier();",
+              "if(!grp1&&t+1<nk)issue_a(I1{},t+1);if(grp1)asmvolatile(\"s_waitcntlgkmcnt(0)\":::\"memory\");cbarrier();",
+              "if(!grp1)ts_wait_tiles(t+1<nk?2:0);cbarrier();",
               "if(!grp1&&t+2<nk)issue_a(I0{},t+2);if(grp1){if(t+TS_WD<nk)issue_w(t+TS_WD);ts_wait_tiles(min(t+TS_WD,nk-1)-(t+1));"
               "asmvolatile(\"s_waitcntlgkmcnt(0)\":::\"memory\");}cbarrier();",
-              "if(!grp1)cbarrier();ifconstexpr(FUSE){"):
+              # half mode (round 6): one phase per K-tile (two barriers), A ring of four slots
+              "constuint32_tring=a_lds+(uint32_t)(kt&3)*(uint32_t)HALF_BYTES;",
+              "constchar*abuf=smem+(t&3)*HALF_BYTES;",
+              "if(!grp1)ts_wait_tiles(min(t+2,nk-1)-t);cbarrier();",
+              "if(!grp1&&t+3<nk)issue_ah(t+3);if(grp1){ts_wait_tiles(max(min(t+TS_WD-1,nk-1)-(t+1),0));"
+              "asmvolatile(\"s_waitcntlgkmcnt(0)\":::\"memory\");}cbarrier();if(grp1&&t+TS_WD<nk)issue_wh(t+TS_WD);",
+              "TS_STAMP(6);if(!grp1)cbarrier();TS_STAMP(7);"):
     assert piece in _SLAB, piece
-assert _SLAB.count("cbarrier();") == 6 and _SLAB.count("ts_wait_tiles(") == 4
+assert _SLAB.count("cbarrier();") == 8 and _SLAB.count("ts_wait_tiles(") == 6
 assert "if(tiles>=4)wait_vmcnt_n<16>();elseif(tiles==3)wait_vmcnt_n<12>();elseif(tiles==2)wait_vmcnt_n<8>();elseif(tiles==1)wait_vmcnt_n<4>();elsewait_vmcnt_n<0>();" \
     in re.sub(r"\s+", "", SRC[SRC.index("__device__ inline void ts_wait_tiles(int tiles)"):][:400])
 
 
 def _slab_stream(grp, nk, bad=None, half=False):
     """program order of one wave; a tile (A half-tile or W) is four DMA instructions of the issuing wave.  half: the round-6 fused form for
-    129 .. 256 rows -- a workgroup owns one 128-row half of a column tile: no A1 loads / reads, phase 1 only refills"""
+    129 .. 256 rows -- a workgroup owns one 128-row half of a column tile: ONE phase per K-tile (two barriers), A ring of four slots"""
     ev = []
 
     def dma(tag):
@@ -634,10 +641,36 @@ def _slab_stream(grp, nk, bad=None, half=False):
     def wait_tiles(n):
         ev.append(("wait", 4 * min(max(n, 0), 4)))
 
+    if half:     # one phase per K-tile (two barriers), group 1 one barrier behind
+        if grp == 0:
+            for kt in range(min(3, nk)):
+                dma(("a0", kt))
+        else:
+            for kt in range(min(TS_WD, nk)):
+                dma(("w", kt))
+            wait_tiles(min(TS_WD, nk) - 1)
+            ev.append(("bar",))
+        for t in range(nk):
+            if grp == 0:
+                wait_tiles(min(t + 2, nk - 1) - t + (1 if bad == "half_a0_late" else 0))
+            ev.append(("bar",))
+            ev.append(("read", ("w", t)))
+            ev.append(("read", ("a0", t)))
+            if grp == 0 and t + 3 < nk:
+                dma(("a0", t + 3))
+            if grp == 1:
+                wait_tiles(max(min(t + TS_WD - 1, nk - 1) - (t + 1), 0) + (1 if bad == "half_w_late" else 0))
+            if grp == 1 and bad == "half_w_early" and t + TS_WD < nk:
+                dma(("w", t + TS_WD))
+            ev.append(("bar",))
+            if grp == 1 and bad != "half_w_early" and t + TS_WD < nk:
+                dma(("w", t + TS_WD))
+        if grp == 0:
+            ev.append(("bar",))
+        return ev
     if grp == 0:
         dma(("a0", 0))
-        if not half:
-            dma(("a1", 0))
+        dma(("a1", 0))
         if nk > 1:
             dma(("a0", 1))
     else:
@@ -647,18 +680,17 @@ def _slab_stream(grp, nk, bad=None, half=False):
         ev.append(("bar",))
     for t in range(nk):
         if grp == 0:
-            wait_tiles((2 if t + 1 < nk else 1) - (1 if half else 0) + (1 if bad == "half_a0_late" else 0))
+            wait_tiles(2 if t + 1 < nk else 1)
         ev.append(("bar",))
         ev.append(("read", ("w", t)))
         ev.append(("read", ("a0", t)))
-        if grp == 0 and t + 1 < nk and not half:
+        if grp == 0 and t + 1 < nk:
             dma(("a1", t + 1))
         ev.append(("bar",))
-        if grp == 0 and not half:
+        if grp == 0:
             wait_tiles((2 if t + 1 < nk else 0) + (1 if bad == "a1_late" else 0))
         ev.append(("bar",))
-        if not half:
-            ev.append(("read", ("a1", t)))
+        ev.append(("read", ("a1", t)))
         if grp == 0 and t + 2 < nk:
             dma(("a0", t + 2))
         if grp == 1:
@@ -675,7 +707,7 @@ def slab_model(nk, bad=None, depth=None, half=False):
     waves = {g: _pp_analyse(_slab_stream(g, nk, bad, half)) for g in (0, 1)}
     assert len({v[3] for v in waves.values()}) == 1, "barrier counts differ between wave groups"
     owner = {"a0": 0, "a1": 0, "w": 1}
-    ring = {"a0": 2, "a1": 2, "w": depth or TS_WD}
+    ring = {"a0": 4 if half else 2, "a1": 2, "w": depth or TS_WD}
     last_read = {}
     for key, (issue, done, reads, _) in waves.items():
         for tag, b in reads:
@@ -703,9 +735,13 @@ def test_slab_kernel_schedule(nk):
     slab_model(nk, half=True)          # round 6: one 128-row half per workgroup (fused epilogues, 129 .. 256 rows)
 
 
-def test_slab_kernel_half_mode_model_detects_a_loose_wait():
+def test_slab_kernel_half_mode_model_detects_errors():
     with pytest.raises(AssertionError, match="RAW"):
         slab_model(8, bad="half_a0_late", half=True)
+    with pytest.raises(AssertionError, match="RAW"):
+        slab_model(8, bad="half_w_late", half=True)
+    with pytest.raises(AssertionError, match="WAR"):
+        slab_model(12, bad="half_w_early", half=True)     # W(t + TS_WD) in front of the barrier that closes group 1's reads of t
 
 
 def test_slab_kernel_model_detects_errors():

@@ -31,9 +31,40 @@ diag = None
 if os.environ.get("BT_SK_DIAG") == "1":      # never-cleared record of stream-K hand-off time-outs (debug build), printed if the run dies
     diag = torch.zeros(8 + 64 * 8 + 64, dtype=torch.int32, device="cuda")
     lib().bt_debug_sk_diag_buffer(diag.data_ptr())
+mid_tl = None
+if os.environ.get("BT_MID_TL") == "1":       # timeline of the fused mid-batch QKV + h->4h launch (debug build): the LAST launch's stamps survive
+    mid_tl = torch.zeros(512 * 8 * 16, dtype=torch.int64, device="cuda")
+    lib().bt_debug_timeline_buffer(mid_tl.data_ptr())
 try:
     runpy.run_path(sys.argv[0], run_name="__main__")
 finally:
+    if mid_tl is not None:
+        import json
+        torch.cuda.synchronize()
+        raw = mid_tl.view(512, 8, 16).cpu()
+        used = raw[:, 0, 0] != 0
+        n_wg = int(used.sum())
+        st = raw[used][:, :, :10].double()                       # [wg, wave, stamp]
+        t0 = st[:, :, 0].min()
+        rel = st[:, :, :9] - t0                                   # ticks since the first wave's entry (s_memtime: 100 MHz on this part)
+        names = ["entry", "prologue_issued", "first_tile_opens", "quarter", "half", "three_quarters", "loop_done", "epilogue_starts", "epilogue_done"]
+        rec = {"op": "mid_fused_timeline", "workgroups": n_wg, "unit": "s_memtime ticks (10 ns) since the first wave's entry"}
+        for i, nme in enumerate(names):
+            v = rel[:, :, i].flatten()
+            rec[nme] = {"min": float(v.min()), "median": float(v.median()), "max": float(v.max())}
+        for g, sl in (("group0", slice(0, 4)), ("group1", slice(4, 8))):
+            d = st[:, sl]
+            rec[g + "_median_ticks"] = {"entry_to_first_tile": float((d[:, :, 2] - d[:, :, 0]).median()),
+                                         "k_loop": float((d[:, :, 6] - d[:, :, 2]).median()),
+                                         "first_quarter": float((d[:, :, 3] - d[:, :, 2]).median()),
+                                         "second_quarter": float((d[:, :, 4] - d[:, :, 3]).median()),
+                                         "third_quarter": float((d[:, :, 5] - d[:, :, 4]).median()),
+                                         "fourth_quarter": float((d[:, :, 6] - d[:, :, 5]).median()),
+                                         "epilogue": float((d[:, :, 8] - d[:, :, 7]).median()),
+                                         "whole": float((d[:, :, 8] - d[:, :, 0]).median())}
+        rt = raw[used][:, 0, 9].double()
+        rec["entry_spread_realtime_ticks"] = float(rt.max() - rt.min())
+        print("[bench_knobs] " + json.dumps(rec), file=sys.stderr)
     if diag is not None:
         n = int(diag[0].item())
         print(f"[bench_knobs] stream-K time-outs recorded on the device: {n}", file=sys.stderr)
