@@ -1825,7 +1825,7 @@ def test_mid_rows_decoder_stack_vs_fp32_oracle(M, dbg_lib):
 
 
 @pytest.mark.parametrize("M", [97, 128, 129, 200, 255, 256, 257, 300, 512])
-@pytest.mark.parametrize("fuse", [0, 1, 2, 3])
+@pytest.mark.parametrize("fuse", [1, 2, 3])          # (0 = the slab + reduce launches: the reference run inside every case)
 def test_mid_rows_fused_epilogue_launch_vs_oracle_and_reduce_launch(M, fuse, dbg_lib):
     """Round 6: the QKV + h->4h launch of the 97 .. 512-row path with its epilogues fused (bias, RoPE, K/V append, GELU in the GEMM's own
     accumulator layout; no reduce launch).  fuse = 1 is the product: fusion where a workgroup covers the whole K -- 257 .. 512 rows (two row
