@@ -4057,6 +4057,155 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
 #undef TS_STAMP
 #undef TS_STAMP_AT
 
+// ---- round 6 EXPERIMENT (debug build only, bt_debug_mid_tall_fuse(5)): the fused QKV + h->4h launch at 129 .. 256 rows, STREAM form -------------
+// Measured SLOWER than the half-mode loop above (35.0 us per launch against 31.1 at 256 rows; with A eight K-tiles ahead as well: 36.6),
+// oracle-clean (tests/test_model_gpu.py::test_mid_rows_fused_launch_at_1p2b_width_vs_oracle).  Kept as the A/B that rules out two
+// explanations of the half mode's 0.75 us per K-tile -- LDS-DMA issue cost / barrier count (none of the former, half of the latter here)
+// and prefetch depth (4 -> 8 K-tiles changes nothing): either form moves 32 KiB per K-tile into a CU at 35-45 GB/s, the rate of the
+// CU's load path for 16-byte-per-lane loads whatever their destination (profiles/r6_mid_half_mode_ablations.md).
+// The kernel does the same work per workgroup -- one 128-row half of a 128-column tile over the whole K, same grid, same epilogue -- with
+//   * W never in LDS: a wave streams ITS fragments global -> registers (two 16-byte loads per lane and K-tile, MS_PW K-tiles ahead), so the
+//     weight stream needs no barrier, no LDS-DMA issue and no ring slot;
+//   * the K-tile's two 32-wide k-steps split between the wave pair (kh = wave >> 2): a wave owns 128 rows x 32 columns at ONE k-step
+//     (8 A fragments + 2 W fragments -> 16 MFMAs), so no W fragment is loaded twice and a wave reads half of the A tile;
+//   * A through LDS by plain loads + ds_write_b128 (MS_PA K-tiles ahead in registers, double-buffered in LDS): every vmcnt is the
+//     compiler's, counted exactly; ONE barrier per K-tile (behind it: A(t + 1) registers -> the other LDS buffer, fragment reads of
+//     A(t), the refills, the MFMAs);
+//   * at the end the pair exchanges halves through LDS (kh = 0 keeps rows 0-63 of the half, kh = 1 rows 64-127, each adds the partner's
+//     partial sums) and every wave runs tall_fused_epilogue on 64 rows x 32 columns exactly as in half mode.
+// Hazards: the LDS buffer (t + 1) & 1 was last read for A(t - 1); every wave drains lgkmcnt in front of barrier B(t), the writes of
+// A(t + 1) come behind it and are drained in front of B(t + 1), the reads of A(t + 1) come behind that.
+// Requires nk % MS_PW == 0, nk >= 2 MS_PW, N % 128 == 0, one K range per tile (host: mid_qkv_gelu).
+#ifdef BT_DEBUG_HOOKS
+constexpr int MS_PW = 8;      // W fragments in flight (K-tiles)
+constexpr int MS_PA = 4;      // A row pieces in flight in registers (K-tiles; 8 measured no faster: 36.6 vs 35.0 us)
+constexpr int MS_SMEM = 65536;
+
+__global__ __launch_bounds__(512) void gemm_bf16_mid_stream_kernel(const TallArgs a, int M, int wg_side1, const TallFuse tf) {
+    static_assert(MS_PW % MS_PA == 0 && MS_PW % 2 == 0, "static register / buffer indices inside one unrolled group");
+    __shared__ __attribute__((aligned(16))) char smem[MS_SMEM];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kh = wave >> 2, wn = wave & 3;
+    const int q = (int)blockIdx.x >> 3, x = (int)blockIdx.x & 7;     // block b = 8 q + x: half = q & 1, column tile (q >> 1) * 8 + x
+    const int half = q & 1, lin = (q >> 1) * 8 + x;
+    const int side = lin >= wg_side1 ? 1 : 0;
+    const TallSide& g = a.g[side];
+    const int tile = lin - side * wg_side1;
+    const int n0 = tile * 128, m0 = half * 128;
+    const int nk = g.nk1;
+    const int64_t lda = g.lda, ldw = g.ldw;
+    // A: wave w stages rows w * 16 .. + 15 of the half (two 8-row pieces), lane = (row in piece, 16-byte chunk); LDS image = the
+    // XOR-swizzled 128-byte rows read_frag expects
+    const char* pa[2];
+    uint32_t la[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = wave * 16 + j * 8 + (lane >> 3);
+        pa[j] = reinterpret_cast<const char*>(g.A) + (int64_t)min(m0 + r, M - 1) * lda * 2 + (lane & 7) * 16;
+        la[j] = (uint32_t)(r * 128 + (((lane & 7) ^ (r & 7)) << 4));
+    }
+    // W: rows n0 + wn * 32 + nb * 16 + (lane & 15), bytes kt * 128 + kh * 64 + (lane >> 4) * 16
+    const char* pw[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+        pw[nb] = reinterpret_cast<const char*>(g.W) + (int64_t)(n0 + wn * 32 + nb * 16 + (lane & 15)) * ldw * 2 + kh * 64 + (lane >> 4) * 16;
+    auto load_a = [&](int kt, bf16x8_t (&r)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) r[j] = *reinterpret_cast<const bf16x8_t*>(pa[j] + (int64_t)kt * 128);
+    };
+    auto load_w = [&](int kt, bf16x8_t (&r)[2]) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) r[nb] = *reinterpret_cast<const bf16x8_t*>(pw[nb] + (int64_t)kt * 128);   // (plain: the tile's other half reads the same lines on this XCD)
+    };
+    auto write_a = [&](int buf, const bf16x8_t (&r)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<bf16x8_t*>(smem + buf * 16384 + la[j]) = r[j];
+    };
+
+    bf16x8_t ar[MS_PA][2], wr[MS_PW][2];
+    f32x4_t acc[8][2];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    // prologue: A(0) -> LDS buffer 0; A(1 .. MS_PA) and W(0 .. MS_PW - 1) in registers
+    load_a(0, ar[0]);
+#pragma unroll
+    for (int k = 0; k < MS_PW; ++k) load_w(k, wr[k]);
+    write_a(0, ar[0]);
+#pragma unroll
+    for (int k = 1; k <= MS_PA; ++k) load_a(k, ar[k % MS_PA]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+    auto group = [&](int t0, auto last_c) {
+        constexpr bool LAST = decltype(last_c)::value;
+        auto step = [&](auto sc) {
+            constexpr int st = decltype(sc)::value;
+            const int t = t0 + st;
+            cbarrier();                                                       // B(t): A(t) is in buffer t & 1; every read of A(t - 1) is done
+            if constexpr (!LAST || st + 1 < MS_PW) write_a((st + 1) & 1, ar[(st + 1) % MS_PA]);   // A(t + 1) -> the other buffer
+            bf16x8_t af[8];
+            const char* abuf = smem + (st & 1) * 16384;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) af[i] = read_frag(abuf, i * 16, kh, lane);
+            if constexpr (!LAST || st + 1 + MS_PA < MS_PW) load_a(t + 1 + MS_PA, ar[(st + 1) % MS_PA]);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) acc[i][nb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wr[st][nb], af[i], acc[i][nb], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!LAST) load_w(t + MS_PW, wr[st]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // the writes of A(t + 1) (and the reads of A(t)) are done before B(t + 1)
+        };
+        step(std::integral_constant<int, 0>{});
+        step(std::integral_constant<int, 1>{});
+        step(std::integral_constant<int, 2>{});
+        step(std::integral_constant<int, 3>{});
+        step(std::integral_constant<int, 4>{});
+        step(std::integral_constant<int, 5>{});
+        step(std::integral_constant<int, 6>{});
+        step(std::integral_constant<int, 7>{});
+    };
+    static_assert(MS_PW == 8, "the group body is written out for eight steps");
+    int t0 = 0;
+    for (; t0 + MS_PW < nk; t0 += MS_PW) group(t0, std::false_type{});
+    group(t0, std::true_type{});
+
+    // ---- the pair exchanges halves: kh = 0 finishes rows 0-63 of the half, kh = 1 rows 64-127 ----
+    cbarrier();                                                               // every read of the A buffers is done: smem is free
+    {
+        char* mine = smem + wave * 8192;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const f32x4_t v = kh ? acc[i][nb] : acc[4 + i][nb];           // the rows this wave gives away
+                *reinterpret_cast<f32x4_t*>(mine + (i * 2 + nb) * 1024 + lane * 16) = v;
+            }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    cbarrier();
+    f32x4_t fin[8][2];
+    {
+        const char* theirs = smem + (wave ^ 4) * 8192;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const f32x4_t p = *reinterpret_cast<const f32x4_t*>(theirs + (i * 2 + nb) * 1024 + lane * 16);
+                const f32x4_t k = kh ? acc[4 + i][nb] : acc[i][nb];
+                fin[i][nb] = k + p;
+                fin[4 + i][nb] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            }
+    }
+    tall_fused_epilogue(tf.ep[side], fin, m0, n0 + wn * 32, kh, lane, true);
+}
+#endif
+
 // ---- GEMV for a handful of rows (M <= 4): the weight-streaming regime of small-batch decode ------------------------------
 // out[m, n] = epi(sum_k x[m, k] * W[n, k]).  One pass over W at HBM speed is the whole cost (N*K*2 bytes; x is a few KiB), so
 // the kernel is a pure streamer: a wave owns RW rows of W, every lane keeps 4 x 16-byte loads per row in flight (a 2048-wide
@@ -6339,6 +6488,13 @@ static int tall_launch(hipStream_t s, int64_t M, const TallSide& g0, const TallS
     const int wg1 = g1 ? tiles_m * (g1->N / 128) * (g1->s1 + g1->s2) : 0;
     if (fuse) {
         const int grid = fuse->half_mode ? 2 * (wg0 + wg1) : wg0 + wg1;
+#ifdef BT_DEBUG_HOOKS
+        if (fuse->half_mode == 2) {
+            hipLaunchKernelGGL(gemm_bf16_mid_stream_kernel, dim3(grid), dim3(512), 0, s, ta, (int)M, wg0, *fuse);
+            BT_LAUNCH_CHECK("mid-batch stream-form fused GEMM launch");
+            return BT_OK;
+        }
+#endif
         hipLaunchKernelGGL((gemm_bf16_mfma256x128_slab_kernel<true, true>), dim3(grid), dim3(512), 0, s, ta, (int)M, wg0, *fuse);
         BT_LAUNCH_CHECK("mid-batch 256 x 128 fused GEMM launch");
         return BT_OK;
@@ -6523,7 +6679,7 @@ int mid_qkv_gelu(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, c
         const int64_t n_tiles = ceil_div(M, 256) * ((N1 + N2) / 128);
         // 129 .. 256 rows (one row tile, two K ranges in the slab form): with fused epilogues each workgroup takes ONE 128-row half of a
         // column tile over the whole K instead -- same 224 workgroups, no hand-off (g_mid_tall_fuse == 3: off, A/B)
-        const bool halves = slices == 2 && M > 128 && M <= 256 && n_tiles % 8 == 0 && g_mid_tall_fuse != 3 && g_mid_tall_fuse != 2;
+        const bool halves = slices == 2 && M > 128 && M <= 256 && n_tiles % 8 == 0 && g_mid_tall_fuse != 3 && g_mid_tall_fuse != 2;   // (5, debug build: the stream-form experiment)
         if (g_mid_tall_fuse && counters && (slices == 1 || halves || (slices == 2 && g_mid_tall_fuse == 2 && nk >= 8)) && n_tiles < TF_STICKY && head_dim % 32 == 0 &&
             ld_qkv % 4 == 0 && I % 4 == 0 && (reinterpret_cast<uintptr_t>(qkv) & 7u) == 0 && (reinterpret_cast<uintptr_t>(h4) & 7u) == 0 &&
             (reinterpret_cast<uintptr_t>(kc) & 7u) == 0 && (reinterpret_cast<uintptr_t>(vc) & 7u) == 0 &&
@@ -6535,6 +6691,11 @@ int mid_qkv_gelu(hipStream_t s, int64_t B, int q_len, int heads, int head_dim, c
             tf.first_nk = std::max(1, nk / 2 - 2);         // the finishing workgroup runs ~4 K-tiles longer: the partner's tile is there when it looks
             if (halves) {
                 tf.half_mode = 1;
+#ifdef BT_DEBUG_HOOKS       // g_mid_tall_fuse == 5: the stream-form experiment (W global -> registers) where its unrolled groups fit
+                if (g_mid_tall_fuse == 5 && nk % MS_PW == 0 && nk >= 2 * MS_PW && aligned16(x1) && aligned16(x2) && aligned16(qkv_w) && aligned16(h4_w) &&
+                    H % 8 == 0 && K % 8 == 0)
+                    tf.half_mode = 2;
+#endif
                 g0.s1 = g1.s1 = 1;                          // one K range per (tile, half)
             }
 #ifdef BT_DEBUG_HOOKS

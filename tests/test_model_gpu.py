@@ -1829,7 +1829,9 @@ def test_mid_rows_decoder_stack_vs_fp32_oracle(M, dbg_lib):
 def test_mid_rows_fused_epilogue_launch_vs_oracle_and_reduce_launch(M, fuse, dbg_lib):
     """Round 6: the QKV + h->4h launch of the 97 .. 512-row path with its epilogues fused (bias, RoPE, K/V append, GELU in the GEMM's own
     accumulator layout; no reduce launch).  fuse = 1 is the product: fusion where a workgroup covers the whole K -- 257 .. 512 rows (two row
-    tiles) and 129 .. 256 rows (one 128-row HALF of a column tile per workgroup, phase 1 of every K-tile empty); 3 = the former only (A/B);
+    tiles) and 129 .. 256 rows (one 128-row HALF of a column tile per workgroup, one phase per K-tile -- needs a tile count that is a multiple
+    of 8, which this 512-wide stack does not have: test_mid_rows_fused_launch_at_1p2b_width_vs_oracle); 3 = fusion at 257 .. 512 rows
+    only (A/B);
     2 = instead of halves, the hand-off between a tile's two K ranges up to 256 rows (measured slower, debug A/B only: one flag per tile,
     write-through slab, bounded polls); 0 = the round-5 slab + reduce launches.  Decode step (q = 1 against a 40-row cache): hidden states and the appended K / V rows vs
     the fp32 oracle, and every setting against fuse = 0 within one bf16 rounding of the same fp32 sums; repeated to catch a flag word
@@ -1866,6 +1868,59 @@ def test_mid_rows_fused_epilogue_launch_vs_oracle_and_reduce_launch(M, fuse, dbg
     assert (k_new - k_ref).abs().max().item() <= 3e-2 * k_ref.abs().max().item() + 1e-2
     assert (v_new - v_ref).abs().max().item() <= 3e-2 * v_ref.abs().max().item() + 1e-2
     # same fp32 sums, same formulas as the reduce launch: at most one bf16 ulp apart (multiply-add contraction may differ)
+    assert (k_new - k0).abs().max().item() <= 2.0 ** -7 * k_ref.abs().max().item()
+    assert (v_new - v0).abs().max().item() <= 2.0 ** -7 * v_ref.abs().max().item()
+    assert (hid - hid0).abs().max().item() <= 3e-2 * scale + 1e-2
+
+
+_WIDE_MID_STACK = {}
+
+
+@pytest.mark.parametrize("M", [129, 200, 256])
+@pytest.mark.parametrize("fuse", [1, 5])
+def test_mid_rows_fused_launch_at_1p2b_width_vs_oracle(M, fuse, dbg_lib):
+    """Round 6: the 129 .. 256-row forms of the fused QKV + h->4h launch need a tile count that is a multiple of 8 (the two halves of a
+    column tile sit 8 block ids apart) -- the 512-wide stack of the test above never takes them.  Two layers at the 1.2B width
+    (H = 2048, 16 heads, I = 8192: 112 column tiles, 32 K-tiles): fuse = 1 = the product (half mode of the slab kernel), 5 = the stream-form
+    experiment of the debug build (gemm_bf16_mid_stream_kernel: W global -> registers, the k-steps of a K-tile split between a wave
+    pair; measured slower, kept as an A/B).  Decode step over an 8-row cache:
+    hidden states and appended K / V rows vs the fp32 oracle and vs the slab + reduce launches (fuse = 0), twice (repeatable)."""
+    if "stack" not in _WIDE_MID_STACK:
+        _WIDE_MID_STACK["stack"] = _mid_stack(layers=2, hidden=2048, heads=16, inter=8192, seed=33)
+    model, dims, o = _WIDE_MID_STACK["stack"]
+    H = dims.bd.hidden
+    g = torch.Generator().manual_seed(2000 + M)
+    past_len = 8
+    xp = (torch.randn(M, past_len, H, generator=g) * 0.5).bfloat16()
+    xs = (torch.randn(M, 1, H, generator=g) * 0.5).bfloat16()
+    ones = torch.ones(M, past_len + 1, dtype=torch.long)
+
+    def run():
+        pre = model.block_decoder(inputs_embeds=xp.to(DEV), block_attention_mask=ones[:, :past_len].to(DEV))
+        step = model.block_decoder(inputs_embeds=xs.to(DEV), block_attention_mask=ones.to(DEV), past_key_values=pre.past_key_values)
+        k, v = step.past_key_values[1]
+        return step.hidden_states[:, 0].float().cpu(), k[:, :, past_len].float().cpu(), v[:, :, past_len].float().cpu()
+
+    try:
+        dbg_lib.bt_debug_mid_tall_fuse(0)
+        hid0, k0, v0 = run()
+        dbg_lib.bt_debug_mid_tall_fuse(fuse)
+        hid, k_new, v_new = run()
+        hid_b, k_b, v_b = run()
+    finally:
+        dbg_lib.bt_debug_mid_tall_fuse(1)
+    assert torch.equal(hid, hid_b) and torch.equal(k_new, k_b) and torch.equal(v_new, v_b), "not repeatable"
+    key = ("ref", M)
+    if key not in _WIDE_MID_STACK:
+        _, past = o.block_decoder(xp.float(), ones[:, :past_len])
+        ref, kv = o.block_decoder(xs.float(), ones, past)
+        _WIDE_MID_STACK[key] = (ref[:, 0], kv[1][0][:, :, past_len], kv[1][1][:, :, past_len])
+    ref, k_ref, v_ref = _WIDE_MID_STACK[key]
+    scale = ref.abs().max().item()
+    assert (hid - ref).abs().max().item() <= 3e-2 * scale + 1e-2, (hid - ref).abs().max().item()
+    assert (k_new - k_ref).abs().max().item() <= 3e-2 * k_ref.abs().max().item() + 1e-2
+    assert (v_new - v_ref).abs().max().item() <= 3e-2 * v_ref.abs().max().item() + 1e-2
+    # same products, another summation order (k-steps split between two waves / one K range instead of two slabs): within one bf16 ulp
     assert (k_new - k0).abs().max().item() <= 2.0 ** -7 * k_ref.abs().max().item()
     assert (v_new - v0).abs().max().item() <= 2.0 ** -7 * v_ref.abs().max().item()
     assert (hid - hid0).abs().max().item() <= 3e-2 * scale + 1e-2
