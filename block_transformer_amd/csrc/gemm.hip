@@ -4061,8 +4061,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_mfma256x128_slab_kernel(const T
 // Measured SLOWER than the half-mode loop above (35.0 us per launch against 31.1 at 256 rows; with A eight K-tiles ahead as well: 36.6),
 // oracle-clean (tests/test_model_gpu.py::test_mid_rows_fused_launch_at_1p2b_width_vs_oracle).  Kept as the A/B that rules out two
 // explanations of the half mode's 0.75 us per K-tile -- LDS-DMA issue cost / barrier count (none of the former, half of the latter here)
-// and prefetch depth (4 -> 8 K-tiles changes nothing): either form moves 32 KiB per K-tile into a CU at 35-45 GB/s, the rate of the
-// CU's load path for 16-byte-per-lane loads whatever their destination (profiles/r6_mid_half_mode_ablations.md).
+// and prefetch depth (4 -> 8 K-tiles changes nothing): either form moves 32 KiB per K-tile into a CU in 0.75-0.9 us
+// (profiles/r6_mid_half_mode_ablations.md; the cause is not isolated).
 // The kernel does the same work per workgroup -- one 128-row half of a 128-column tile over the whole K, same grid, same epilogue -- with
 //   * W never in LDS: a wave streams ITS fragments global -> registers (two 16-byte loads per lane and K-tile, MS_PW K-tiles ahead), so the
 //     weight stream needs no barrier, no LDS-DMA issue and no ring slot;
